@@ -1,0 +1,44 @@
+"""
+Regenerable inputs shared by tools/gen_golden.py (which runs the reference on them)
+and the tests (which run the oracle / the HIP path on them).  Pure data generation.
+"""
+import zlib
+
+import numpy as np
+
+
+def checksum(*arrays) -> int:
+    """CRC of the raw bytes; lets tests detect drift of regenerated inputs."""
+    crc = 0
+    for a in arrays:
+        crc = zlib.crc32(np.ascontiguousarray(a).tobytes(), crc)
+    return crc
+
+
+MVNPDF_SHAPES = [(2, 3), (7, 1), (50, 5), (333, 20), (1250, 20), (3000, 20), (64, 32)]
+
+
+def mvnpdf_inputs(idx, n, k):
+    """inputs of golden set G3 (random shapes)"""
+    rng = np.random.default_rng(1000 + idx)
+    M = rng.standard_normal((n, k)) * 0.3
+    mu = rng.standard_normal(n)
+    d = 0.05 + rng.random(n)
+    y = mu + M @ rng.standard_normal(k) + np.sqrt(d) * rng.standard_normal(n)
+    return y, mu, M, d
+
+
+def raw_spectrum_and_model(seed=5, k=20):
+    """synthetic raw SDSS-like spectrum + learned model arrays for golden set G7"""
+    rng = np.random.default_rng(seed)
+    z_qso = 2.9
+    obs = 10.0 ** (3.5600 + 1e-4 * np.arange(4400))
+    rest = obs / (1 + z_qso)
+    flux = 3.0 + 0.5 * np.sin(rest / 40.0) + 0.2 * rng.standard_normal(rest.shape[0])
+    noise_variance = 0.04 * (1 + rng.random(rest.shape[0]))
+    pixel_mask = rng.random(rest.shape[0]) < 0.03
+    rest_grid = np.arange(911.75, 1215.75 + 1e-9, 0.25)
+    mu = 1 + 0.2 * np.cos(rest_grid / 30.0)
+    M = 0.1 * rng.standard_normal((rest_grid.shape[0], k)) * (0.9 ** np.arange(k))[None, :]
+    log_omega = -2.0 + 0.3 * np.sin(rest_grid / 55.0)
+    return z_qso, rest, flux, noise_variance, pixel_mask, rest_grid, mu, M, log_omega, -2.3, -5.9, 1.2

@@ -1,0 +1,121 @@
+"""
+Pins the oracle (oracle/ref_like.py) against golden vectors produced by the reference
+itself (tools/gen_golden.py) and against the reference's own known answers
+(reference tests/test_model.py:52-72, tests/test_voigt.py:8-57).  CPU only.
+"""
+import numpy as np
+import pytest
+from scipy.stats import multivariate_normal
+
+from gpy_dla_detection_amd import lyman_series as ls
+from gpy_dla_detection_amd.synthetic import make_sightline
+from oracle import ref_like as R
+from tests.conftest import load_golden, oracle_state
+from tests.golden_inputs import MVNPDF_SHAPES, checksum, mvnpdf_inputs
+
+# oracle and reference call the same BLAS/LAPACK/wofz entry points in the same order,
+# so agreement is expected at rounding level; 1e-12 relative leaves room for BLAS threading.
+RTOL = 1e-12
+
+
+def test_voigt_profile_matches_reference_grid():
+    g = load_golden("voigt_profile.npz")
+    for line in range(ls.MAX_LINES):
+        mine = R.voigt_profile(g["velocity"], ls.SIGMA_CGS, ls.LORENTZ_WIDTHS[line])
+        np.testing.assert_allclose(mine, g["profile"][line], rtol=1e-15, atol=0)
+
+
+def test_voigt_absorption_matches_reference():
+    g = load_golden("voigt_absorption.npz")
+    n_cases = g["case_z"].shape[0]
+    assert n_cases > 100
+    for i in range(n_cases):
+        grid = g["grid_" + str(g["case_grid"][i])]
+        mine = R.voigt_absorption(
+            grid,
+            10.0 ** g["case_log_nhi"][i],
+            g["case_z"][i],
+            num_lines=int(g["case_num_lines"][i]),
+            broadening=bool(g["case_broadening"][i]),
+        )
+        np.testing.assert_allclose(mine, g["out_%d" % i], rtol=1e-14, atol=1e-300)
+
+
+def test_instrumental_broadening_is_valid_convolution():
+    # reference tests/test_voigt.py:8-57: explicit 7-tap loop == np.convolve "valid"
+    for z_qso, z_dla, log_nhi, lines, npts in ((3.15, 3.1, 20.3, 3, 1000), (5.0, 4.5, 21.0, 5, 50)):
+        lam = np.linspace(911, 1216, npts) * (1 + z_qso)
+        raw = R.voigt_absorption(lam, 10.0 ** log_nhi, z_dla, num_lines=lines, broadening=False)
+        explicit = np.zeros(npts - 6)
+        for i in range(npts - 6):
+            for t in range(7):
+                explicit[i] += raw[i + t] * ls.INSTRUMENT_PROFILE[t]
+        smooth = R.voigt_absorption(lam, 10.0 ** log_nhi, z_dla, num_lines=lines, broadening=True)
+        assert np.all(np.abs(explicit - smooth) < 1e-4)
+
+
+def test_log_mvnpdf_known_answers():
+    # reference tests/test_model.py:52-72, tolerance 1e-4 there
+    mu = np.array([1, 2])
+    M = np.array([[2, 3, 1], [1, 2, 4]])
+    rv = multivariate_normal(mu, np.matmul(M, M.T) + np.eye(2) * 2)
+    g = load_golden("mvnpdf.npz")
+    for y, want in zip(([1, 2], [2, 3], [100, 100]), g["kat_out"]):
+        got = R.log_mvnpdf_low_rank(np.array(y), mu, M, np.ones(2) * 2)
+        assert abs(got - rv.logpdf(y)) < 1e-4
+        assert abs(got - want) <= RTOL * abs(want)
+
+
+@pytest.mark.parametrize("idx", range(len(MVNPDF_SHAPES)))
+def test_log_mvnpdf_random_shapes(idx):
+    g = load_golden("mvnpdf.npz")
+    n, k = MVNPDF_SHAPES[idx]
+    y, mu, M, d = mvnpdf_inputs(idx, n, k)
+    assert checksum(y, mu, M, d) == int(g["rand_input_crc"][idx]), "regenerated inputs drifted"
+    for col, lapack in ((0, True), (1, False)):
+        got = R.log_mvnpdf_low_rank(y, mu, M, d, scipy_lapack=lapack)
+        want = g["rand_out"][idx, col]
+        assert abs(got - want) <= RTOL * abs(want)
+
+
+def test_sample_log_likelihood_k_dlas():
+    g = load_golden("sample_ll.npz")
+    sight = make_sightline(int(g["sight_index"]))
+    assert checksum(sight.y, sight.this_M, sight.padded_wavelengths, sight.keep) == int(g["sight_crc"])
+    st = oracle_state(sight)
+    assert abs(R.null_log_model_evidence(st) - g["null_evidence"]) <= RTOL * abs(g["null_evidence"])
+    for kd in (1, 2, 3, 4):
+        z, nhi, want = g["z_kd%d" % kd], g["nhi_kd%d" % kd], g["out_kd%d" % kd]
+        got = np.array([R.sample_log_likelihood_k_dlas(st, z[i], nhi[i]) for i in range(0, z.shape[0], 4)])
+        np.testing.assert_allclose(got, want[::4], rtol=RTOL)
+    st_nb = oracle_state(sight, broadening=False)
+    got = np.array([R.sample_log_likelihood_k_dlas(st_nb, g["z_kd1"][i], g["nhi_kd1"][i]) for i in range(0, 64, 8)])
+    np.testing.assert_allclose(got, g["out_nobroad_kd1"][::8], rtol=RTOL)
+    st_l5 = oracle_state(sight, num_lines=5)
+    got = np.array([R.sample_log_likelihood_k_dlas(st_l5, g["z_kd2"][i], g["nhi_kd2"][i]) for i in range(0, 64, 8)])
+    np.testing.assert_allclose(got, g["out_lines5_kd2"][::8], rtol=RTOL)
+
+
+def test_log_model_evidences_small_seeded():
+    """full occupation sweep incl. the legacy-RNG resampling, on the 400-pixel sightline"""
+    g = load_golden("evidences_small.npz")
+    sight = make_sightline(int(g["sight_index"]), n_unmasked=int(g["sight_n_unmasked"]),
+                           n_masked=int(g["sight_n_masked"]), k=int(g["sight_k"]))
+    assert checksum(sight.y, sight.this_M, sight.padded_wavelengths, sight.keep) == int(g["sight_crc"])
+    st = oracle_state(sight)
+    S = int(g["S"])
+    from gpy_dla_detection_amd.samples import halton
+
+    nhi = 10.0 ** (20.0 + 3.0 * halton(S, 3))
+    np.random.seed(0)
+    ev, sll, base = R.log_model_evidences(st, g["dla_sample_z"], nhi, 4, float(g["dla_min_z_separation"]), verbose=False)
+    np.testing.assert_array_equal(base, g["dla_base_inds"])
+    np.testing.assert_allclose(ev, g["dla_evidences"], rtol=RTOL)
+    np.testing.assert_allclose(sll, g["dla_sample_ll"], rtol=RTOL, equal_nan=True)
+    assert np.array_equal(np.isnan(sll), np.isnan(g["dla_sample_ll"]))
+
+    nhi_sub = 10.0 ** (19.5 + 0.5 * halton(S, 3))
+    np.random.seed(0)
+    ev, sll, _ = R.log_model_evidences(st, g["dla_sample_z"], nhi_sub, 1, float(g["dla_min_z_separation"]), verbose=False)
+    np.testing.assert_allclose(ev, g["sub_evidences"], rtol=RTOL)
+    np.testing.assert_allclose(sll, g["sub_sample_ll"], rtol=RTOL)
