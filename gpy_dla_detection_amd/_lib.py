@@ -1,0 +1,95 @@
+"""
+ctypes binding of libdlagp_hip.so (C ABI: include/dlagp.h).
+
+This is the only place the shared library is touched.  There is no fallback: if the
+library is missing or no GPU is usable, the first evaluation raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_ssize_t, c_ubyte, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdlagp_hip.so")
+
+# error codes of include/dlagp.h
+DLAGP_OK, DLAGP_EINVAL, DLAGP_EDEVICE, DLAGP_ELINALG = 0, -1, -2, -3
+
+# every symbol include/dlagp.h declares: name -> (restype, argtypes)
+_dp = POINTER(c_double)
+SIGNATURES = {
+    "dlagp_abi_version": (c_int, []),
+    "dlagp_device_count": (c_int, []),
+    "dlagp_last_error": (c_char_p, []),
+    "dlagp_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, _dp, _dp, _dp, c_ssize_t, c_ssize_t,
+                             _dp, _dp, _dp, POINTER(c_ubyte), c_int, c_int, c_int]),
+    "dlagp_destroy": (None, [c_void_p]),
+    "dlagp_ctx_n": (c_int, [c_void_p]),
+    "dlagp_ctx_k": (c_int, [c_void_p]),
+    "dlagp_ctx_device": (c_int, [c_void_p]),
+    "dlagp_eval": (c_int, [c_void_p, c_int64, c_int, _dp, _dp, _dp]),
+    "dlagp_null": (c_int, [c_void_p, _dp]),
+    "dlagp_mvnpdf": (c_int, [c_int, c_int, _dp, _dp, _dp, c_ssize_t, c_ssize_t, _dp, _dp, c_int]),
+    "dlagp_absorption": (c_int, [c_void_p, c_int, _dp, _dp, _dp]),
+    "dlagp_eval_device": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dlagp_batch_create": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int]),
+    "dlagp_batch_destroy": (None, [c_void_p]),
+    "dlagp_batch_eval_device": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dlagp_batch_eval": (c_int, [c_void_p, c_int64, c_int, _dp, _dp, _dp]),
+    "dlagp_set_option": (c_int, [c_char_p, c_int64]),
+    "dlagp_timing_read": (c_int, [_dp, POINTER(c_int64), c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library once; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libdlagp_hip.so not found at {} -- build it with `make -C gpy_dla_detection_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback".format(LIB_PATH)
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return load().dlagp_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Map a C status to the exception the reference would raise at that point."""
+    if rc == DLAGP_OK:
+        return
+    msg = last_error()
+    if rc == DLAGP_EINVAL:
+        raise ValueError(msg)
+    if rc == DLAGP_ELINALG:
+        raise np.linalg.LinAlgError(msg)  # numpy.linalg.cholesky at reference null_gp.py:343
+    raise RuntimeError(msg)
+
+
+def as_f64(a) -> np.ndarray:
+    """contiguous float64 view/copy (the reference's tests pass integer arrays, tests/test_model.py:53-55)"""
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(_dp)
+
+
+def strided_f64(M) -> np.ndarray:
+    """float64 array usable with element strides (Fortran order is passed through without a copy)"""
+    M = np.asarray(M)
+    if M.dtype != np.float64 or any(s % 8 for s in M.strides) or any(s < 0 for s in M.strides):
+        M = np.array(M, dtype=np.float64, order="C")
+    return M

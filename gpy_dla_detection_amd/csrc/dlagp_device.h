@@ -1,0 +1,54 @@
+// Device-visible descriptors shared by the kernels and the host API (libdlagp_hip.so).
+//
+// Vocabulary:
+//   entry   one wavelength of the grid the raw absorption profile is built on
+//           (padded pixels, n_u + 6, with broadening; the n_u unmasked pixels without)
+//   pixel   one KEPT pixel i in [0, n): its absorption is the 7-tap (or 1-tap) window of raw
+//           profile values starting at entry pos[i]
+//   step    4 consecutive kept pixels = the K extent of one v_mfma_f64_16x16x4_f64
+//   tile    16 columns of the shared operand P; "w-tiles" hold vech(M_i M_i') and are weighted
+//           by a^2/d, "q-tiles" hold M_i and are weighted by a r/d
+#pragma once
+#include <stdint.h>
+
+#include "../../include/dlagp_lyman.h"
+
+#define DLAGP_TILE_COLS 16
+#define DLAGP_STEP_PIXELS 4
+#define DLAGP_TILE_DOUBLES (DLAGP_TILE_COLS * DLAGP_STEP_PIXELS) /* one (step, tile) block */
+#define DLAGP_ROW_EXTRA 8 /* trailing scalars of a partial row: [0] sum r^2/d, [1] sum log d */
+
+// One sightline, as the kernels see it.  All pointers are device pointers.
+struct SightlineDev {
+    int n;          // kept pixels
+    int n_pad;      // n rounded up to a multiple of 4 (padding pixels contribute exactly zero)
+    int nsteps;     // n_pad / 4
+    int k;          // rank of M
+    int num_entries;  // E
+    int num_lines;  // Lyman-series members
+    int ntaps;      // 7 with instrumental broadening, 1 without
+    int ntw;        // w-tiles: ceil(k (k + 1) / 2 / 16)
+    int ntq;        // q-tiles: ceil(k / 16)
+    int row_width;  // (ntw + ntq) * 16 + DLAGP_ROW_EXTRA doubles per partial row
+    const double *y;       // [n_pad]  padding: 0
+    const double *mu;      // [n_pad]  padding: 0
+    const double *omega2;  // [n_pad]  padding: 0
+    const double *v;       // [n_pad]  padding: 1  (so d = 1, log d = 0, r = 0)
+    const int *pos;        // [n_pad]  first entry of the pixel's window; padding: 0
+    const double *lam;     // [E]      observed wavelength of every entry, Angstrom
+    const double *P;       // [nsteps][ntw + ntq][4][16] shared operand, see build_shared_operand
+    double taps[DLAGP_NUM_TAPS];  // instrument profile (or {1, 0, ...})
+};
+
+// Per-line constants of the Voigt profile, identical for every sightline; lives in constant memory.
+//   velocity_l = lam * mult_l(z) - c,  mult_l(z) = c / (lambda_l (1 + z)) / 1e8   (voigt.py:299,305)
+//   x = velocity / (sqrt2 sigma),  y_l = gamma_l / (sqrt2 sigma)                  (voigt.py:247)
+//   tau_l = lc_l Re w(x + i y_l) / (sqrt(2 pi) sigma)                             (voigt.py:248,307)
+struct LineConstants {
+    double lambda_cm[DLAGP_MAX_LINES];   // transition wavelengths, cm
+    double y[DLAGP_MAX_LINES];           // damping parameter
+    double k_core[DLAGP_MAX_LINES];      // lc_l / (sqrt(2 pi) sigma)
+    double k_wing[DLAGP_MAX_LINES];      // k_core * y / sqrt(pi): prefactor of the asymptotic form
+    double inv_sqrt2_sigma;              // 1 / (sqrt2 sigma)
+    double c;                            // speed of light, cm/s
+};

@@ -1,0 +1,143 @@
+// Kernels shared by every evaluation path: the shared-operand builder and the per-sample
+// finalisation (k x k Cholesky, triangular solve, log-determinant, assembly).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dlagp_device.h"
+
+namespace dlagp {
+
+#define DLAGP_LOG_2PI 1.83787706640934534  // reference null_gp.py:325
+
+// column of B(i, j), j <= i, inside the w-tiles
+__host__ __device__ __forceinline__ int vech_col(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// ---------------------------------------------------------------------------------------------
+// Shared operand P[step][tile][4][16] of one sightline, built once at dlagp_create:
+//   w-tiles: P[i][vech_col(a, b)] = M[i][a] M[i][b]   -> B - I = sum_i w_i P_i   (null_gp.py:339)
+//   q-tiles: P[i][ntw*16 + c]     = M[i][c]           -> u     = sum_i q_i M_i   (null_gp.py:346-354)
+// Padding pixels and padding columns are zero, so they contribute exactly nothing.
+// M_dev is dense row-major [n][k].
+// ---------------------------------------------------------------------------------------------
+__global__ void build_shared_operand(const double *__restrict__ M_dev, int n, int n_pad, int k, int ntw,
+                                     int ntq, double *__restrict__ P) {
+    const int nt = ntw + ntq;
+    const long total = (long)n_pad * nt * DLAGP_TILE_COLS;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cc = idx % DLAGP_TILE_COLS;
+        const int slot = (idx / DLAGP_TILE_COLS) % DLAGP_STEP_PIXELS;
+        const int tile = (idx / DLAGP_TILE_DOUBLES) % nt;
+        const int step = idx / ((long)DLAGP_TILE_DOUBLES * nt);
+        const int i = step * DLAGP_STEP_PIXELS + slot;
+        double val = 0.0;
+        if (i < n) {
+            if (tile < ntw) {
+                const int col = tile * DLAGP_TILE_COLS + cc;
+                // invert vech_col: largest a with a (a + 1) / 2 <= col
+                int a = (int)((sqrt(8.0 * col + 1.0) - 1.0) * 0.5);
+                while ((a + 1) * (a + 2) / 2 <= col) ++a;
+                while (a * (a + 1) / 2 > col) --a;
+                const int b = col - a * (a + 1) / 2;
+                if (a < k) val = M_dev[(long)i * k + a] * M_dev[(long)i * k + b];
+            } else {
+                const int c = (tile - ntw) * DLAGP_TILE_COLS + cc;
+                if (c < k) val = M_dev[(long)i * k + c];
+            }
+        }
+        P[idx] = val;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Finalisation: one thread per sample.
+//   partial rows: part[split][row][row_width]; row = sightline * S + sample
+//   B = I + sum_splits (w-tiles),  u = sum_splits (q-tiles),
+//   L L' = B (lower, null_gp.py:343), t = L^-1 u,
+//   log p = -1/2 ( sum r^2/d - t't + sum log d + 2 sum log L_ii + n log 2pi )  (null_gp.py:354-358)
+// The reference forms K^-1 y through two explicit triangular inverses (:346-347); t't is the
+// same quantity y' D^-1 M B^-1 M' D^-1 y.  Splits are summed in index order (deterministic).
+// A non-positive pivot yields NaN and raises *status (the reference raises LinAlgError);
+// NaN inputs propagate to a NaN result without raising, as in the reference.
+// KT > 0: compile-time rank, everything in registers.  KT == 0: runtime rank, local arrays.
+// ---------------------------------------------------------------------------------------------
+#define DLAGP_FINALIZE_THREADS 64
+template <int KT>
+__global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const double *__restrict__ part, int nsplit, long rows, long S,
+                                 const SightlineDev *__restrict__ sightlines,
+                                 double *__restrict__ out, int *__restrict__ status) {
+    const long row = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const SightlineDev &sl = sightlines[row / S];
+    const int k = KT > 0 ? KT : sl.k;
+    const int rw = sl.row_width;
+    const int qbase = sl.ntw * DLAGP_TILE_COLS;
+    const int sbase = (sl.ntw + sl.ntq) * DLAGP_TILE_COLS;
+    const long split_stride = rows * (long)rw;
+    const double *p0 = part + row * (long)rw;
+
+    constexpr int KMAX = KT > 0 ? KT : DLAGP_MAX_RANK;
+    // fixed rank: unroll everything so L and t live in registers; runtime rank: keep the loops
+    constexpr int UNROLL = KT > 0 ? 4096 : 1;
+    double L[KMAX * (KMAX + 1) / 2];
+    double t[KMAX];
+
+    double sum_r2 = 0.0, sum_logd = 0.0;
+#pragma unroll UNROLL
+    for (int c = 0; c < KMAX * (KMAX + 1) / 2; ++c) {
+        if (c < k * (k + 1) / 2) {
+            double acc = 0.0;
+            for (int h = 0; h < nsplit; ++h) acc += p0[h * split_stride + c];
+            L[c] = acc;
+        }
+    }
+#pragma unroll UNROLL
+    for (int c = 0; c < KMAX; ++c) {
+        if (c < k) {
+            double acc = 0.0;
+            for (int h = 0; h < nsplit; ++h) acc += p0[h * split_stride + qbase + c];
+            t[c] = acc;
+        }
+    }
+    for (int h = 0; h < nsplit; ++h) {
+        sum_r2 += p0[h * split_stride + sbase];
+        sum_logd += p0[h * split_stride + sbase + 1];
+    }
+
+    bool bad = false;
+    double tt = 0.0, log_diag = 0.0;
+#pragma unroll UNROLL
+    for (int i = 0; i < KMAX; ++i) {
+        if (i < k) {
+#pragma unroll UNROLL
+            for (int j = 0; j <= i; ++j) {
+                double s = L[vech_col(i, j)];
+                if (j == i) s += 1.0;  // identity on the diagonal (null_gp.py:341)
+#pragma unroll UNROLL
+                for (int m = 0; m < j; ++m) s = fma(-L[vech_col(i, m)], L[vech_col(j, m)], s);
+                if (j == i) {
+                    if (s <= 0.0) bad = true;  // NaN pivots propagate silently, as LAPACK's do
+                    const double diag = sqrt(s);
+                    L[vech_col(i, i)] = diag;
+                    log_diag += log(diag);
+                    double ti = t[i];
+#pragma unroll UNROLL
+                    for (int m = 0; m < i; ++m) ti = fma(-L[vech_col(i, m)], t[m], ti);
+                    ti /= diag;
+                    t[i] = ti;
+                    tt = fma(ti, ti, tt);
+                } else {
+                    L[vech_col(i, j)] = s / L[vech_col(j, j)];
+                }
+            }
+        }
+    }
+    double result = -0.5 * ((sum_r2 - tt) + (sum_logd + 2.0 * log_diag) + sl.n * DLAGP_LOG_2PI);
+    if (bad) {
+        result = __builtin_nan("");
+        atomicOr(status, 1);
+    }
+    out[row] = result;
+}
+
+}  // namespace dlagp

@@ -1,0 +1,137 @@
+// Generic evaluation path: one 256-thread workgroup per QMC sample.
+//
+// Handles every rank k <= DLAGP_MAX_RANK, any number of Lyman lines and absorbers.  It is the
+// path for shapes the MFMA kernel does not specialise and an independent cross-check of it;
+// its structure follows the reference one sample at a time:
+//   phase A  raw profile of every absorber on the entries, instrument convolution, product
+//            (voigt.py:299-319, dla_gp.py:370-388)                      -> a[i] in LDS
+//   phase B  d = omega2 a^2 + v, r = y - mu a, w = a^2/d, q = a r/d,
+//            sum r^2/d, sum log d (dla_gp.py:392-394, null_gp.py:329-333,356)
+//   phase C  one thread per column of P: sum_i w_i P_i (B - I) and sum_i q_i M_i (u)
+// and writes one partial row [B-I | u | sum r^2/d, sum log d] for finalize_samples.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dlagp_device.h"
+#include "voigt_device.h"
+
+namespace dlagp {
+
+#define DLAGP_GENERIC_THREADS 256
+
+// Absorption vector of one sample into LDS a[0..n_pad) (padding pixels get 1).
+// raw[] is scratch of num_entries doubles; mult[] of DLAGP_MAX_LINES doubles.
+__device__ __forceinline__ void sample_absorption(const SightlineDev &sl, int kd, const double *z,
+                                                  const double *nhi, double *raw, double *a,
+                                                  double *mult) {
+    const int tid = threadIdx.x;
+    if (kd == 0) {  // null model: a = 1 exactly
+        for (int i = tid; i < sl.n_pad; i += DLAGP_GENERIC_THREADS) a[i] = 1.0;
+        __syncthreads();
+        return;
+    }
+    for (int j = 0; j < kd; ++j) {
+        const double zj = z[j];
+        const double nj = nhi[j];
+        if (tid < sl.num_lines) mult[tid] = line_multiplier(tid, zj);
+        __syncthreads();
+        for (int e = tid; e < sl.num_entries; e += DLAGP_GENERIC_THREADS) {
+            const double tau = line_optical_depth(sl.lam[e], mult, sl.num_lines);
+            raw[e] = exp(-nj * tau);  // voigt.py:309
+        }
+        __syncthreads();
+        for (int i = tid; i < sl.n_pad; i += DLAGP_GENERIC_THREADS) {
+            double conv = 1.0;
+            if (i < sl.n) {
+                const int p = sl.pos[i];
+                conv = 0.0;
+                for (int t = 0; t < sl.ntaps; ++t) conv = fma(raw[p + t], sl.taps[t], conv);  // voigt.py:319
+            }
+            a[i] = j == 0 ? conv : a[i] * conv;  // dla_gp.py:379-386
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ double block_sum(double x, double *red) {
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = x;
+    __syncthreads();
+    double total = 0.0;
+    for (int w = 0; w < DLAGP_GENERIC_THREADS / 64; ++w) total += red[w];
+    __syncthreads();
+    return total;
+}
+
+// grid: (S, nb).  Dynamic LDS: (num_entries + n_pad + MAX_LINES + 8) doubles (max over sightlines).
+__global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
+    const SightlineDev *__restrict__ sightlines, long S, int kd, const double *__restrict__ z,
+    const double *__restrict__ nhi, double *__restrict__ part, int lds_entries, int lds_pixels) {
+    extern __shared__ double lds[];
+    double *raw = lds;
+    double *a = raw + lds_entries;
+    double *mult = a + lds_pixels;
+    double *red = mult + DLAGP_MAX_LINES + 1;
+
+    const SightlineDev &sl = sightlines[blockIdx.y];
+    const long row = blockIdx.y * S + blockIdx.x;
+    const int tid = threadIdx.x;
+
+    sample_absorption(sl, kd, z + row * kd, nhi + row * kd, raw, a, mult);
+
+    // phase B: per-pixel weights; w overwrites raw[], q overwrites a[]
+    double *w = raw;
+    double sum_r2 = 0.0, sum_logd = 0.0;
+    for (int i = tid; i < sl.n_pad; i += DLAGP_GENERIC_THREADS) {
+        const double ai = a[i];
+        const double d = fma(sl.omega2[i] * ai, ai, sl.v[i]);
+        const double h = 1.0 / d;
+        const double r = fma(-sl.mu[i], ai, sl.y[i]);
+        const double rh = r * h;
+        w[i] = ai * ai * h;
+        a[i] = ai * rh;
+        sum_r2 = fma(r, rh, sum_r2);
+        sum_logd += log(d);
+    }
+    __syncthreads();
+    sum_r2 = block_sum(sum_r2, red);
+    sum_logd = block_sum(sum_logd, red);
+
+    // phase C: columns
+    const int nt = sl.ntw + sl.ntq;
+    double *prow = part + row * (long)sl.row_width;
+    for (int c = tid; c < nt * DLAGP_TILE_COLS; c += DLAGP_GENERIC_THREADS) {
+        const int tile = c / DLAGP_TILE_COLS;
+        const int cc = c % DLAGP_TILE_COLS;
+        const double *weight = tile < sl.ntw ? w : a;
+        const double *col = sl.P + (long)tile * DLAGP_TILE_DOUBLES + cc;
+        double acc = 0.0;
+        for (int step = 0; step < sl.nsteps; ++step) {
+            const double *blk = col + (long)step * nt * DLAGP_TILE_DOUBLES;
+#pragma unroll
+            for (int slot = 0; slot < DLAGP_STEP_PIXELS; ++slot)
+                acc = fma(weight[step * DLAGP_STEP_PIXELS + slot], blk[slot * DLAGP_TILE_COLS], acc);
+        }
+        prow[c] = acc;
+    }
+    if (tid == 0) {
+        prow[nt * DLAGP_TILE_COLS] = sum_r2;
+        prow[nt * DLAGP_TILE_COLS + 1] = sum_logd;
+    }
+}
+
+// Absorption vector of one sample to global memory (dlagp_absorption).  grid: 1 block.
+__global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void absorption_generic(
+    const SightlineDev *__restrict__ sightlines, int kd, const double *__restrict__ z,
+    const double *__restrict__ nhi, double *__restrict__ out, int lds_entries, int lds_pixels) {
+    extern __shared__ double lds[];
+    double *raw = lds;
+    double *a = raw + lds_entries;
+    double *mult = a + lds_pixels;
+    const SightlineDev &sl = sightlines[0];
+    sample_absorption(sl, kd, z, nhi, raw, a, mult);
+    for (int i = threadIdx.x; i < sl.n; i += DLAGP_GENERIC_THREADS) out[i] = a[i];
+}
+
+}  // namespace dlagp

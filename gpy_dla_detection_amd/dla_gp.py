@@ -1,0 +1,213 @@
+"""
+GP model with k intervening DLAs; the QMC model-evidence sweep runs on the GPU.
+
+Drop-in for the model-evidence surface of the reference class
+(gpy_dla_detection/dla_gp.py:25-472): `log_model_evidences`, `sample_log_likelihood_k_dlas`,
+`this_dla_gp`, `log_priors`, `maximum_a_posteriori`, and the side effects callers read
+(`sample_log_likelihoods`, `base_sample_inds`).
+
+What moved to the device: the body of the loop over the QMC samples (reference :132-159) --
+all `num_dla_samples` Voigt-absorbed models and low-rank Gaussian log-densities of one
+occupation level are one `dlagp_eval` call.  What stays on the host, on purpose: the
+separation masking, the log-mean-exp evidence and the posterior resampling with the legacy
+global NumPy RNG (reference :164-218), so that `np.random.seed` reproduces the reference's
+indices bit for bit.
+"""
+from typing import Tuple
+
+import numpy as np
+
+from .null_gp import NullGP
+from .set_parameters import Parameters
+
+
+class _AbsorberGP(NullGP):
+    """machinery shared by the DLA and sub-DLA models (the reference keeps two copies of it)"""
+
+    def _init_absorber(self, dla_samples, min_z_separation: float, broadening: bool) -> None:
+        self.min_z_separation = self.params.kms_to_z(min_z_separation)
+        self.dla_samples = dla_samples
+        self.broadening = broadening
+
+    def _sample_redshifts(self) -> np.ndarray:
+        raise NotImplementedError
+
+    # -- one sample ----------------------------------------------------------------------------
+    def this_dla_gp(self, z_dlas: np.ndarray, nhis: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """
+        (dla_mu, dla_M, dla_omega2): the GP with the given absorbers imprinted
+        (reference dla_gp.py:331-396).  The absorption vector comes from the device
+        (dlagp_absorption); the three products are formed on the host because callers
+        (plotting) want NumPy arrays.
+        """
+        assert len(z_dlas) == len(nhis)
+        absorption = self.device_sightline().absorption(z_dlas, nhis)
+        assert len(absorption) == len(self.this_mu)
+        return (
+            self.this_mu * absorption,
+            self.this_M * absorption[:, None],
+            self.this_omega2 * absorption ** 2,
+        )
+
+    def sample_log_likelihood_k_dlas(self, z_dlas: np.ndarray, nhis: np.ndarray) -> float:
+        """log p(y | {z_dla, N_HI}_1..k) for one parameter set (reference dla_gp.py:311-329)"""
+        assert len(z_dlas) == len(nhis)
+        if not self._stock_absorption():
+            dla_mu, dla_M, dla_omega2 = self.this_dla_gp(z_dlas, nhis)
+            return self.log_mvnpdf_low_rank(self.y, dla_mu, dla_M, dla_omega2 + self.v)
+        z = np.asarray(z_dlas, dtype=np.float64)[None, :]
+        n = np.asarray(nhis, dtype=np.float64)[None, :]
+        return float(self.device_sightline().eval(z, n)[0])
+
+    def _stock_absorption(self) -> bool:
+        # a subclass that overrides this_dla_gp (e.g. the LLS variant, reference
+        # examples/gp_find_lls.py:159-224) changes the model: honour it, one sample at a time
+        return type(self).this_dla_gp is _AbsorberGP.this_dla_gp
+
+    def _level_log_likelihoods(self, z: np.ndarray, nhi: np.ndarray) -> np.ndarray:
+        """(S, kd) parameter sets -> (S,) log-likelihoods; one device launch"""
+        if self._stock_absorption():
+            return self.device_sightline().eval(z, nhi)
+        return np.array([self.sample_log_likelihood_k_dlas(z[i], nhi[i]) for i in range(z.shape[0])])
+
+    # -- the sweep -----------------------------------------------------------------------------
+    def _sweep(self, max_dlas: int):
+        S = self.params.num_dla_samples
+        log_s = np.log(S)
+        evidences = np.full((max_dlas,), np.nan)
+        base_sample_inds = np.zeros((max_dlas - 1, S), dtype=np.int32)
+        sample_log_likelihoods = np.full((S, max_dlas), np.nan)
+
+        sample_z = np.asarray(self._sample_redshifts(), dtype=np.float64)
+        sample_nhi = np.asarray(self.dla_samples.nhi_samples, dtype=np.float64)
+
+        for level in range(max_dlas):
+            # parameters of the level's samples: the i-th QMC point plus `level` points drawn
+            # from the previous levels' posteriors (reference :135-150)
+            idx = np.concatenate([np.arange(S)[None, :], base_sample_inds[:level, :]], axis=0)  # (kd, S)
+            z = np.ascontiguousarray(sample_z[idx].T)
+            nhi = np.ascontiguousarray(sample_nhi[idx].T)
+            sample_log_likelihoods[:, level] = self._level_log_likelihoods(z, nhi) - log_s  # :155-159
+
+            if level > 0:  # reference :164-177
+                too_close = np.any(np.diff(np.sort(sample_z[idx], axis=0), axis=0) < self.min_z_separation, axis=0)
+                sample_log_likelihoods[too_close, level] = np.nan
+
+            top = np.nanmax(sample_log_likelihoods[:, level])
+            probabilities = np.exp(sample_log_likelihoods[:, level] - top)
+            evidences[level] = top + np.log(np.nanmean(probabilities)) - log_s * level  # :186-190
+
+            if level + 1 == max_dlas:
+                break
+            if np.isnan(evidences[level]):  # reference :200-206
+                print("Finish the loop earlier because NaN value in log p(D | z_QSO, {} DLAs)".format(level))
+                break
+
+            weights = probabilities
+            weights[np.isnan(weights)] = 0.0
+            base_sample_inds[level, :] = np.random.choice(  # reference :213-218, legacy global RNG
+                np.arange(S).astype(np.int32), size=S, replace=True, p=weights / weights.sum()
+            )
+
+        return evidences, sample_log_likelihoods, base_sample_inds
+
+
+class DLAGP(_AbsorberGP):
+    """
+    p(y | lambda, sigma^2, M, omega, c_0, tau_0, beta, tau_kim, beta_kim, {z_dla, log N_HI})
+
+    :param dla_samples: QMC samples (`sample_z_dlas`, `nhi_samples`, `log_nhi_samples`)
+    :param min_z_separation: minimum separation of two absorbers, km/s
+    :param broadening: apply the SDSS instrumental broadening to the Voigt profile
+    remaining parameters as in `NullGP`.
+    """
+
+    def __init__(
+        self,
+        params: Parameters,
+        prior,
+        dla_samples,
+        rest_wavelengths: np.ndarray,
+        mu: np.ndarray,
+        M: np.ndarray,
+        log_omega: np.ndarray,
+        log_c_0: float,
+        log_tau_0: float,
+        log_beta: float,
+        prev_tau_0: float = 0.0023,
+        prev_beta: float = 3.65,
+        min_z_separation: float = 3000.0,
+        broadening: bool = True,
+        device: int = 0,
+    ):
+        super().__init__(params, prior, rest_wavelengths, mu, M, log_omega, log_c_0, log_tau_0, log_beta,
+                         prev_tau_0, prev_beta, device=device)
+        self._init_absorber(dla_samples, min_z_separation, broadening)
+
+    def _sample_redshifts(self) -> np.ndarray:
+        return self.dla_samples.sample_z_dlas(self.this_wavelengths, self.z_qso)
+
+    def log_model_evidences(self, max_dlas: int) -> np.ndarray:
+        """
+        [log p(D | 1 DLA), ..., log p(D | max_dlas DLAs)] by quasi-Monte-Carlo integration
+        (reference dla_gp.py:92-225).  Stores `sample_log_likelihoods` (S, max_dlas) and
+        `base_sample_inds` (max_dlas - 1, S) for `maximum_a_posteriori`.
+        """
+        evidences, self.sample_log_likelihoods, self.base_sample_inds = self._sweep(max_dlas)
+        return evidences
+
+    def log_priors(self, z_qso: float, max_dlas: int) -> np.ndarray:
+        """log P(k DLAs | z_qso), k = 1..max_dlas, with P(>= k) = (M/N)^k (reference :398-426)"""
+        num_dlas, num_quasars = self.prior.less_ind(z_qso)
+        at_least = (num_dlas / num_quasars) ** np.arange(1, max_dlas + 1)
+        at_least[:-1] = at_least[:-1] - at_least[1:]
+        return np.log(at_least)
+
+    def maximum_a_posteriori(self):
+        """
+        MAP (z_dla, log N_HI) of every occupation level, traced back through the resampled
+        base indices (reference :428-472).  Shapes (max_dlas, max_dlas), NaN where unused.
+        """
+        best = np.nanargmax(self.sample_log_likelihoods, axis=0)
+        max_dlas = self.sample_log_likelihoods.shape[1]
+        MAP_z_dla = np.full((max_dlas, max_dlas), np.nan)
+        MAP_log_nhi = np.full((max_dlas, max_dlas), np.nan)
+        sample_z = self._sample_redshifts()
+        log_nhi = self.dla_samples.log_nhi_samples
+        for level, top in enumerate(best):
+            members = np.concatenate([[top], self.base_sample_inds[:level, top]]).astype(int)
+            MAP_z_dla[level, : level + 1] = sample_z[members]
+            MAP_log_nhi[level, : level + 1] = log_nhi[members]
+        return MAP_z_dla, MAP_log_nhi
+
+    def run_mcmc(self, *args, **kwargs):
+        raise NotImplementedError(
+            "the emcee posterior sampler (reference dla_gp.py:227-309) is outside the GPU hot path; "
+            "call sample_log_likelihood_k_dlas from your own sampler"
+        )
+
+    @classmethod
+    def from_mat(cls, params: Parameters, prior, dla_samples, min_z_separation: float = 3000.0,
+                 learned_file: str = "learned_qso_model_lyseries_variance_kim_dr9q_minus_concordance.mat",
+                 broadening: bool = True, **kwargs):
+        """Load the learned model from the MATLAB v7.3 file (reference DLAGPMAT, :475-514)."""
+        import h5py  # optional dependency
+
+        with h5py.File(learned_file, "r") as learned:
+            args = (
+                learned["rest_wavelengths"][:, 0],
+                learned["mu"][:, 0],
+                learned["M"][()].T,
+                learned["log_omega"][:, 0],
+                learned["log_c_0"][0, 0],
+                learned["log_tau_0"][0, 0],
+                learned["log_beta"][0, 0],
+            )
+        return cls(params, prior, dla_samples, *args, prev_tau_0=0.0023, prev_beta=3.65,
+                   min_z_separation=min_z_separation, broadening=broadening, **kwargs)
+
+
+def DLAGPMAT(params, prior, dla_samples, min_z_separation: float = 3000.0,
+             learned_file: str = "learned_qso_model_lyseries_variance_kim_dr9q_minus_concordance.mat",
+             broadening: bool = True):
+    return DLAGP.from_mat(params, prior, dla_samples, min_z_separation, learned_file, broadening)

@@ -1,0 +1,188 @@
+"""
+Python handles on the HBM-resident sightline contexts of libdlagp_hip.so.
+
+`DeviceSightline` owns one `dlagp_ctx` (the post-`set_data` state of one spectrum,
+reference null_gp.py:117-177, :240-242); `DeviceBatch` groups several for one launch.
+The GP classes (null_gp.py, dla_gp.py, subdla_gp.py) and bench.py call through these.
+"""
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceSightline:
+    """
+    :param y, mu, omega2, v: (n,) flux, GP mean, absorption noise, instrumental noise variance
+    :param M: (n, k) low-rank factor, any element strides
+    :param wavelengths: (n_u + 6,) padded observed wavelengths if `broadening`, else (n_u,)
+    :param keep: (n_u,) bool, True for the n kept pixels (= ~pixel_mask[ind_unmasked])
+    """
+
+    def __init__(self, y, mu, M, omega2, v, wavelengths, keep, num_lines: int = 3,
+                 broadening: bool = True, device: int = 0):
+        lib = _lib.load()
+        y, mu, omega2, v = (_lib.as_f64(a) for a in (y, mu, omega2, v))
+        wavelengths = _lib.as_f64(wavelengths)
+        M = _lib.strided_f64(M)
+        keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        if M.ndim != 2:
+            raise ValueError("M must be (n, k)")
+        n, k = M.shape
+        n_u = keep.shape[0]
+        for name, arr in (("y", y), ("mu", mu), ("omega2", omega2), ("v", v)):
+            if arr.shape != (n,):
+                raise ValueError("{} has shape {}, expected ({},)".format(name, arr.shape, n))
+        expected = n_u + 6 if broadening else n_u
+        if wavelengths.shape != (expected,):
+            raise ValueError("wavelengths has shape {}, expected ({},)".format(wavelengths.shape, expected))
+        handle = ctypes.c_void_p()
+        rc = lib.dlagp_create(
+            ctypes.byref(handle), n, n_u, k, _lib.ptr(y), _lib.ptr(mu), _lib.ptr(M),
+            M.strides[0] // 8, M.strides[1] // 8, _lib.ptr(omega2), _lib.ptr(v), _lib.ptr(wavelengths),
+            keep.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), int(num_lines), int(bool(broadening)), int(device),
+        )
+        _lib.check(rc)
+        self._handle = handle
+        self.n, self.k, self.device = n, k, int(device)
+        self.num_lines, self.broadening = int(num_lines), bool(broadening)
+
+    @classmethod
+    def from_state(cls, st, num_lines: int = 3, broadening: bool = True, device: int = 0):
+        """from any object with the reference's post-set_data attribute names"""
+        keep = getattr(st, "keep", None)
+        if keep is None:
+            keep = ~st.pixel_mask[st.ind_unmasked]
+        grid = st.padded_wavelengths if broadening else st.unmasked_wavelengths
+        return cls(st.y, st.this_mu, st.this_M, st.this_omega2, st.v, grid, keep,
+                   num_lines=num_lines, broadening=broadening, device=device)
+
+    # -- lifetime -----------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            _lib.load().dlagp_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- evaluation (host arrays) -------------------------------------------------------------
+    @staticmethod
+    def _samples(z, nhi):
+        z = _lib.as_f64(z)
+        nhi = _lib.as_f64(nhi)
+        if z.shape != nhi.shape:
+            raise ValueError("z and nhi must have the same shape")  # assert at dla_gp.py:321
+        if z.ndim == 1:
+            z, nhi = z[:, None], nhi[:, None]
+        if z.ndim != 2:
+            raise ValueError("samples must be (S,) or (S, kd)")
+        return np.ascontiguousarray(z), np.ascontiguousarray(nhi)
+
+    def eval(self, z, nhi) -> np.ndarray:
+        """log-likelihood of S samples with kd absorbers each; z, nhi: (S,) or (S, kd)"""
+        z, nhi = self._samples(z, nhi)
+        S, kd = z.shape
+        out = np.empty(S, dtype=np.float64)
+        _lib.check(_lib.load().dlagp_eval(self._handle, S, kd, _lib.ptr(z), _lib.ptr(nhi), _lib.ptr(out)))
+        return out
+
+    def null(self) -> float:
+        out = np.empty(1, dtype=np.float64)
+        _lib.check(_lib.load().dlagp_null(self._handle, _lib.ptr(out)))
+        return float(out[0])
+
+    def absorption(self, z_dlas, nhis) -> np.ndarray:
+        """absorption vector on the kept pixels for one sample (dla_gp.py:360-388)"""
+        z = _lib.as_f64(np.atleast_1d(z_dlas))
+        nhi = _lib.as_f64(np.atleast_1d(nhis))
+        if z.shape != nhi.shape or z.ndim != 1:
+            raise ValueError("z_dlas and nhis must be 1-d and of equal length")
+        out = np.empty(self.n, dtype=np.float64)
+        _lib.check(_lib.load().dlagp_absorption(self._handle, z.shape[0], _lib.ptr(z), _lib.ptr(nhi), _lib.ptr(out)))
+        return out
+
+    # -- evaluation (HBM-resident torch tensors or raw device pointers) -------------------------
+    def eval_device(self, S: int, kd: int, d_z: int, d_nhi: int, d_out: int, stream: int = 0) -> None:
+        """enqueue on `stream` (raw hipStream_t value); pointers are device addresses"""
+        _lib.check(_lib.load().dlagp_eval_device(self._handle, S, kd, d_z, d_nhi, d_out, stream))
+
+
+class DeviceBatch:
+    """Sightlines of one device evaluated by one launch sequence; arrays are [nb][S][kd]."""
+
+    def __init__(self, sightlines: Sequence[DeviceSightline]):
+        lib = _lib.load()
+        self.sightlines = list(sightlines)
+        nb = len(self.sightlines)
+        arr = (ctypes.c_void_p * nb)(*[s._handle for s in self.sightlines])
+        handle = ctypes.c_void_p()
+        _lib.check(lib.dlagp_batch_create(ctypes.byref(handle), arr, nb))
+        self._handle = handle
+        self.nb = nb
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            _lib.load().dlagp_batch_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def eval(self, z, nhi) -> np.ndarray:
+        z = _lib.as_f64(z)
+        nhi = _lib.as_f64(nhi)
+        if z.shape != nhi.shape:
+            raise ValueError("z and nhi must have the same shape")
+        if z.ndim == 2:
+            z, nhi = z[:, :, None], nhi[:, :, None]
+        if z.ndim != 3 or z.shape[0] != self.nb:
+            raise ValueError("samples must be (nb, S) or (nb, S, kd)")
+        z, nhi = np.ascontiguousarray(z), np.ascontiguousarray(nhi)
+        _, S, kd = z.shape
+        out = np.empty((self.nb, S), dtype=np.float64)
+        _lib.check(_lib.load().dlagp_batch_eval(self._handle, S, kd, _lib.ptr(z), _lib.ptr(nhi), _lib.ptr(out)))
+        return out
+
+    def eval_device(self, S: int, kd: int, d_z: int, d_nhi: int, d_out: int, stream: int = 0) -> None:
+        _lib.check(_lib.load().dlagp_batch_eval_device(self._handle, S, kd, d_z, d_nhi, d_out, stream))
+
+
+def log_mvnpdf_low_rank(y, mu, M, d, device: int = 0) -> float:
+    """stateless log N(y; mu, M M' + diag(d)) on the GPU (reference null_gp.py:307-360)"""
+    y, mu, d = (_lib.as_f64(a) for a in (y, mu, d))
+    M = _lib.strided_f64(M)
+    if M.ndim != 2:
+        raise ValueError("M must be (n, k)")
+    n, k = M.shape
+    out = np.empty(1, dtype=np.float64)
+    rc = _lib.load().dlagp_mvnpdf(n, k, _lib.ptr(y), _lib.ptr(mu), _lib.ptr(M), M.strides[0] // 8,
+                                  M.strides[1] // 8, _lib.ptr(d), _lib.ptr(out), int(device))
+    _lib.check(rc)
+    return float(out[0])
+
+
+def set_option(name: str, value: int) -> None:
+    _lib.check(_lib.load().dlagp_set_option(name.encode(), int(value)))
+
+
+def timing_read(reset: bool = True):
+    """(total accumulate-kernel milliseconds, launches) recorded while option 'timing' was on"""
+    total = ctypes.c_double()
+    launches = ctypes.c_int64()
+    _lib.check(_lib.load().dlagp_timing_read(ctypes.byref(total), ctypes.byref(launches), int(reset)))
+    return total.value, launches.value

@@ -1,0 +1,144 @@
+/*
+ * dlagp.h -- C ABI of the MI355X-native GP model-evidence sweep (libdlagp_hip.so).
+ *
+ * The reference (jibanCat/gpy_dla_detection) has no FFI; its seam is the Python method
+ * surface of NullGP / DLAGP / SubDLAGP.  Each entry point below replaces one piece of
+ * that surface.  Reference paths are relative to the reference repository root.
+ *
+ *   dlagp_create / dlagp_destroy   the state `NullGP.set_data` + `get_interp` leave on the
+ *                                  instance and that the sweep reads
+ *                                  (gpy_dla_detection/null_gp.py:117-177, :240-242)
+ *   dlagp_eval                     the body of the QMC loop: S x `sample_log_likelihood_k_dlas`
+ *                                  (dla_gp.py:132-159 -> :311-329 -> :331-396 ->
+ *                                   voigt.py:251-322 -> null_gp.py:307-360;
+ *                                   subdla_gp.py:130-157 is the same code)
+ *   dlagp_null                     `NullGP.log_model_evidence` (null_gp.py:294-305)
+ *   dlagp_mvnpdf                   `NullGP.log_mvnpdf_low_rank` staticmethod (null_gp.py:307-360)
+ *   dlagp_absorption               the absorption vector inside `this_dla_gp`
+ *                                  (dla_gp.py:360-388), from which the wrapper rebuilds
+ *                                  (dla_mu, dla_M, dla_omega2) (:392-394)
+ *   dlagp_eval_device /
+ *   dlagp_batch_*                  the same sweep on HBM-resident samples, one or many
+ *                                  sightlines per launch (the reference's per-spectrum loop,
+ *                                  run_bayes_select.py:141-189, made a batch)
+ *
+ * Conventions
+ *   - all floating point is IEEE-754 float64; `keep` is one byte per pixel (0/1)
+ *   - every function returns 0 on success, a negative DLAGP_E* code on failure; the message is
+ *     available from dlagp_last_error() (thread-local).  Nothing aborts the process.
+ *   - the caller owns all host buffers; the library copies what it needs to the device in
+ *     dlagp_create and owns that device memory until dlagp_destroy.
+ *   - a context is not thread-safe; use one per (sightline, host thread).
+ *   - there is no CPU fallback: without a usable GPU every compute call fails with DLAGP_EDEVICE.
+ */
+#ifndef DLAGP_H
+#define DLAGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLAGP_OK 0
+#define DLAGP_EINVAL (-1)  /* bad argument (shape, NULL pointer, unsupported size)          */
+#define DLAGP_EDEVICE (-2) /* no GPU, HIP runtime error, out of device memory               */
+#define DLAGP_ELINALG (-3) /* B = I + M' D^-1 M not positive definite (numpy LinAlgError)   */
+
+#define DLAGP_MAX_ABSORBERS 8 /* absorbers per sample (the reference sweeps 1..4)            */
+#define DLAGP_MAX_RANK 64     /* largest k of the low-rank factor                            */
+
+typedef struct dlagp_ctx dlagp_ctx;     /* one sightline's model + data, resident in HBM    */
+typedef struct dlagp_batch dlagp_batch; /* a launch group of sightlines on one device       */
+
+/* ABI version of this header; bumped on any signature change. */
+int dlagp_abi_version(void);
+
+/* Number of visible HIP devices (0 if none / runtime unusable). */
+int dlagp_device_count(void);
+
+/* Message of the last failure on the calling thread ("" if none). */
+const char *dlagp_last_error(void);
+
+/*
+ * Upload one sightline.
+ *   n            kept pixels (length of y, mu, omega2, v; rows of M)
+ *   n_u          unmasked pixels in the modelling window, n_u >= n      (null_gp.py:139-147)
+ *   k            rank of M, 1 <= k <= DLAGP_MAX_RANK                    (set_parameters.py:36)
+ *   M            element (i, c) at M[i * m_row_stride + c * m_col_stride] (strides in doubles;
+ *                the reference's this_M is Fortran-ordered, null_gp.py:88-93)
+ *   wavelengths  observed wavelengths (Angstrom) the absorption profile is built on:
+ *                n_u + 6 padded pixels if broadening != 0 (null_gp.py:159-177),
+ *                else the n_u unmasked pixels                           (dla_gp.py:364-367)
+ *   keep         n_u flags, keep[j] != 0 iff unmasked pixel j is a kept pixel
+ *                (= ~pixel_mask[ind_unmasked], dla_gp.py:360); exactly n flags set
+ *   num_lines    Lyman-series members in the Voigt profile, 1..31       (set_parameters.py:60)
+ *   device       HIP device ordinal
+ */
+int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const double *mu,
+                 const double *M, ptrdiff_t m_row_stride, ptrdiff_t m_col_stride,
+                 const double *omega2, const double *v, const double *wavelengths,
+                 const uint8_t *keep, int num_lines, int broadening, int device);
+
+void dlagp_destroy(dlagp_ctx *ctx);
+
+/* Shape queries (for wrappers / tests). */
+int dlagp_ctx_n(const dlagp_ctx *ctx);
+int dlagp_ctx_k(const dlagp_ctx *ctx);
+int dlagp_ctx_device(const dlagp_ctx *ctx);
+
+/*
+ * out[s] = log N(y; mu*a_s, (M*a_s)(M*a_s)' + diag(omega2*a_s^2 + v)),  s = 0..S-1, where
+ * a_s = prod_j voigt_absorption(wavelengths, nhi[s*kd+j], z[s*kd+j])[keep].
+ * Host pointers; synchronous.  1 <= kd <= DLAGP_MAX_ABSORBERS.
+ * No "- log S" Occam term is applied (the wrapper does, dla_gp.py:157-159).
+ */
+int dlagp_eval(dlagp_ctx *ctx, int64_t S, int kd, const double *z, const double *nhi,
+               double *out);
+
+/* Null-model evidence: the same density with a = 1. */
+int dlagp_null(dlagp_ctx *ctx, double *out);
+
+/* Stateless log N(y; mu, M M' + diag(d)); M strided as in dlagp_create. */
+int dlagp_mvnpdf(int n, int k, const double *y, const double *mu, const double *M,
+                 ptrdiff_t m_row_stride, ptrdiff_t m_col_stride, const double *d, double *out,
+                 int device);
+
+/* Absorption vector a[0..n) of one sample with kd absorbers (host pointers). */
+int dlagp_absorption(dlagp_ctx *ctx, int kd, const double *z, const double *nhi, double *out);
+
+/*
+ * Device-resident sweep: d_z, d_nhi ([S][kd]) and d_out ([S]) are HBM pointers on the context's
+ * device; the work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream)
+ * and NOT synchronised.  Failures of the finalisation (non-PD B) surface as NaN in d_out.
+ */
+int dlagp_eval_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, const double *d_nhi,
+                      double *d_out, void *stream);
+
+/*
+ * Batch of sightlines evaluated by one launch sequence.  All contexts must live on the same
+ * device.  Sample arrays are laid out [nb][S][kd], outputs [nb][S].
+ */
+int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb);
+void dlagp_batch_destroy(dlagp_batch *batch);
+int dlagp_batch_eval_device(dlagp_batch *batch, int64_t S, int kd, const double *d_z,
+                            const double *d_nhi, double *d_out, void *stream);
+int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, const double *nhi,
+                     double *out);
+
+/*
+ * Tuning / measurement hooks.
+ *   dlagp_set_option: "pixel_splits" (0 = automatic), "path" (0 = automatic, 1 = generic
+ *                     kernel, 2 = MFMA kernel), "timing" (1 = bracket the accumulate kernel
+ *                     of every launch with HIP events on its stream)
+ *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
+ *                     reset; synchronises the recorded events.
+ */
+int dlagp_set_option(const char *name, int64_t value);
+int dlagp_timing_read(double *total_ms, int64_t *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLAGP_H */

@@ -1,0 +1,63 @@
+"""
+CPU-side checks of the C-ABI boundary: the shared library loads, exports every symbol
+include/dlagp.h declares, and the compiled constants equal the Python tables.  No compute calls.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gpy_dla_detection_amd import _lib, lyman_series as ls
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "dlagp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dlagp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "build with `make -C gpy_dla_detection_amd/csrc`"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert _lib.load().dlagp_abi_version() == 1
+
+
+def test_lyman_header_matches_python_tables():
+    text = open(os.path.join(REPO, "include", "dlagp_lyman.h")).read()
+
+    def table(name):
+        body = re.search(name + r"\[\d+\] = \{(.*?)\};", text, flags=re.S).group(1)
+        return np.array([float.fromhex(tok) for tok in body.replace("\n", " ").split(",") if tok.strip()])
+
+    np.testing.assert_array_equal(table("DLAGP_TRANSITION_WAVELENGTHS_CM"), ls.TRANSITION_WAVELENGTHS)
+    np.testing.assert_array_equal(table("DLAGP_LEADING_CONSTANTS"), ls.LEADING_CONSTANTS)
+    np.testing.assert_array_equal(table("DLAGP_LORENTZ_WIDTHS"), ls.LORENTZ_WIDTHS)
+    np.testing.assert_array_equal(table("DLAGP_INSTRUMENT_PROFILE"), ls.INSTRUMENT_PROFILE)
+    c = float.fromhex(re.search(r"DLAGP_SPEED_OF_LIGHT_CGS (\S+)", text).group(1))
+    sigma = float.fromhex(re.search(r"DLAGP_SIGMA_CGS (\S+)", text).group(1))
+    assert c == ls.SPEED_OF_LIGHT_CGS and sigma == ls.SIGMA_CGS
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    lib = _lib.load()
+    # NULL context / bad kd are rejected before any device call
+    out = np.zeros(1)
+    assert lib.dlagp_eval(None, 1, 1, _lib.ptr(out), _lib.ptr(out), _lib.ptr(out)) == _lib.DLAGP_EINVAL
+    assert "NULL" in _lib.last_error()
+    assert lib.dlagp_set_option(b"no_such_option", 1) == _lib.DLAGP_EINVAL
+    with pytest.raises(ValueError):
+        _lib.check(_lib.DLAGP_EINVAL)
+    with pytest.raises(np.linalg.LinAlgError):
+        _lib.check(_lib.DLAGP_ELINALG)
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.DLAGP_EDEVICE)

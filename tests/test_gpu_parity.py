@@ -1,0 +1,318 @@
+"""
+Parity of the HIP path (through the C ABI, via ctypes) with the reference's golden vectors
+and with the oracle on freshly seeded inputs.  Needs a real MI355X: `pytest -m gpu`.
+
+Tolerances.  BASELINE.json asks for <= 1e-6 relative in log-likelihood and identical argmax.
+The device path sums in a different order and uses its own Faddeeva evaluation (2.7e-14 from
+wofz), so differences of ~1e-12 are expected; the tests pin RTOL_LL = 1e-9 to catch regressions
+long before the contractual 1e-6.
+"""
+import numpy as np
+import pytest
+
+from gpy_dla_detection_amd.samples import halton
+from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline
+from tests.conftest import load_golden, oracle_state
+from tests.golden_inputs import MVNPDF_SHAPES, checksum, mvnpdf_inputs
+
+pytestmark = pytest.mark.gpu
+
+RTOL_LL = 1e-9     # log-likelihoods / evidences
+RTOL_ABS = 1e-11   # absorption profile values (absolute, profile in [0, 1])
+
+
+def device_sightline(sight, **kw):
+    from gpy_dla_detection_amd.sightline import DeviceSightline
+
+    return DeviceSightline.from_state(sight, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# Voigt profile + instrument convolution (reference voigt.py:251-322), via dlagp_absorption
+# ------------------------------------------------------------------------------------------------
+def test_absorption_matches_reference_golden():
+    from gpy_dla_detection_amd.sightline import DeviceSightline
+
+    g = load_golden("voigt_absorption.npz")
+    cache = {}
+    worst = 0.0
+    for i in range(g["case_z"].shape[0]):
+        grid = g["grid_" + str(g["case_grid"][i])]
+        L, broad = int(g["case_num_lines"][i]), bool(g["case_broadening"][i])
+        key = (str(g["case_grid"][i]), L, broad)
+        if key not in cache:
+            n_u = grid.shape[0] - 6 if broad else grid.shape[0]
+            ones = np.ones(n_u)
+            cache[key] = DeviceSightline(ones, ones, np.ones((n_u, 2)), ones, ones, grid, np.ones(n_u, bool),
+                                         num_lines=L, broadening=broad)
+        got = cache[key].absorption([g["case_z"][i]], [10.0 ** g["case_log_nhi"][i]])
+        want = g["out_%d" % i]
+        worst = max(worst, np.max(np.abs(got - want)))
+        np.testing.assert_allclose(got, want, rtol=0, atol=RTOL_ABS)
+    assert worst < RTOL_ABS
+
+
+def test_absorption_of_several_absorbers_is_the_product():
+    sight = make_sightline(0, n_unmasked=500, n_masked=13)
+    dev = device_sightline(sight)
+    z, _, nhi = make_qmc_samples(sight, 6)
+    single = [dev.absorption([z[j]], [nhi[j]]) for j in range(3)]
+    np.testing.assert_allclose(dev.absorption(z[:3], nhi[:3]), single[0] * single[1] * single[2], rtol=1e-14)
+    from oracle import ref_like as R
+
+    want = R.voigt_absorption(sight.padded_wavelengths, nhi[4], z[4])[sight.keep]
+    np.testing.assert_allclose(dev.absorption([z[4]], [nhi[4]]), want, rtol=0, atol=RTOL_ABS)
+
+
+# ------------------------------------------------------------------------------------------------
+# low-rank Gaussian log-density (reference null_gp.py:307-360), via dlagp_mvnpdf
+# ------------------------------------------------------------------------------------------------
+def test_log_mvnpdf_reference_known_answers():
+    # reference tests/test_model.py:52-72, integer inputs, tolerance 1e-4 there
+    from scipy.stats import multivariate_normal
+
+    from gpy_dla_detection_amd.null_gp import NullGP
+
+    g = load_golden("mvnpdf.npz")
+    mu = np.array([1, 2])
+    M = np.array([[2, 3, 1], [1, 2, 4]])
+    rv = multivariate_normal(mu, np.matmul(M, M.T) + np.eye(2) * 2)
+    for y, want in zip(([1, 2], [2, 3], [100, 100]), g["kat_out"]):
+        got = NullGP.log_mvnpdf_low_rank(np.array(y), mu, M, np.ones(2) * 2)
+        assert abs(got - np.log(rv.pdf(y))) < 1e-4 or rv.pdf(y) == 0
+        assert abs(got - want) <= RTOL_LL * abs(want)
+
+
+@pytest.mark.parametrize("idx", range(len(MVNPDF_SHAPES)))
+def test_log_mvnpdf_random_shapes(idx):
+    from gpy_dla_detection_amd.sightline import log_mvnpdf_low_rank
+
+    g = load_golden("mvnpdf.npz")
+    n, k = MVNPDF_SHAPES[idx]
+    y, mu, M, d = mvnpdf_inputs(idx, n, k)
+    assert checksum(y, mu, M, d) == int(g["rand_input_crc"][idx])
+    want = g["rand_out"][idx, 0]
+    for layout in (M, np.asfortranarray(M)):  # the reference's this_M is Fortran-ordered
+        got = log_mvnpdf_low_rank(y, mu, layout, d)
+        assert abs(got - want) <= RTOL_LL * abs(want)
+
+
+def test_log_mvnpdf_not_positive_definite_raises_linalgerror():
+    from gpy_dla_detection_amd.sightline import log_mvnpdf_low_rank
+
+    y, mu, M, d = mvnpdf_inputs(2, 50, 5)
+    with pytest.raises(np.linalg.LinAlgError):
+        log_mvnpdf_low_rank(y, mu, M * 10.0, -np.abs(d))  # I + M' D^-1 M indefinite
+
+
+# ------------------------------------------------------------------------------------------------
+# per-sample likelihoods (reference dla_gp.py:311-396)
+# ------------------------------------------------------------------------------------------------
+def test_sample_log_likelihoods_match_reference_golden():
+    g = load_golden("sample_ll.npz")
+    sight = make_sightline(int(g["sight_index"]))
+    assert checksum(sight.y, sight.this_M, sight.padded_wavelengths, sight.keep) == int(g["sight_crc"])
+    dev = device_sightline(sight)
+    assert abs(dev.null() - g["null_evidence"]) <= RTOL_LL * abs(g["null_evidence"])
+    for kd in (1, 2, 3, 4):
+        got = dev.eval(g["z_kd%d" % kd], g["nhi_kd%d" % kd])
+        np.testing.assert_allclose(got, g["out_kd%d" % kd], rtol=RTOL_LL)
+    got = device_sightline(sight, broadening=False).eval(g["z_kd1"], g["nhi_kd1"])
+    np.testing.assert_allclose(got, g["out_nobroad_kd1"], rtol=RTOL_LL)
+    got = device_sightline(sight, num_lines=5).eval(g["z_kd2"], g["nhi_kd2"])
+    np.testing.assert_allclose(got, g["out_lines5_kd2"], rtol=RTOL_LL)
+
+
+@pytest.mark.parametrize("shape", [dict(index=5, n_unmasked=401, n_masked=10, k=20),
+                                   dict(index=6, n_unmasked=777, n_masked=0, k=7),
+                                   dict(index=7, n_unmasked=130, n_masked=40, k=33)])
+def test_against_oracle_on_fresh_inputs(shape):
+    """seeded inputs that are not in the golden set: ragged n, other ranks, heavy masking"""
+    from oracle import ref_like as R
+
+    sight = make_sightline(**shape)
+    st = oracle_state(sight)
+    dev = device_sightline(sight)
+    z, _, nhi = make_qmc_samples(sight, 48)
+    rng = np.random.default_rng(3)
+    assert abs(dev.null() - R.null_log_model_evidence(st)) <= RTOL_LL * abs(R.null_log_model_evidence(st))
+    for kd in (1, 3):
+        zz = np.stack([z] + [z[rng.permutation(48)] for _ in range(kd - 1)], axis=1)
+        nn = np.stack([nhi] + [nhi[rng.permutation(48)] for _ in range(kd - 1)], axis=1)
+        want = np.array([R.sample_log_likelihood_k_dlas(st, zz[i], nn[i]) for i in range(48)])
+        np.testing.assert_allclose(dev.eval(zz, nn), want, rtol=RTOL_LL)
+
+
+# ------------------------------------------------------------------------------------------------
+# the occupation sweep through the drop-in classes (reference dla_gp.py:92-225, subdla_gp.py:90-222)
+# ------------------------------------------------------------------------------------------------
+class FixedPrior:
+    def less_ind(self, z_qso):
+        return 731.0, 9265.0
+
+
+def build_models(sight, S):
+    """NullGP / SubDLAGP / DLAGP of this package with a synthetic sightline's state installed"""
+    from gpy_dla_detection_amd.dla_gp import DLAGP
+    from gpy_dla_detection_amd.null_gp import NullGP
+    from gpy_dla_detection_amd.samples import DLASamples, SubDLASamples
+    from gpy_dla_detection_amd.set_parameters import Parameters
+    from gpy_dla_detection_amd.subdla_gp import SubDLAGP
+
+    params = Parameters(num_dla_samples=S, k=sight.k)
+    rest = np.linspace(911.75, 1215.75, 5)
+    learned = (rest, np.ones(5), np.ones((5, sight.k)), np.zeros(5), 0.0, 0.0, 0.0)
+    prior = FixedPrior()
+    u = halton(S, 3)
+    models = [
+        NullGP(params, prior, *learned),
+        SubDLAGP(params, prior, SubDLASamples(params, prior, halton(S, 2), 19.5 + 0.5 * u, Z_dla=1.0, Z_lls=0.25), *learned),
+        DLAGP(params, prior, DLASamples(params, prior, halton(S, 2), 20.0 + 3.0 * u), *learned),
+    ]
+    n_u = sight.unmasked_wavelengths.shape[0]
+    for gp in models:
+        gp.y, gp.v = sight.y, sight.v
+        gp.this_mu, gp.this_M, gp.this_omega2 = sight.this_mu, sight.this_M, sight.this_omega2
+        gp.padded_wavelengths = sight.padded_wavelengths
+        gp.unmasked_wavelengths = sight.unmasked_wavelengths
+        gp.this_wavelengths = sight.this_wavelengths
+        gp.ind_unmasked = np.ones(n_u, dtype=bool)
+        gp.pixel_mask = ~sight.keep
+        gp.z_qso = sight.z_qso
+    return models
+
+
+@pytest.mark.parametrize("tag", ["small", "full", "full2k"])
+def test_log_model_evidences_match_reference_golden(tag):
+    g = load_golden("evidences_%s.npz" % tag)
+    kwargs = {k[len("sight_"):]: int(g[k]) for k in g.files if k.startswith("sight_") and k != "sight_crc"}
+    sight = make_sightline(**kwargs)
+    assert checksum(sight.y, sight.this_M, sight.padded_wavelengths, sight.keep) == int(g["sight_crc"])
+    null, sub, dla = build_models(sight, int(g["S"]))
+
+    assert abs(null.log_model_evidence() - g["null_evidence"]) <= RTOL_LL * abs(g["null_evidence"])
+
+    np.random.seed(0)
+    ev = dla.log_model_evidences(4)
+    np.testing.assert_allclose(dla.dla_samples.sample_z_dlas(dla.this_wavelengths, dla.z_qso), g["dla_sample_z"], rtol=1e-15)
+    np.testing.assert_array_equal(dla.base_sample_inds, g["dla_base_inds"])
+    assert dla.base_sample_inds.dtype == np.int32
+    np.testing.assert_allclose(ev, g["dla_evidences"], rtol=RTOL_LL)
+    assert np.array_equal(np.isnan(dla.sample_log_likelihoods), np.isnan(g["dla_sample_ll"]))
+    np.testing.assert_allclose(dla.sample_log_likelihoods, g["dla_sample_ll"], rtol=RTOL_LL, equal_nan=True)
+    assert int(np.argmax(ev)) == int(np.argmax(g["dla_evidences"]))
+    MAP_z, MAP_l = dla.maximum_a_posteriori()
+    np.testing.assert_allclose(MAP_z, g["dla_map_z"], rtol=1e-14, equal_nan=True)
+    np.testing.assert_allclose(MAP_l, g["dla_map_log_nhi"], rtol=1e-14, equal_nan=True)
+
+    np.random.seed(0)
+    ev_sub = sub.log_model_evidences(1)
+    np.testing.assert_allclose(ev_sub, g["sub_evidences"], rtol=RTOL_LL)
+    np.testing.assert_allclose(sub.sample_log_likelihoods, g["sub_sample_ll"], rtol=RTOL_LL)
+
+
+def test_model_selection_matches_reference_golden():
+    from gpy_dla_detection_amd.bayesian_model_selection import BayesModelSelect
+
+    g = load_golden("model_selection.npz")
+    sight = make_sightline(1, n_unmasked=400, n_masked=9)
+    assert checksum(sight.y, sight.this_M) == int(g["sight_crc"])
+    models = build_models(sight, int(g["S"]))
+    bayes = BayesModelSelect([0, 1, 4], 2)
+    np.random.seed(0)
+    log_post = bayes.model_selection(models, sight.z_qso)
+    np.testing.assert_allclose(bayes.log_priors, g["log_priors"], rtol=1e-13)
+    np.testing.assert_allclose(bayes.log_likelihoods, g["log_likelihoods"], rtol=RTOL_LL)
+    np.testing.assert_allclose(log_post, g["log_posteriors"], rtol=RTOL_LL)
+    assert int(np.argmax(log_post)) == int(np.argmax(g["log_posteriors"]))  # identical model selection
+    np.testing.assert_allclose(bayes.model_posteriors, g["model_posteriors"], rtol=1e-6, atol=1e-12)
+    assert abs(bayes.p_dla - g["p_dla"]) < 1e-9
+
+
+def test_set_data_pipeline_matches_reference_golden():
+    """f1 row: NullGP.set_data / get_interp on the host, then the null evidence on the device"""
+    from gpy_dla_detection_amd.null_gp import NullGP
+    from gpy_dla_detection_amd.set_parameters import Parameters
+    from tests.golden_inputs import raw_spectrum_and_model
+
+    g = load_golden("set_data.npz")
+    z_qso, rest, flux, nv, mask, rest_grid, mu, M, log_omega, lc0, lt0, lb = raw_spectrum_and_model()
+    gp = NullGP(Parameters(), FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb)
+    gp.set_data(rest, flux, nv, mask, z_qso, normalize=True, build_model=True)
+    assert abs(gp.log_model_evidence() - g["null_evidence"]) <= RTOL_LL * abs(g["null_evidence"])
+
+
+# ------------------------------------------------------------------------------------------------
+# interface behaviour and edge cases
+# ------------------------------------------------------------------------------------------------
+def test_edge_cases_and_errors():
+    sight = make_sightline(3, n_unmasked=203, n_masked=4, k=20)  # n = 199, not a multiple of 4
+    dev = device_sightline(sight)
+    z, _, nhi = make_qmc_samples(sight, 5)
+    assert dev.eval(z[:0], nhi[:0]).shape == (0,)                 # empty sweep
+    one = dev.eval(z[:1], nhi[:1])
+    assert one.shape == (1,) and np.isfinite(one[0])
+    # a vanishing column density leaves the null model (to convolution rounding)
+    assert abs(dev.eval(z[:1], [0.0])[0] - dev.null()) <= 1e-12 * abs(dev.null())
+    # saturated absorber: a = 0 on part of the spectrum, still finite
+    assert np.isfinite(dev.eval(z[:1], [1e23])[0])
+    with pytest.raises(ValueError):
+        dev.eval(z[:3], nhi[:2])                                   # assert at reference dla_gp.py:321
+    with pytest.raises(ValueError):
+        dev.eval(np.zeros((2, 9)), np.zeros((2, 9)))               # more absorbers than supported
+    from gpy_dla_detection_amd.sightline import DeviceSightline
+
+    with pytest.raises(ValueError):                                # mask selects a different number of pixels
+        DeviceSightline(sight.y, sight.this_mu, sight.this_M, sight.this_omega2, sight.v,
+                        sight.padded_wavelengths, np.ones_like(sight.keep))
+    # NaN handling follows the reference: a NaN redshift is dropped by np.nansum (voigt.py:309),
+    # leaving the null model; a NaN column density propagates to a NaN likelihood
+    assert abs(dev.eval([np.nan], [1e20])[0] - dev.null()) <= 1e-12 * abs(dev.null())
+    assert np.isnan(dev.eval(z[:1], [np.nan])[0])
+
+
+def test_batch_equals_single_sightline_launches():
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    sights = [make_sightline(i, n_unmasked=n_u, n_masked=m) for i, (n_u, m) in enumerate([(300, 5), (411, 0), (257, 30)])]
+    devs = [device_sightline(s) for s in sights]
+    S = 40
+    zs, ns = [], []
+    for s in sights:
+        z, _, nhi = make_qmc_samples(s, S)
+        zs.append(np.stack([z, z[::-1]], axis=1))
+        ns.append(np.stack([nhi, nhi[::-1]], axis=1))
+    batch = DeviceBatch(devs)
+    got = batch.eval(np.stack(zs), np.stack(ns))
+    for b, dev in enumerate(devs):
+        np.testing.assert_array_equal(got[b], dev.eval(zs[b], ns[b]))
+
+
+def test_full_size_properties():
+    """BASELINE config 2 (n = 3000, k = 20, S = 10 000): size-independent properties"""
+    sight = make_sightline(1)
+    dev = device_sightline(sight)
+    S = 10000
+    z, log_nhi, nhi = make_qmc_samples(sight, S)
+    ll = dev.eval(z, nhi)
+    assert ll.shape == (S,) and np.all(np.isfinite(ll))
+    # (1) order independence: a permuted sweep returns the permuted results bit for bit
+    perm = np.random.default_rng(0).permutation(S)
+    np.testing.assert_array_equal(dev.eval(z[perm], nhi[perm]), ll[perm])
+    # (2) the best sample sits on the injected absorber
+    best = int(np.argmax(ll))
+    assert abs(z[best] - sight.injected_z[0]) < 0.02 and abs(log_nhi[best] - sight.injected_log_nhi[0]) < 0.4
+    # (3) absorbers commute; a second absorber of zero column density changes nothing
+    sub = slice(0, 512)
+    two = dev.eval(np.stack([z[sub], z[sub][::-1]], 1), np.stack([nhi[sub], nhi[sub][::-1]], 1))
+    swapped = dev.eval(np.stack([z[sub][::-1], z[sub]], 1), np.stack([nhi[sub][::-1], nhi[sub]], 1))
+    np.testing.assert_allclose(two, swapped, rtol=1e-12)
+    ghost = dev.eval(np.stack([z[sub], z[sub][::-1]], 1), np.stack([nhi[sub], np.zeros(512)], 1))
+    np.testing.assert_allclose(ghost, ll[sub], rtol=1e-12)
+    # (4) spot-check against the oracle on a strided subset
+    from oracle import ref_like as R
+
+    st = oracle_state(sight)
+    pick = np.arange(0, S, 500)
+    want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in pick])
+    np.testing.assert_allclose(ll[pick], want, rtol=RTOL_LL)
