@@ -21,7 +21,7 @@
 // One sightline, as the kernels see it.  All pointers are device pointers.
 struct SightlineDev {
     int n;          // kept pixels
-    int n_pad;      // n rounded up to a multiple of 4 (padding pixels contribute exactly zero)
+    int n_pad;      // n rounded up to a multiple of 8 (padding pixels contribute exactly zero)
     int nsteps;     // n_pad / 4
     int k;          // rank of M
     int num_entries;  // E
@@ -34,7 +34,7 @@ struct SightlineDev {
     const double *mu;      // [n_pad]  padding: 0
     const double *omega2;  // [n_pad]  padding: 0
     const double *v;       // [n_pad]  padding: 1  (so d = 1, log d = 0, r = 0)
-    const int *pos;        // [n_pad]  first entry of the pixel's window; padding: 0
+    const int *pos;        // [n_pad]  first entry of the pixel's window; padding: pos[n - 1]
     const double *lam;     // [E]      observed wavelength of every entry, Angstrom
     const double *P;       // [nsteps][ntw + ntq][4][16] shared operand, see build_shared_operand
     double taps[DLAGP_NUM_TAPS];  // instrument profile (or {1, 0, ...})
@@ -49,6 +49,9 @@ struct LineConstants {
     double y[DLAGP_MAX_LINES];           // damping parameter
     double k_core[DLAGP_MAX_LINES];      // lc_l / (sqrt(2 pi) sigma)
     double k_wing[DLAGP_MAX_LINES];      // k_core * y / sqrt(pi): prefactor of the asymptotic form
+    // far wing, everything folded: tau_l = u W_l(u), u = 1/x^2,
+    // W_l(u) = k_wing [A(u) - y^2 u (1 + 5u + 26.25u^2)], A = degree-5 fit (faddeeva_table.h)
+    double wing[DLAGP_MAX_LINES][6];
     double inv_sqrt2_sigma;              // 1 / (sqrt2 sigma)
     double c;                            // speed of light, cm/s
 };

@@ -9,6 +9,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -17,6 +19,7 @@
 #include "dlagp_device.h"
 #include "kernels_common.h"
 #include "kernels_generic.h"
+#include "kernels_mfma.h"
 #include "voigt_device.h"
 
 using namespace dlagp;
@@ -82,6 +85,10 @@ static int ensure_device(int device) {
         lc.y[l] = DLAGP_LORENTZ_WIDTHS[l] / sqrt2_sigma;
         lc.k_core[l] = DLAGP_LEADING_CONSTANTS[l] / sqrt_2pi_sigma;
         lc.k_wing[l] = lc.k_core[l] * lc.y[l] / std::sqrt(M_PI);
+        const double a[DLAGP_WING_DEGREE + 1] = DLAGP_WING_COEF_INIT;
+        const double y2 = lc.y[l] * lc.y[l];
+        const double corr[DLAGP_WING_DEGREE + 1] = {0.0, 1.0, 5.0, 26.25, 0.0, 0.0};
+        for (int m = 0; m <= DLAGP_WING_DEGREE; ++m) lc.wing[l][m] = lc.k_wing[l] * (a[m] - y2 * corr[m]);
     }
     lc.inv_sqrt2_sigma = 1.0 / sqrt2_sigma;
     lc.c = DLAGP_SPEED_OF_LIGHT_CGS;
@@ -116,59 +123,208 @@ struct DeviceBuffer {
     }
 };
 
-// scratch shared by the launches of one context / batch
+// scratch shared by the launches of one launch group
 struct Workspace {
     DeviceBuffer part;    // partial rows [nsplit][rows][row_width]
     DeviceBuffer status;  // int flag raised by finalize on a non-PD pivot
+    DeviceBuffer prep;    // per-(sample, absorber) multipliers + column density (MFMA path)
     DeviceBuffer z, nhi, out;  // staging for the host-pointer entry points
     void release() {
         part.release();
         status.release();
+        prep.release();
         z.release();
         nhi.release();
         out.release();
     }
 };
 
-struct dlagp_ctx {
-    int device = 0;
-    SightlineDev sl{};         // host copy of the descriptor (device pointers inside)
-    DeviceBuffer d_sl;         // the same descriptor in HBM (table of one)
-    DeviceBuffer y, mu, omega2, v, pos, lam, P;
-    Workspace ws;
+// pass / split tables of one sightline for one split count (MFMA path)
+struct SightlinePlan {
+    DeviceBuffer passes;  // PassDesc[npasses]
+    DeviceBuffer splits;  // int2[nsplit]: pass range of every split
+    int npasses = 0;
 };
 
-struct dlagp_batch {
+// the tables of every sightline of a launch group, as device arrays of device pointers
+struct GroupPlan {
+    DeviceBuffer pass_ptrs, split_ptrs;
+};
+
+struct dlagp_ctx;
+
+// one or more sightlines evaluated by one launch sequence
+struct LaunchGroup {
     int device = 0;
     std::vector<dlagp_ctx *> ctxs;
     DeviceBuffer d_table;  // SightlineDev[nb]
-    int max_entries = 0, max_npad = 0;
-    bool uniform_rank = true;
-    int k = 0, row_width = 0;
+    int k = 0, row_width = 0, num_lines = 0;
+    int max_entries = 0, max_npad = 0, max_chunks = 0;
+    bool mfma_ok = false;
     Workspace ws;
+    std::map<int, std::unique_ptr<GroupPlan>> plans;
+    void release() {
+        d_table.release();
+        ws.release();
+        for (auto &kv : plans) {
+            kv.second->pass_ptrs.release();
+            kv.second->split_ptrs.release();
+        }
+        plans.clear();
+    }
 };
+
+struct dlagp_ctx {
+    int device = 0;
+    int user_k = 0;            // rank the caller passed (k <= 20 is zero-padded to 20 internally)
+    SightlineDev sl{};         // host copy of the descriptor (device pointers inside)
+    DeviceBuffer y, mu, omega2, v, pos, lam, P;
+    std::vector<int> h_pos;    // host copy of pos[], for planning
+    bool mfma_ok = false;      // rank padded to 20 and every 8-pixel chunk fits one 64-entry pass
+    std::map<int, std::unique_ptr<SightlinePlan>> plans;
+    LaunchGroup self;          // the group {this}
+};
+
+struct dlagp_batch {
+    LaunchGroup group;
+};
+
+// ------------------------------------------------------------------------------------------------
+// planning: splits = equal ranges of 8-pixel chunks; passes = runs of <= 7 chunks whose
+// convolution windows fit in 64 consecutive entries (kernels_mfma.h)
+// ------------------------------------------------------------------------------------------------
+static bool plan_passes(const std::vector<int> &pos, int n_pad, int ntaps, int nsplit,
+                        std::vector<PassDesc> &passes, std::vector<int2> &splits) {
+    const int nchunks = n_pad / DLAGP_CHUNK_PIXELS;
+    passes.clear();
+    splits.assign(nsplit, int2{0, 0});
+    for (int h = 0; h < nsplit; ++h) {
+        const int c0 = (int)((long)h * nchunks / nsplit);
+        const int c1 = (int)((long)(h + 1) * nchunks / nsplit);
+        splits[h].x = (int)passes.size();
+        int c = c0;
+        while (c < c1) {
+            PassDesc pd{pos[c * DLAGP_CHUNK_PIXELS], c, 0, 0};
+            while (c + pd.nchunks < c1 && pd.nchunks < DLAGP_MAX_PASS_CHUNKS &&
+                   pos[(c + pd.nchunks) * DLAGP_CHUNK_PIXELS + DLAGP_CHUNK_PIXELS - 1] + ntaps <=
+                       pd.entry_start + DLAGP_PASS_ENTRIES)
+                ++pd.nchunks;
+            if (pd.nchunks == 0) return false;  // a single chunk spans more than 64 entries
+            passes.push_back(pd);
+            c += pd.nchunks;
+        }
+        splits[h].y = (int)passes.size();
+    }
+    return true;
+}
+
+static int sightline_plan(dlagp_ctx *ctx, int nsplit, SightlinePlan **out) {
+    auto it = ctx->plans.find(nsplit);
+    if (it != ctx->plans.end()) {
+        *out = it->second.get();
+        return DLAGP_OK;
+    }
+    std::vector<PassDesc> passes;
+    std::vector<int2> splits;
+    if (!plan_passes(ctx->h_pos, ctx->sl.n_pad, ctx->sl.ntaps, nsplit, passes, splits))
+        return fail(DLAGP_EINVAL, "pixel mask too ragged for the MFMA path");
+    std::unique_ptr<SightlinePlan> plan(new SightlinePlan());
+    int rc = plan->passes.reserve(std::max<size_t>(1, passes.size()) * sizeof(PassDesc));
+    if (!rc) rc = plan->splits.reserve(splits.size() * sizeof(int2));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(plan->passes.ptr, passes.data(), passes.size() * sizeof(PassDesc), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(plan->splits.ptr, splits.data(), splits.size() * sizeof(int2), hipMemcpyHostToDevice));
+    plan->npasses = (int)passes.size();
+    *out = plan.get();
+    ctx->plans[nsplit] = std::move(plan);
+    return DLAGP_OK;
+}
+
+static int group_plan(LaunchGroup &g, int nsplit, GroupPlan **out) {
+    auto it = g.plans.find(nsplit);
+    if (it != g.plans.end()) {
+        *out = it->second.get();
+        return DLAGP_OK;
+    }
+    std::vector<const PassDesc *> pp;
+    std::vector<const int2 *> sp;
+    for (dlagp_ctx *ctx : g.ctxs) {
+        SightlinePlan *plan = nullptr;
+        int rc = sightline_plan(ctx, nsplit, &plan);
+        if (rc) return rc;
+        pp.push_back(plan->passes.as<PassDesc>());
+        sp.push_back(plan->splits.as<int2>());
+    }
+    std::unique_ptr<GroupPlan> gp(new GroupPlan());
+    int rc = gp->pass_ptrs.reserve(pp.size() * sizeof(void *));
+    if (!rc) rc = gp->split_ptrs.reserve(sp.size() * sizeof(void *));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(gp->pass_ptrs.ptr, pp.data(), pp.size() * sizeof(void *), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(gp->split_ptrs.ptr, sp.data(), sp.size() * sizeof(void *), hipMemcpyHostToDevice));
+    *out = gp.get();
+    g.plans[nsplit] = std::move(gp);
+    return DLAGP_OK;
+}
+
+// Number of pixel splits: enough workgroups to fill the chip (256 CUs x 2 resident workgroups)
+// a few times over, a multiple of 8 when splitting at all (blocks that share an XCD then share
+// a slice of P), and never finer than 2 chunks per split.
+static int choose_splits(const LaunchGroup &g, int64_t S) {
+    if (g_opt_pixel_splits > 0) return (int)std::min<int64_t>(g_opt_pixel_splits, std::max(1, g.max_chunks));
+    const long groups = (long)g.ctxs.size() * ((S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP);
+    const long target = 4 * 512;
+    if (groups >= target) return 1;
+    long h = (target + groups - 1) / groups;
+    h = (h + 7) / 8 * 8;
+    const long max_h = std::max(1, g.max_chunks / 2);
+    if (h > max_h) h = max_h >= 8 ? max_h / 8 * 8 : max_h;
+    return (int)std::max<long>(1, h);
+}
 
 // ------------------------------------------------------------------------------------------------
 // launch sequence common to single-sightline and batch evaluation
 // ------------------------------------------------------------------------------------------------
-struct LaunchShape {
-    const SightlineDev *d_table;
-    int nb;
-    int k;          // common rank
-    int row_width;  // common partial-row width
-    int max_entries, max_npad;
-};
+template <int LINES, bool MULTI>
+static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, GroupPlan *gp, int nsplit,
+                        long S, int kd, const double *prep, double *part, long rows) {
+    hipLaunchKernelGGL((accumulate_mfma<LINES, MULTI>), grid, dim3(DLAGP_MFMA_THREADS), 0, stream, table,
+                       gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S, kd, prep,
+                       part, rows);
+}
 
-static int launch_sweep(const LaunchShape &shape, Workspace &ws, int64_t S, int kd, const double *d_z,
-                        const double *d_nhi, double *d_out, hipStream_t stream) {
+static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, const double *d_nhi,
+                        double *d_out, hipStream_t stream) {
     if (S <= 0) return DLAGP_OK;
-    const long rows = (long)shape.nb * S;
-    const int nsplit = 1;
-    int rc = ws.part.reserve((size_t)nsplit * rows * shape.row_width * sizeof(double));
+    Workspace &ws = g.ws;
+    const int nb = (int)g.ctxs.size();
+    const long rows = (long)nb * S;
+    const SightlineDev *table = g.d_table.as<SightlineDev>();
+
+    bool use_mfma = g.mfma_ok && kd >= 1;
+    if (g_opt_path == 1) use_mfma = false;
+    if (g_opt_path == 2 && kd >= 1) {
+        if (!g.mfma_ok) return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (rank > 20 or ragged mask)");
+        use_mfma = true;
+    }
+    const int nsplit = use_mfma ? choose_splits(g, S) : 1;
+
+    int rc = ws.part.reserve((size_t)nsplit * rows * g.row_width * sizeof(double));
     if (rc) return rc;
     rc = ws.status.reserve(sizeof(int));
     if (rc) return rc;
+    GroupPlan *gp = nullptr;
+    if (use_mfma) {
+        if ((rc = group_plan(g, nsplit, &gp))) return rc;
+        if ((rc = ws.prep.reserve((size_t)rows * kd * (g.num_lines + 1) * sizeof(double)))) return rc;
+    }
     HIP_TRY(hipMemsetAsync(ws.status.ptr, 0, sizeof(int), stream));
+
+    if (use_mfma) {
+        const long count = rows * kd;
+        hipLaunchKernelGGL(prepare_samples, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, d_z, d_nhi,
+                           count, g.num_lines, ws.prep.as<double>());
+        HIP_TRY(hipGetLastError());
+    }
 
     EventPair ev{};
     const bool timing = g_opt_timing != 0;
@@ -178,20 +334,33 @@ static int launch_sweep(const LaunchShape &shape, Workspace &ws, int64_t S, int 
         HIP_TRY(hipEventRecord(ev.start, stream));
     }
 
-    {
+    if (use_mfma) {
+        const long groups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
+        dim3 grid((unsigned)(groups * nsplit), (unsigned)nb);
+        const bool lines3 = g.num_lines == 3;
+        double *part = ws.part.as<double>();
+        const double *prep = ws.prep.as<double>();
+        if (kd == 1) {
+            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, prep, part, rows);
+            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, prep, part, rows);
+        } else {
+            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, prep, part, rows);
+            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, prep, part, rows);
+        }
+        HIP_TRY(hipGetLastError());
+    } else {
         // w[] (n_pad values) reuses the raw-profile buffer: size it for both
-        const int lds_entries = std::max(shape.max_entries, shape.max_npad);
-        const int lds_pixels = shape.max_npad;
+        const int lds_entries = std::max(g.max_entries, g.max_npad);
+        const int lds_pixels = g.max_npad;
         const size_t lds_bytes = (size_t)(lds_entries + lds_pixels + DLAGP_MAX_LINES + 1 + 8) * sizeof(double);
         if (lds_bytes > 160 * 1024)
             return fail(DLAGP_EINVAL, "sightline too long for the generic kernel: %zu B of LDS needed", lds_bytes);
         if (lds_bytes > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_generic),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        dim3 grid((unsigned)S, (unsigned)shape.nb);
-        hipLaunchKernelGGL(accumulate_generic, grid, dim3(DLAGP_GENERIC_THREADS), lds_bytes, stream,
-                           shape.d_table, (long)S, kd, d_z, d_nhi, ws.part.as<double>(), lds_entries,
-                           lds_pixels);
+        dim3 grid((unsigned)S, (unsigned)nb);
+        hipLaunchKernelGGL(accumulate_generic, grid, dim3(DLAGP_GENERIC_THREADS), lds_bytes, stream, table, (long)S,
+                           kd, d_z, d_nhi, ws.part.as<double>(), lds_entries, lds_pixels);
         HIP_TRY(hipGetLastError());
     }
 
@@ -203,23 +372,21 @@ static int launch_sweep(const LaunchShape &shape, Workspace &ws, int64_t S, int 
 
     const int threads = DLAGP_FINALIZE_THREADS;
     const unsigned blocks = (unsigned)((rows + threads - 1) / threads);
-    if (shape.k == 20) {
-        hipLaunchKernelGGL(finalize_samples<20>, dim3(blocks), dim3(threads), 0, stream,
-                           ws.part.as<double>(), nsplit, rows, (long)S, shape.d_table, d_out,
-                           ws.status.as<int>());
+    if (g.k == 20) {
+        hipLaunchKernelGGL(finalize_samples<20>, dim3(blocks), dim3(threads), 0, stream, ws.part.as<double>(),
+                           nsplit, rows, (long)S, table, d_out, ws.status.as<int>());
     } else {
-        hipLaunchKernelGGL(finalize_samples<0>, dim3(blocks), dim3(threads), 0, stream,
-                           ws.part.as<double>(), nsplit, rows, (long)S, shape.d_table, d_out,
-                           ws.status.as<int>());
+        hipLaunchKernelGGL(finalize_samples<0>, dim3(blocks), dim3(threads), 0, stream, ws.part.as<double>(),
+                           nsplit, rows, (long)S, table, d_out, ws.status.as<int>());
     }
     HIP_TRY(hipGetLastError());
     return DLAGP_OK;
 }
 
 // host-pointer wrapper: stage, launch, copy back, report non-PD as DLAGP_ELINALG
-static int sweep_from_host(const LaunchShape &shape, Workspace &ws, int64_t S, int kd, const double *z,
-                           const double *nhi, double *out) {
-    const long rows = (long)shape.nb * S;
+static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, const double *nhi, double *out) {
+    Workspace &ws = g.ws;
+    const long rows = (long)g.ctxs.size() * S;
     const size_t nsamp = (size_t)rows * (kd > 0 ? kd : 1);
     int rc;
     if ((rc = ws.z.reserve(nsamp * sizeof(double)))) return rc;
@@ -229,7 +396,7 @@ static int sweep_from_host(const LaunchShape &shape, Workspace &ws, int64_t S, i
         HIP_TRY(hipMemcpy(ws.z.ptr, z, nsamp * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ws.nhi.ptr, nhi, nsamp * sizeof(double), hipMemcpyHostToDevice));
     }
-    rc = launch_sweep(shape, ws, S, kd, ws.z.as<double>(), ws.nhi.as<double>(), ws.out.as<double>(), nullptr);
+    rc = launch_sweep(g, S, kd, ws.z.as<double>(), ws.nhi.as<double>(), ws.out.as<double>(), nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, ws.out.ptr, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost));
     int status = 0;
@@ -238,14 +405,24 @@ static int sweep_from_host(const LaunchShape &shape, Workspace &ws, int64_t S, i
     return DLAGP_OK;
 }
 
-static LaunchShape shape_of(dlagp_ctx *ctx) {
-    return LaunchShape{ctx->d_sl.as<SightlineDev>(), 1, ctx->sl.k, ctx->sl.row_width, ctx->sl.num_entries,
-                       ctx->sl.n_pad};
-}
-
-static LaunchShape shape_of(dlagp_batch *b) {
-    return LaunchShape{b->d_table.as<SightlineDev>(), (int)b->ctxs.size(), b->k, b->row_width, b->max_entries,
-                       b->max_npad};
+// fill the group-level summary from its members and upload the descriptor table
+static int finish_group(LaunchGroup &g) {
+    std::vector<SightlineDev> table;
+    g.k = g.ctxs[0]->sl.k;
+    g.row_width = g.ctxs[0]->sl.row_width;
+    g.num_lines = g.ctxs[0]->sl.num_lines;
+    g.mfma_ok = true;
+    for (dlagp_ctx *ctx : g.ctxs) {
+        table.push_back(ctx->sl);
+        g.max_entries = std::max(g.max_entries, ctx->sl.num_entries);
+        g.max_npad = std::max(g.max_npad, ctx->sl.n_pad);
+        g.max_chunks = std::max(g.max_chunks, ctx->sl.n_pad / DLAGP_CHUNK_PIXELS);
+        g.mfma_ok = g.mfma_ok && ctx->mfma_ok && ctx->sl.num_lines == g.num_lines;
+    }
+    int rc = g.d_table.reserve(table.size() * sizeof(SightlineDev));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(g.d_table.ptr, table.data(), table.size() * sizeof(SightlineDev), hipMemcpyHostToDevice));
+    return DLAGP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -282,34 +459,46 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
 
     dlagp_ctx *ctx = new dlagp_ctx();
     ctx->device = device;
+    ctx->user_k = k;
+    // ranks up to 20 run as rank 20: zero columns of M add an identity block to B and nothing to u,
+    // so the density is unchanged and one MFMA tile layout serves them all
+    const int k_eff = k <= DLAGP_MFMA_RANK ? DLAGP_MFMA_RANK : k;
     SightlineDev &sl = ctx->sl;
     sl.n = n;
-    sl.n_pad = (n + DLAGP_STEP_PIXELS - 1) / DLAGP_STEP_PIXELS * DLAGP_STEP_PIXELS;
+    sl.n_pad = (n + DLAGP_CHUNK_PIXELS - 1) / DLAGP_CHUNK_PIXELS * DLAGP_CHUNK_PIXELS;
     sl.nsteps = sl.n_pad / DLAGP_STEP_PIXELS;
-    sl.k = k;
+    sl.k = k_eff;
     sl.ntaps = broadening ? DLAGP_NUM_TAPS : 1;
     sl.num_entries = broadening ? n_u + DLAGP_NUM_TAPS - 1 : n_u;
     sl.num_lines = num_lines;
-    sl.ntw = (k * (k + 1) / 2 + DLAGP_TILE_COLS - 1) / DLAGP_TILE_COLS;
-    sl.ntq = (k + DLAGP_TILE_COLS - 1) / DLAGP_TILE_COLS;
+    sl.ntw = (k_eff * (k_eff + 1) / 2 + DLAGP_TILE_COLS - 1) / DLAGP_TILE_COLS;
+    sl.ntq = (k_eff + DLAGP_TILE_COLS - 1) / DLAGP_TILE_COLS;
     sl.row_width = (sl.ntw + sl.ntq) * DLAGP_TILE_COLS + DLAGP_ROW_EXTRA;
     for (int t = 0; t < DLAGP_NUM_TAPS; ++t) sl.taps[t] = broadening ? DLAGP_INSTRUMENT_PROFILE[t] : (t == 0 ? 1.0 : 0.0);
 
     // padded host images
     std::vector<double> hy(sl.n_pad, 0.0), hmu(sl.n_pad, 0.0), ho(sl.n_pad, 0.0), hv(sl.n_pad, 1.0);
-    std::vector<int> hpos(sl.n_pad, 0);
-    std::vector<double> hM((size_t)n * k);
+    std::vector<double> hM((size_t)n * k_eff, 0.0);
     for (int i = 0; i < n; ++i) {
         hy[i] = y[i];
         hmu[i] = mu[i];
         ho[i] = omega2[i];
         hv[i] = v[i];
-        for (int c = 0; c < k; ++c) hM[(size_t)i * k + c] = M[i * m_row_stride + c * m_col_stride];
+        for (int c = 0; c < k; ++c) hM[(size_t)i * k_eff + c] = M[i * m_row_stride + c * m_col_stride];
     }
     // window start of kept pixel i = index of its unmasked pixel: with broadening the padded grid
     // has 3 extra entries in front, so the 7-tap "valid" window of unmasked pixel j is j .. j+6
+    std::vector<int> &hpos = ctx->h_pos;
+    hpos.assign(sl.n_pad, 0);
     for (int j = 0, i = 0; j < n_u; ++j)
         if (keep[j]) hpos[i++] = j;
+    for (int i = n; i < sl.n_pad; ++i) hpos[i] = hpos[n - 1];
+
+    {
+        std::vector<PassDesc> passes;
+        std::vector<int2> splits;
+        ctx->mfma_ok = k_eff == DLAGP_MFMA_RANK && plan_passes(hpos, sl.n_pad, sl.ntaps, 1, passes, splits);
+    }
 
     auto upload = [&](DeviceBuffer &buf, const void *src, size_t bytes) -> int {
         int r = buf.reserve(bytes);
@@ -341,7 +530,7 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
     sl.lam = ctx->lam.as<double>();
     sl.P = ctx->P.as<double>();
 
-    hipLaunchKernelGGL(build_shared_operand, dim3(1024), dim3(256), 0, nullptr, dM.as<double>(), n, sl.n_pad, k,
+    hipLaunchKernelGGL(build_shared_operand, dim3(1024), dim3(256), 0, nullptr, dM.as<double>(), n, sl.n_pad, k_eff,
                        sl.ntw, sl.ntq, ctx->P.as<double>());
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) err = hipDeviceSynchronize();
@@ -350,7 +539,9 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
         dlagp_destroy(ctx);
         return fail(DLAGP_EDEVICE, "build_shared_operand failed: %s", hipGetErrorString(err));
     }
-    rc = upload(ctx->d_sl, &sl, sizeof(sl));
+    ctx->self.device = device;
+    ctx->self.ctxs.push_back(ctx);
+    rc = finish_group(ctx->self);
     if (rc) {
         dlagp_destroy(ctx);
         return rc;
@@ -362,7 +553,6 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
 void dlagp_destroy(dlagp_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    ctx->d_sl.release();
     ctx->y.release();
     ctx->mu.release();
     ctx->omega2.release();
@@ -370,12 +560,16 @@ void dlagp_destroy(dlagp_ctx *ctx) {
     ctx->pos.release();
     ctx->lam.release();
     ctx->P.release();
-    ctx->ws.release();
+    for (auto &kv : ctx->plans) {
+        kv.second->passes.release();
+        kv.second->splits.release();
+    }
+    ctx->self.release();
     delete ctx;
 }
 
 int dlagp_ctx_n(const dlagp_ctx *ctx) { return ctx ? ctx->sl.n : DLAGP_EINVAL; }
-int dlagp_ctx_k(const dlagp_ctx *ctx) { return ctx ? ctx->sl.k : DLAGP_EINVAL; }
+int dlagp_ctx_k(const dlagp_ctx *ctx) { return ctx ? ctx->user_k : DLAGP_EINVAL; }
 int dlagp_ctx_device(const dlagp_ctx *ctx) { return ctx ? ctx->device : DLAGP_EINVAL; }
 
 static int check_eval_args(const void *ctx, int64_t S, int kd, const void *z, const void *nhi, const void *out) {
@@ -392,13 +586,13 @@ int dlagp_eval(dlagp_ctx *ctx, int64_t S, int kd, const double *z, const double 
     if (rc) return rc;
     if (S == 0) return DLAGP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    return sweep_from_host(shape_of(ctx), ctx->ws, S, kd, z, nhi, out);
+    return sweep_from_host(ctx->self, S, kd, z, nhi, out);
 }
 
 int dlagp_null(dlagp_ctx *ctx, double *out) {
     if (!ctx || !out) return fail(DLAGP_EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
-    return sweep_from_host(shape_of(ctx), ctx->ws, 1, 0, nullptr, nullptr, out);
+    return sweep_from_host(ctx->self, 1, 0, nullptr, nullptr, out);
 }
 
 int dlagp_mvnpdf(int n, int k, const double *y, const double *mu, const double *M, ptrdiff_t m_row_stride,
@@ -422,7 +616,7 @@ int dlagp_absorption(dlagp_ctx *ctx, int kd, const double *z, const double *nhi,
     int rc = check_eval_args(ctx, 1, kd, z, nhi, out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    Workspace &ws = ctx->ws;
+    Workspace &ws = ctx->self.ws;
     if ((rc = ws.z.reserve(kd * sizeof(double)))) return rc;
     if ((rc = ws.nhi.reserve(kd * sizeof(double)))) return rc;
     if ((rc = ws.out.reserve((size_t)ctx->sl.n_pad * sizeof(double)))) return rc;
@@ -435,8 +629,8 @@ int dlagp_absorption(dlagp_ctx *ctx, int kd, const double *z, const double *nhi,
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(absorption_generic),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(absorption_generic, dim3(1), dim3(DLAGP_GENERIC_THREADS), lds_bytes, nullptr,
-                       ctx->d_sl.as<SightlineDev>(), kd, ws.z.as<double>(), ws.nhi.as<double>(), ws.out.as<double>(),
-                       lds_entries, ctx->sl.n_pad);
+                       ctx->self.d_table.as<SightlineDev>(), kd, ws.z.as<double>(), ws.nhi.as<double>(),
+                       ws.out.as<double>(), lds_entries, ctx->sl.n_pad);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, ws.out.ptr, (size_t)ctx->sl.n * sizeof(double), hipMemcpyDeviceToHost));
     return DLAGP_OK;
@@ -447,42 +641,25 @@ int dlagp_eval_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, cons
     int rc = check_eval_args(ctx, S, kd, d_z, d_nhi, d_out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    return launch_sweep(shape_of(ctx), ctx->ws, S, kd, d_z, d_nhi, d_out, static_cast<hipStream_t>(stream));
+    return launch_sweep(ctx->self, S, kd, d_z, d_nhi, d_out, static_cast<hipStream_t>(stream));
 }
 
 int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
     if (!out) return fail(DLAGP_EINVAL, "out is NULL");
     *out = nullptr;
     if (!ctxs || nb <= 0) return fail(DLAGP_EINVAL, "empty batch");
-    for (int b = 0; b < nb; ++b)
-        if (!ctxs[b]) return fail(DLAGP_EINVAL, "context %d is NULL", b);
-    dlagp_batch *batch = new dlagp_batch();
-    batch->device = ctxs[0]->device;
-    batch->k = ctxs[0]->sl.k;
-    batch->row_width = ctxs[0]->sl.row_width;
-    std::vector<SightlineDev> table(nb);
     for (int b = 0; b < nb; ++b) {
-        if (ctxs[b]->device != batch->device) {
-            delete batch;
+        if (!ctxs[b]) return fail(DLAGP_EINVAL, "context %d is NULL", b);
+        if (ctxs[b]->device != ctxs[0]->device)
             return fail(DLAGP_EINVAL, "context %d lives on device %d, batch on %d", b, ctxs[b]->device, ctxs[0]->device);
-        }
-        if (ctxs[b]->sl.k != batch->k) {
-            delete batch;
-            return fail(DLAGP_EINVAL, "context %d has rank %d, batch rank is %d", b, ctxs[b]->sl.k, batch->k);
-        }
-        batch->ctxs.push_back(ctxs[b]);
-        table[b] = ctxs[b]->sl;
-        batch->max_entries = std::max(batch->max_entries, ctxs[b]->sl.num_entries);
-        batch->max_npad = std::max(batch->max_npad, ctxs[b]->sl.n_pad);
+        if (ctxs[b]->sl.k != ctxs[0]->sl.k)
+            return fail(DLAGP_EINVAL, "context %d has rank %d, batch rank is %d", b, ctxs[b]->user_k, ctxs[0]->user_k);
     }
-    if (hipSetDevice(batch->device) != hipSuccess) {
-        delete batch;
-        return fail(DLAGP_EDEVICE, "hipSetDevice(%d) failed", batch->device);
-    }
-    int rc = batch->d_table.reserve(table.size() * sizeof(SightlineDev));
-    if (!rc && hipMemcpy(batch->d_table.ptr, table.data(), table.size() * sizeof(SightlineDev),
-                         hipMemcpyHostToDevice) != hipSuccess)
-        rc = fail(DLAGP_EDEVICE, "uploading the sightline table failed");
+    if (hipSetDevice(ctxs[0]->device) != hipSuccess) return fail(DLAGP_EDEVICE, "hipSetDevice(%d) failed", ctxs[0]->device);
+    dlagp_batch *batch = new dlagp_batch();
+    batch->group.device = ctxs[0]->device;
+    batch->group.ctxs.assign(ctxs, ctxs + nb);
+    int rc = finish_group(batch->group);
     if (rc) {
         dlagp_batch_destroy(batch);
         return rc;
@@ -493,9 +670,8 @@ int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
 
 void dlagp_batch_destroy(dlagp_batch *batch) {
     if (!batch) return;
-    (void)hipSetDevice(batch->device);
-    batch->d_table.release();
-    batch->ws.release();
+    (void)hipSetDevice(batch->group.device);
+    batch->group.release();
     delete batch;
 }
 
@@ -503,16 +679,16 @@ int dlagp_batch_eval_device(dlagp_batch *batch, int64_t S, int kd, const double 
                             double *d_out, void *stream) {
     int rc = check_eval_args(batch, S, kd, d_z, d_nhi, d_out);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(batch->device));
-    return launch_sweep(shape_of(batch), batch->ws, S, kd, d_z, d_nhi, d_out, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipSetDevice(batch->group.device));
+    return launch_sweep(batch->group, S, kd, d_z, d_nhi, d_out, static_cast<hipStream_t>(stream));
 }
 
 int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, const double *nhi, double *out) {
     int rc = check_eval_args(batch, S, kd, z, nhi, out);
     if (rc) return rc;
     if (S == 0) return DLAGP_OK;
-    HIP_TRY(hipSetDevice(batch->device));
-    return sweep_from_host(shape_of(batch), batch->ws, S, kd, z, nhi, out);
+    HIP_TRY(hipSetDevice(batch->group.device));
+    return sweep_from_host(batch->group, S, kd, z, nhi, out);
 }
 
 int dlagp_set_option(const char *name, int64_t value) {

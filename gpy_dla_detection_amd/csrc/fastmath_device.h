@@ -1,0 +1,52 @@
+// FP64 helpers for the hot kernels: reciprocal, exp of a non-positive argument, and a running
+// product used to replace sum(log d) by one log per lane.  On gfx950 `log` costs ~400 cycles
+// and an IEEE division ~55 per wave-instruction (profiles/r01_microbench_mfma_f64.txt), so the
+// inner loops avoid both.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "faddeeva_table.h"
+
+namespace dlagp {
+
+// 1/x: v_rcp_f64 seed + two Newton steps (relative error ~1e-16 for normal x)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+
+// exp(x) for x <= 0 (also correct for moderate x > 0); max relative error 5e-16.
+// x = k ln2 + r, |r| <= ln2/2, e^r by a degree-10 fit, scaled with v_ldexp_f64 (underflows to 0).
+__device__ __forceinline__ double fast_exp(double x) {
+    constexpr double c[DLAGP_EXP_DEGREE + 1] = DLAGP_EXP_COEF_INIT;
+    const double k = __builtin_rint(x * 1.44269504088896338700e+00);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = c[DLAGP_EXP_DEGREE];
+#pragma unroll
+    for (int m = DLAGP_EXP_DEGREE - 1; m >= 0; --m) p = fma(p, r, c[m]);
+    // clamp the exponent so the int conversion is defined for -inf / huge arguments
+    const double kc = fmax(k, -2200.0);
+    return __builtin_amdgcn_ldexp(p, (int)kc);
+}
+
+// Running product with explicit exponent: value = mant * 2^expo.  sum(log d_i) = log(mant) + expo ln2.
+// 750 multiplications lose < 1e-13 absolutely in the logarithm (against |log p| ~ 1e3).
+struct LogProduct {
+    double mant = 1.0;
+    int expo = 0;
+    __device__ __forceinline__ void multiply(double d) {
+        const double t = mant * d;
+        mant = __builtin_amdgcn_frexp_mant(t);
+        expo += __builtin_amdgcn_frexp_exp(t);
+    }
+    __device__ __forceinline__ double log_value() const {
+        return log(mant) + expo * 6.93147180559945286227e-01;
+    }
+};
+
+}  // namespace dlagp

@@ -1,0 +1,308 @@
+// MFMA evaluation path for rank k <= 20 (zero-padded to 20): the production kernel.
+//
+// Work decomposition (DESIGN.md "accumulate_mfma"):
+//   workgroup = 4 waves; each wave owns 16 QMC samples of one sightline and one pixel split.
+//   The Gram/projection contraction is the FP64 GEMM  [samples x pixels] . [pixels x 256 cols]:
+//     A operand (16 samples x 4 pixels per v_mfma_f64_16x16x4_f64) = the per-pixel weights
+//       w = a^2/d (14 w-tiles, vech(M_i M_i')) and q = a r/d (2 q-tiles, M_i), generated in
+//       registers by the same lane that feeds them to the MFMA -- they never touch memory;
+//     B operand = the sightline's shared operand P (kernels_common.h), staged through LDS in
+//       chunks of 8 pixels and shared by the 4 waves.
+//   Accumulators: 16 tiles x 4 doubles per lane (128 VGPRs) -> 2 waves per SIMD, so one wave's
+//   VALU phases (Voigt profile, weights) overlap the sibling wave's MFMAs.
+//
+// Per pass (<= 56 kept pixels whose 7-tap windows fit in 64 consecutive entries):
+//   phase 1  lane = entry, loop over the wave's 16 samples: optical depth of every absorber and
+//            line (wing polynomial; Taylor/table core path behind a wave-uniform branch),
+//            raw = exp(-N tau) -> LDS raw[sample][entry]            (voigt.py:299-309)
+//   phase 2  lane = (sample = lane & 15, pixel slot = lane >> 4), per step of 4 pixels:
+//            a = sum_t taps_t raw[pos + t] (voigt.py:319, dla_gp.py:388), d = omega2 a^2 + v,
+//            r = y - mu a, w = a^2/d, q = a r/d, running sum r^2/d and product of d
+//            (dla_gp.py:392-394, null_gp.py:329-333,356), then 16 MFMAs   (null_gp.py:339-354)
+// Output: one partial row per (split, sample) for finalize_samples.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dlagp_device.h"
+#include "fastmath_device.h"
+#include "voigt_device.h"
+
+namespace dlagp {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define DLAGP_MFMA_RANK 20
+#define DLAGP_MFMA_NTW 14
+#define DLAGP_MFMA_NT 16
+#define DLAGP_MFMA_WAVES 4
+#define DLAGP_MFMA_THREADS (64 * DLAGP_MFMA_WAVES)
+#define DLAGP_MFMA_GROUP (16 * DLAGP_MFMA_WAVES)  // samples per workgroup
+#define DLAGP_PASS_ENTRIES 64
+#define DLAGP_RAW_STRIDE 66      // doubles per sample row in LDS; stride/2 odd -> conflict-free b64 reads
+#define DLAGP_CHUNK_PIXELS 8     // P staging granule = 2 steps
+#define DLAGP_CHUNK_DOUBLES (2 * DLAGP_MFMA_NT * DLAGP_TILE_DOUBLES)
+#define DLAGP_MAX_PASS_CHUNKS 7  // 56 pixels
+
+struct PassDesc {
+    int entry_start;  // first entry computed by phase 1
+    int chunk_begin;  // first chunk (8 kept pixels) consumed by phase 2
+    int nchunks;      // 1..7
+    int pad;
+};
+
+// Per-(sample, absorber) constants prepared once per launch: the L velocity multipliers
+// c / (lambda_l (1 + z)) / 1e8 (voigt.py:299) followed by the column density.
+// Layout: prep[row][absorber][num_lines + 1].
+__global__ void prepare_samples(const double *__restrict__ z, const double *__restrict__ nhi, long count,
+                                int num_lines, double *__restrict__ prep) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    const double zi = z[idx];
+    double *dst = prep + idx * (num_lines + 1);
+    for (int l = 0; l < num_lines; ++l) dst[l] = line_multiplier(l, zi);
+    dst[num_lines] = nhi[idx];
+}
+
+// optical depth per unit column density at one entry, all lines; `mult` is wave-uniform
+template <int LINES>
+__device__ __forceinline__ double optical_depth(double lam, const double *__restrict__ mult, int num_lines) {
+    const int L = LINES > 0 ? LINES : num_lines;
+    double tau = 0.0;
+    double xs[LINES > 0 ? LINES : 1];
+    bool any_core = false;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const double velocity = __dsub_rn(__dmul_rn(lam, mult[l]), DLAGP_LINES.c);  // voigt.py:305
+        const double x = velocity * DLAGP_LINES.inv_sqrt2_sigma;
+        if (LINES > 0) xs[l] = x;
+        const double x2 = x * x;
+        const bool core = !(x2 >= DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT);  // also catches NaN
+        const double u = fast_rcp(fmax(x2, DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT));
+        const double *w = DLAGP_LINES.wing[l];
+        double poly = w[DLAGP_WING_DEGREE];
+#pragma unroll
+        for (int m = DLAGP_WING_DEGREE - 1; m >= 0; --m) poly = fma(poly, u, w[m]);
+        double term = u * poly;
+        if (LINES > 0) {
+            any_core |= core;
+            tau += core ? 0.0 : term;
+        } else {
+            if (core) term = DLAGP_LINES.k_core[l] * core_taylor(x, DLAGP_LINES.y[l]);
+            if (term == term) tau += term;  // np.nansum (voigt.py:309)
+        }
+    }
+    if (LINES > 0) {
+        // rare: some lane sits within 16 Doppler widths of a line centre (~6 entries per line)
+        if (__builtin_amdgcn_ballot_w64(any_core)) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const double x = xs[l];
+                if (!(x * x >= DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT)) {
+                    const double term = DLAGP_LINES.k_core[l] * core_taylor(x, DLAGP_LINES.y[l]);
+                    if (term == term) tau += term;
+                }
+            }
+        }
+    }
+    return tau;
+}
+
+// grid: (ngroups * nsplit, nb); block: 256.
+//   block L -> split = L % nsplit (so that blocks sharing an XCD share a slice of P when nsplit
+//   is a multiple of 8), sample group = L / nsplit.
+// MULTI = false: exactly one absorber per sample, convolution fused into the MFMA loop.
+// MULTI = true : kd absorbers; each absorber's profile is convolved and multiplied into
+//                per-step registers before the MFMA loop (dla_gp.py:379-386).
+template <int LINES, bool MULTI>
+__global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
+    const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
+    const int2 *const *__restrict__ split_tables, int nsplit, long S, int kd,
+    const double *__restrict__ prep, double *__restrict__ part, long rows) {
+    __shared__ double raw_lds[DLAGP_MFMA_WAVES][16 * DLAGP_RAW_STRIDE];
+    __shared__ double p_lds[2][DLAGP_CHUNK_DOUBLES];
+
+    const int b = blockIdx.y;
+    const SightlineDev &sl = sightlines[b];
+    const int split = blockIdx.x % nsplit;
+    const int group = blockIdx.x / nsplit;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s_loc = lane & 15;
+    const int slot = lane >> 4;
+
+    const long sample0 = (long)group * DLAGP_MFMA_GROUP + wave * 16;  // first sample of this wave
+    const int L = LINES > 0 ? LINES : sl.num_lines;
+    const int prep_stride = L + 1;
+    double *raw = raw_lds[wave];
+
+    const PassDesc *passes = pass_tables[b];
+    const int2 span = split_tables[b][split];  // passes [x, y)
+
+    d4 acc[DLAGP_MFMA_NT];
+#pragma unroll
+    for (int t = 0; t < DLAGP_MFMA_NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+    double sum_r2 = 0.0;
+    LogProduct dprod;
+
+    const double tap0 = sl.taps[0], tap1 = sl.taps[1], tap2 = sl.taps[2], tap3 = sl.taps[3];
+    const double tap4 = sl.taps[4], tap5 = sl.taps[5], tap6 = sl.taps[6];
+    const int ntaps = sl.ntaps;
+
+    // stage the first chunk of this split
+    const int first_chunk = span.x < span.y ? passes[span.x].chunk_begin : 0;
+    const int end_chunk = span.x < span.y ? passes[span.y - 1].chunk_begin + passes[span.y - 1].nchunks : 0;
+    {
+        const double *src = sl.P + (long)first_chunk * DLAGP_CHUNK_DOUBLES;
+        if (first_chunk < end_chunk) {
+#pragma unroll
+            for (int q = 0; q < DLAGP_CHUNK_DOUBLES / DLAGP_MFMA_THREADS / 2; ++q) {
+                const int off = (q * DLAGP_MFMA_THREADS + tid) * 2;
+                *reinterpret_cast<double2 *>(&p_lds[0][off]) = *reinterpret_cast<const double2 *>(src + off);
+            }
+        }
+    }
+    int buf = 0;
+
+    for (int pass = span.x; pass < span.y; ++pass) {
+        const PassDesc pd = passes[pass];
+
+        // ---------------- phase 1: raw profiles of the wave's 16 samples ----------------
+        {
+            int e = pd.entry_start + lane;
+            e = e < sl.num_entries ? e : sl.num_entries - 1;
+            const double lam = sl.lam[e];
+            if (!MULTI) {
+#pragma unroll 2
+                for (int ss = 0; ss < 16; ++ss) {
+                    long row = sample0 + ss;
+                    row = row < S ? row : S - 1;
+                    const double *sp = prep + ((long)b * S + row) * prep_stride;
+                    const double tau = optical_depth<LINES>(lam, sp, L);
+                    raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp(-sp[L] * tau);  // voigt.py:309
+                }
+            }
+        }
+
+        double a_reg[MULTI ? 2 * DLAGP_MAX_PASS_CHUNKS : 1];
+        if (MULTI) {
+            int e = pd.entry_start + lane;
+            e = e < sl.num_entries ? e : sl.num_entries - 1;
+            const double lam = sl.lam[e];
+            for (int jd = 0; jd < kd; ++jd) {
+                for (int ss = 0; ss < 16; ++ss) {
+                    long row = sample0 + ss;
+                    row = row < S ? row : S - 1;
+                    const double *sp = prep + (((long)b * S + row) * kd + jd) * prep_stride;
+                    const double tau = optical_depth<LINES>(lam, sp, L);
+                    raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp(-sp[L] * tau);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int st = 0; st < 2 * DLAGP_MAX_PASS_CHUNKS; ++st) {
+                    if (st < 2 * pd.nchunks) {
+                        const int pix = (pd.chunk_begin * 2 + st) * DLAGP_STEP_PIXELS + slot;
+                        const double *win = raw + s_loc * DLAGP_RAW_STRIDE + (sl.pos[pix] - pd.entry_start);
+                        double conv = win[0] * tap0;
+                        if (ntaps > 1) {
+                            conv = fma(win[1], tap1, conv);
+                            conv = fma(win[2], tap2, conv);
+                            conv = fma(win[3], tap3, conv);
+                            conv = fma(win[4], tap4, conv);
+                            conv = fma(win[5], tap5, conv);
+                            conv = fma(win[6], tap6, conv);
+                        }
+                        a_reg[st] = jd == 0 ? conv : a_reg[st] * conv;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();  // raw[] visible to the whole wave; first P chunk staged
+
+        // ---------------- phase 2: weights and MFMAs, chunk by chunk ----------------
+        constexpr int CHUNK_UNROLL = MULTI ? DLAGP_MAX_PASS_CHUNKS : 1;
+#pragma unroll CHUNK_UNROLL
+        for (int c = 0; c < (MULTI ? DLAGP_MAX_PASS_CHUNKS : pd.nchunks); ++c) {
+            if (MULTI && c >= pd.nchunks) break;
+            const int chunk = pd.chunk_begin + c;
+            // prefetch the next chunk of P into registers
+            double2 pre[DLAGP_CHUNK_DOUBLES / DLAGP_MFMA_THREADS / 2];
+            const bool have_next = chunk + 1 < end_chunk;
+            if (have_next) {
+                const double *src = sl.P + (long)(chunk + 1) * DLAGP_CHUNK_DOUBLES;
+#pragma unroll
+                for (int q = 0; q < DLAGP_CHUNK_DOUBLES / DLAGP_MFMA_THREADS / 2; ++q)
+                    pre[q] = *reinterpret_cast<const double2 *>(src + (q * DLAGP_MFMA_THREADS + tid) * 2);
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int pix = (chunk * 2 + st) * DLAGP_STEP_PIXELS + slot;
+                double a;
+                if (MULTI) {
+                    a = a_reg[2 * c + st];
+                } else {
+                    const double *win = raw + s_loc * DLAGP_RAW_STRIDE + (sl.pos[pix] - pd.entry_start);
+                    a = win[0] * tap0;
+                    if (ntaps > 1) {
+                        a = fma(win[1], tap1, a);
+                        a = fma(win[2], tap2, a);
+                        a = fma(win[3], tap3, a);
+                        a = fma(win[4], tap4, a);
+                        a = fma(win[5], tap5, a);
+                        a = fma(win[6], tap6, a);
+                    }
+                }
+                const double d = fma(sl.omega2[pix] * a, a, sl.v[pix]);
+                const double h = fast_rcp(d);
+                const double r = fma(-sl.mu[pix], a, sl.y[pix]);
+                const double rh = r * h;
+                const double w = a * a * h;
+                const double q = a * rh;
+                sum_r2 = fma(r, rh, sum_r2);
+                dprod.multiply(d);
+                const double *pb = &p_lds[buf][st * DLAGP_MFMA_NT * DLAGP_TILE_DOUBLES + lane];
+#pragma unroll
+                for (int t = 0; t < DLAGP_MFMA_NT; ++t) {
+                    const double bfrag = pb[t * DLAGP_TILE_DOUBLES];
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(t < DLAGP_MFMA_NTW ? w : q, bfrag, acc[t], 0, 0, 0);
+                }
+            }
+            if (have_next) {
+#pragma unroll
+                for (int q = 0; q < DLAGP_CHUNK_DOUBLES / DLAGP_MFMA_THREADS / 2; ++q)
+                    *reinterpret_cast<double2 *>(&p_lds[buf ^ 1][(q * DLAGP_MFMA_THREADS + tid) * 2]) = pre[q];
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---------------- epilogue: one partial row per sample ----------------
+    const int rw = sl.row_width;
+    double *base = part + ((long)split * rows + (long)b * S) * rw;
+#pragma unroll
+    for (int t = 0; t < DLAGP_MFMA_NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long row = sample0 + slot + 4 * r;  // D row = (lane >> 4) + 4 r
+            if (row < S) base[row * rw + t * DLAGP_TILE_COLS + s_loc] = acc[t][r];
+        }
+    }
+    double logd = dprod.log_value();
+    sum_r2 += __shfl_xor(sum_r2, 16);
+    sum_r2 += __shfl_xor(sum_r2, 32);
+    logd += __shfl_xor(logd, 16);
+    logd += __shfl_xor(logd, 32);
+    if (slot == 0) {
+        const long row = sample0 + s_loc;
+        if (row < S) {
+            base[row * rw + DLAGP_MFMA_NT * DLAGP_TILE_COLS] = sum_r2;
+            base[row * rw + DLAGP_MFMA_NT * DLAGP_TILE_COLS + 1] = logd;
+        }
+    }
+}
+
+}  // namespace dlagp

@@ -285,7 +285,9 @@ def test_batch_equals_single_sightline_launches():
     batch = DeviceBatch(devs)
     got = batch.eval(np.stack(zs), np.stack(ns))
     for b, dev in enumerate(devs):
-        np.testing.assert_array_equal(got[b], dev.eval(zs[b], ns[b]))
+        # the batch and the single launch may choose different pixel-split counts, i.e. a
+        # different (deterministic) summation order: equal to rounding, not bit for bit
+        np.testing.assert_allclose(got[b], dev.eval(zs[b], ns[b]), rtol=1e-13)
 
 
 def test_full_size_properties():
@@ -316,3 +318,50 @@ def test_full_size_properties():
     pick = np.arange(0, S, 500)
     want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in pick])
     np.testing.assert_allclose(ll[pick], want, rtol=RTOL_LL)
+
+
+# ------------------------------------------------------------------------------------------------
+# the two evaluation paths and the pixel-split decomposition
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture
+def restore_options():
+    from gpy_dla_detection_amd.sightline import set_option
+
+    yield set_option
+    set_option("path", 0)
+    set_option("pixel_splits", 0)
+
+
+@pytest.mark.parametrize("shape", [dict(index=4, n_unmasked=1250, n_masked=28, k=20),
+                                   dict(index=8, n_unmasked=333, n_masked=77, k=12),
+                                   dict(index=9, n_unmasked=70, n_masked=3, k=20)])
+def test_generic_and_mfma_paths_agree(shape, restore_options):
+    """path 1 = one workgroup per sample (VALU), path 2 = MFMA kernel; any split count"""
+    set_option = restore_options
+    sight = make_sightline(**shape)
+    dev = device_sightline(sight)
+    S = 203  # not a multiple of the 64-sample workgroup
+    z, _, nhi = make_qmc_samples(sight, S)
+    zz = np.stack([z, z[::-1], np.roll(z, 7)], axis=1)
+    nn = np.stack([nhi, nhi[::-1], np.roll(nhi, 7)], axis=1)
+    for kd in (1, 3):
+        set_option("path", 1)
+        want = dev.eval(zz[:, :kd], nn[:, :kd])
+        set_option("path", 2)
+        for splits in (1, 2, 3, 8, 1000):
+            set_option("pixel_splits", splits)
+            got = dev.eval(zz[:, :kd], nn[:, :kd])
+            np.testing.assert_allclose(got, want, rtol=1e-11, err_msg="kd=%d splits=%d" % (kd, splits))
+        set_option("pixel_splits", 0)
+
+
+def test_mfma_path_other_line_counts(restore_options):
+    set_option = restore_options
+    sight = make_sightline(2, n_unmasked=600, n_masked=11)
+    z, _, nhi = make_qmc_samples(sight, 96)
+    for lines in (1, 5, 31):
+        dev = device_sightline(sight, num_lines=lines)
+        set_option("path", 1)
+        want = dev.eval(z, nhi)
+        set_option("path", 2)
+        np.testing.assert_allclose(dev.eval(z, nhi), want, rtol=1e-11)
