@@ -93,6 +93,10 @@ static int ensure_device(int device) {
     lc.inv_sqrt2_sigma = 1.0 / sqrt2_sigma;
     lc.c = DLAGP_SPEED_OF_LIGHT_CGS;
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(DLAGP_LINES), &lc, sizeof(lc)));
+    // finalize_rank20 stages 117 KB per workgroup in LDS
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_rank20),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double))));
     g_device_ready[device] = 1;
     return DLAGP_OK;
 }
@@ -266,19 +270,18 @@ static int group_plan(LaunchGroup &g, int nsplit, GroupPlan **out) {
     return DLAGP_OK;
 }
 
-// Number of pixel splits: enough workgroups to fill the chip (256 CUs x 2 resident workgroups)
-// a few times over, a multiple of 8 when splitting at all (blocks that share an XCD then share
-// a slice of P), and never finer than 2 chunks per split.
+// Number of pixel splits.  A workgroup (64 samples) keeps 2 waves on every SIMD busy only when
+// all 512 resident workgroup slots (256 CUs x 2) are taken; a single sightline with S = 10 000
+// has just 157 sample groups, so its pixels are cut into floor(512 / groups) equal splits whose
+// partial sums the finalize kernel adds in a fixed order.  More splits than that would only add
+// partial-sum traffic and halo recomputation.
 static int choose_splits(const LaunchGroup &g, int64_t S) {
-    if (g_opt_pixel_splits > 0) return (int)std::min<int64_t>(g_opt_pixel_splits, std::max(1, g.max_chunks));
+    const int max_h = std::max(1, g.max_chunks);
+    if (g_opt_pixel_splits > 0) return (int)std::min<int64_t>(g_opt_pixel_splits, max_h);
     const long groups = (long)g.ctxs.size() * ((S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP);
-    const long target = 4 * 512;
-    if (groups >= target) return 1;
-    long h = (target + groups - 1) / groups;
-    h = (h + 7) / 8 * 8;
-    const long max_h = std::max(1, g.max_chunks / 2);
-    if (h > max_h) h = max_h >= 8 ? max_h / 8 * 8 : max_h;
-    return (int)std::max<long>(1, h);
+    const long slots = 512;
+    long h = groups >= slots ? 1 : slots / groups;
+    return (int)std::min<long>(std::max<long>(1, h), std::max(1, max_h / DLAGP_MAX_PASS_CHUNKS));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -360,7 +363,7 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         dim3 grid((unsigned)S, (unsigned)nb);
         hipLaunchKernelGGL(accumulate_generic, grid, dim3(DLAGP_GENERIC_THREADS), lds_bytes, stream, table, (long)S,
-                           kd, d_z, d_nhi, ws.part.as<double>(), lds_entries, lds_pixels);
+                           kd, d_z, d_nhi, ws.part.as<double>(), rows, lds_entries, lds_pixels);
         HIP_TRY(hipGetLastError());
     }
 
@@ -370,14 +373,14 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
         g_timing_events.push_back(ev);
     }
 
-    const int threads = DLAGP_FINALIZE_THREADS;
-    const unsigned blocks = (unsigned)((rows + threads - 1) / threads);
-    if (g.k == 20) {
-        hipLaunchKernelGGL(finalize_samples<20>, dim3(blocks), dim3(threads), 0, stream, ws.part.as<double>(),
-                           nsplit, rows, (long)S, table, d_out, ws.status.as<int>());
+    if (g.k == DLAGP_FIN_K) {
+        const size_t lds_bytes = DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double);
+        hipLaunchKernelGGL(finalize_rank20, dim3((unsigned)((rows + 63) / 64)), dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
+                           ws.part.as<double>(), nsplit, rows, (long)S, table, d_out, ws.status.as<int>());
     } else {
-        hipLaunchKernelGGL(finalize_samples<0>, dim3(blocks), dim3(threads), 0, stream, ws.part.as<double>(),
-                           nsplit, rows, (long)S, table, d_out, ws.status.as<int>());
+        const int threads = DLAGP_FINALIZE_THREADS;
+        hipLaunchKernelGGL(finalize_samples<0>, dim3((unsigned)((rows + threads - 1) / threads)), dim3(threads), 0,
+                           stream, ws.part.as<double>(), nsplit, rows, (long)S, table, d_out, ws.status.as<int>());
     }
     HIP_TRY(hipGetLastError());
     return DLAGP_OK;

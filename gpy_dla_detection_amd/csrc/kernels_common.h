@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dlagp_device.h"
+#include "fastmath_device.h"
 
 namespace dlagp {
 
@@ -51,7 +52,8 @@ __global__ void build_shared_operand(const double *__restrict__ M_dev, int n, in
 
 // ---------------------------------------------------------------------------------------------
 // Finalisation: one thread per sample.
-//   partial rows: part[split][row][row_width]; row = sightline * S + sample
+//   partials: part[split][column][row], row = sightline * S + sample (column-major over the
+//   samples, so that consecutive threads read consecutive addresses)
 //   B = I + sum_splits (w-tiles),  u = sum_splits (q-tiles),
 //   L L' = B (lower, null_gp.py:343), t = L^-1 u,
 //   log p = -1/2 ( sum r^2/d - t't + sum log d + 2 sum log L_ii + n log 2pi )  (null_gp.py:354-358)
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
     const int qbase = sl.ntw * DLAGP_TILE_COLS;
     const int sbase = (sl.ntw + sl.ntq) * DLAGP_TILE_COLS;
     const long split_stride = rows * (long)rw;
-    const double *p0 = part + row * (long)rw;
+    const double *p0 = part + row;  // element (split h, column c) at p0[h * split_stride + c * rows]
 
     constexpr int KMAX = KT > 0 ? KT : DLAGP_MAX_RANK;
     // fixed rank: unroll everything so L and t live in registers; runtime rank: keep the loops
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
     for (int c = 0; c < KMAX * (KMAX + 1) / 2; ++c) {
         if (c < k * (k + 1) / 2) {
             double acc = 0.0;
-            for (int h = 0; h < nsplit; ++h) acc += p0[h * split_stride + c];
+            for (int h = 0; h < nsplit; ++h) acc += p0[h * split_stride + c * rows];
             L[c] = acc;
         }
     }
@@ -95,13 +97,13 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
     for (int c = 0; c < KMAX; ++c) {
         if (c < k) {
             double acc = 0.0;
-            for (int h = 0; h < nsplit; ++h) acc += p0[h * split_stride + qbase + c];
+            for (int h = 0; h < nsplit; ++h) acc += p0[h * split_stride + (qbase + c) * rows];
             t[c] = acc;
         }
     }
     for (int h = 0; h < nsplit; ++h) {
-        sum_r2 += p0[h * split_stride + sbase];
-        sum_logd += p0[h * split_stride + sbase + 1];
+        sum_r2 += p0[h * split_stride + sbase * rows];
+        sum_logd += p0[h * split_stride + (sbase + 1) * rows];
     }
 
     bool bad = false;
@@ -138,6 +140,99 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
         atomicOr(status, 1);
     }
     out[row] = result;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Finalisation for the fixed rank K = 20 (the production path): one wave = 64 samples.
+//   stage   every column of [B - I | u | scalars], summed over the splits in index order, goes to
+//           LDS as lds[column][sample]: independent coalesced loads shared by the 4 waves of the
+//           workgroup, many in flight (a register-resident one-thread-per-sample variant
+//           serialised on them)
+//   factor  row-by-row Cholesky (Cholesky-Banachiewicz): row i is finished in registers from the
+//           rows before it, which are read back from LDS; pivots are inverted once (20 rcp instead
+//           of 190 divisions) and log det B = log prod_i L_ii^2 costs a single log
+//   solve   t_i = (u_i - sum_m L_im t_m) / L_ii interleaved with the factorisation
+// Same results as finalize_samples<20> to rounding; ~15x faster on 10 000 samples.
+// Dynamic LDS: DLAGP_FINALIZE_LDS_DOUBLES doubles.
+// ---------------------------------------------------------------------------------------------
+#define DLAGP_FIN_K 20
+#define DLAGP_FIN_COLS (DLAGP_FIN_K * (DLAGP_FIN_K + 1) / 2)
+#define DLAGP_FINALIZE_LDS_DOUBLES ((DLAGP_FIN_COLS + DLAGP_FIN_K + 2) * 64)
+
+#define DLAGP_FIN_THREADS 256
+__global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const double *__restrict__ part, int nsplit, long rows, long S,
+                                                      const SightlineDev *__restrict__ sightlines,
+                                                      double *__restrict__ out, int *__restrict__ status) {
+    extern __shared__ double fin_lds[];
+    constexpr int K = DLAGP_FIN_K;
+    constexpr int NC = DLAGP_FIN_COLS;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long row0 = blockIdx.x * 64L;
+    const long row = row0 + lane;
+    const long rclamp = row < rows ? row : rows - 1;
+    const SightlineDev &sl = sightlines[rclamp / S];
+    const int rw = sl.row_width;
+    const int qbase = sl.ntw * DLAGP_TILE_COLS;
+    const int sbase = (sl.ntw + sl.ntq) * DLAGP_TILE_COLS;
+    const long split_stride = rows * (long)rw;
+    const double *p0 = part + rclamp;
+
+    // ---- stage: lds[c][lane], c < NC: vech(B - I); NC..NC+K-1: u; NC+K: sum r^2/d; NC+K+1: sum log d
+    // the 4 waves share the columns so that 4x as many loads are in flight; wave 0 then factorises
+    double *mine = fin_lds + lane;
+#pragma unroll 6
+    for (int c = wave; c < NC + K + 2; c += DLAGP_FIN_THREADS / 64) {
+        const int src = c < NC ? c : (c < NC + K ? qbase + (c - NC) : sbase + (c - NC - K));
+        double acc = 0.0;
+        for (int h = 0; h < nsplit; ++h) acc += p0[h * split_stride + (long)src * rows];
+        mine[c * 64] = acc;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+
+    double t[K], inv_diag[K];
+    double tt = 0.0;
+    LogProduct pivots;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        double r[K];
+#pragma unroll
+        for (int j = 0; j <= i; ++j) r[j] = mine[vech_col(i, j) * 64];
+        r[i] += 1.0;  // identity on the diagonal (null_gp.py:341)
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            double s = r[j];
+#pragma unroll
+            for (int m = 0; m < j; ++m) s = fma(-r[m], mine[vech_col(j, m) * 64], s);
+            r[j] = s * inv_diag[j];
+        }
+        double s = r[i];
+#pragma unroll
+        for (int m = 0; m < i; ++m) s = fma(-r[m], r[m], s);
+        if (s <= 0.0) bad = true;  // NaN pivots propagate silently, as LAPACK's do
+        pivots.multiply(s);        // log det B = sum log L_ii^2
+        const double diag = sqrt(s);
+        const double inv = fast_rcp(diag);
+        inv_diag[i] = inv;
+#pragma unroll
+        for (int j = 0; j < i; ++j) mine[vech_col(i, j) * 64] = r[j];
+        double ti = mine[(NC + i) * 64];
+#pragma unroll
+        for (int m = 0; m < i; ++m) ti = fma(-r[m], t[m], ti);
+        ti *= inv;
+        t[i] = ti;
+        tt = fma(ti, ti, tt);
+    }
+    const double sum_r2 = mine[(NC + K) * 64];
+    const double sum_logd = mine[(NC + K + 1) * 64];
+    double result = -0.5 * ((sum_r2 - tt) + (sum_logd + pivots.log_value()) + sl.n * DLAGP_LOG_2PI);
+    if (bad) {
+        result = __builtin_nan("");
+        atomicOr(status, 1);
+    }
+    if (row < rows) out[row] = result;
 }
 
 }  // namespace dlagp

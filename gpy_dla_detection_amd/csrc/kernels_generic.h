@@ -8,7 +8,8 @@
 //   phase B  d = omega2 a^2 + v, r = y - mu a, w = a^2/d, q = a r/d,
 //            sum r^2/d, sum log d (dla_gp.py:392-394, null_gp.py:329-333,356)
 //   phase C  one thread per column of P: sum_i w_i P_i (B - I) and sum_i q_i M_i (u)
-// and writes one partial row [B-I | u | sum r^2/d, sum log d] for finalize_samples.
+// and writes one partial column set [B-I | u | sum r^2/d, sum log d] for finalize_samples
+// (layout part[column][row], see kernels_common.h).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -67,7 +68,7 @@ __device__ __forceinline__ double block_sum(double x, double *red) {
 // grid: (S, nb).  Dynamic LDS: (num_entries + n_pad + MAX_LINES + 8) doubles (max over sightlines).
 __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
     const SightlineDev *__restrict__ sightlines, long S, int kd, const double *__restrict__ z,
-    const double *__restrict__ nhi, double *__restrict__ part, int lds_entries, int lds_pixels) {
+    const double *__restrict__ nhi, double *__restrict__ part, long rows, int lds_entries, int lds_pixels) {
     extern __shared__ double lds[];
     double *raw = lds;
     double *a = raw + lds_entries;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
 
     // phase C: columns
     const int nt = sl.ntw + sl.ntq;
-    double *prow = part + row * (long)sl.row_width;
+    double *prow = part + row;  // column c of this sample at prow[c * rows]
     for (int c = tid; c < nt * DLAGP_TILE_COLS; c += DLAGP_GENERIC_THREADS) {
         const int tile = c / DLAGP_TILE_COLS;
         const int cc = c % DLAGP_TILE_COLS;
@@ -113,11 +114,11 @@ __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
             for (int slot = 0; slot < DLAGP_STEP_PIXELS; ++slot)
                 acc = fma(weight[step * DLAGP_STEP_PIXELS + slot], blk[slot * DLAGP_TILE_COLS], acc);
         }
-        prow[c] = acc;
+        prow[c * rows] = acc;
     }
     if (tid == 0) {
-        prow[nt * DLAGP_TILE_COLS] = sum_r2;
-        prow[nt * DLAGP_TILE_COLS + 1] = sum_logd;
+        prow[(long)(nt * DLAGP_TILE_COLS) * rows] = sum_r2;
+        prow[(long)(nt * DLAGP_TILE_COLS + 1) * rows] = sum_logd;
     }
 }
 

@@ -280,15 +280,26 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         }
     }
 
-    // ---------------- epilogue: one partial row per sample ----------------
+    // ---------------- epilogue: partial sums to part[split][column][row] ----------------
+    // Transposed through LDS (p_lds is free now) so that every store instruction writes the 64
+    // samples of one column contiguously.  D layout: lane holds column (lane & 15) of rows
+    // (lane >> 4) + 4 r of its wave's 16-sample tile.
     const int rw = sl.row_width;
-    double *base = part + ((long)split * rows + (long)b * S) * rw;
+    const long row_base = (long)b * S + (long)group * DLAGP_MFMA_GROUP;  // first row of this workgroup
+    const long rows_left = S - (long)group * DLAGP_MFMA_GROUP;            // valid samples from there
+    double *base = part + (long)split * rw * rows;
+    double *tr = &p_lds[0][0];           // [16 columns][65] doubles per tile
+    constexpr int TR_STRIDE = 65;
 #pragma unroll
     for (int t = 0; t < DLAGP_MFMA_NT; ++t) {
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long row = sample0 + slot + 4 * r;  // D row = (lane >> 4) + 4 r
-            if (row < S) base[row * rw + t * DLAGP_TILE_COLS + s_loc] = acc[t][r];
+        for (int r = 0; r < 4; ++r) tr[s_loc * TR_STRIDE + wave * 16 + slot + 4 * r] = acc[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < DLAGP_TILE_COLS / DLAGP_MFMA_WAVES; ++cc) {
+            const int col = wave * (DLAGP_TILE_COLS / DLAGP_MFMA_WAVES) + cc;
+            if (lane < rows_left) base[(long)(t * DLAGP_TILE_COLS + col) * rows + row_base + lane] = tr[col * TR_STRIDE + lane];
         }
     }
     double logd = dprod.log_value();
@@ -296,12 +307,10 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     sum_r2 += __shfl_xor(sum_r2, 32);
     logd += __shfl_xor(logd, 16);
     logd += __shfl_xor(logd, 32);
-    if (slot == 0) {
-        const long row = sample0 + s_loc;
-        if (row < S) {
-            base[row * rw + DLAGP_MFMA_NT * DLAGP_TILE_COLS] = sum_r2;
-            base[row * rw + DLAGP_MFMA_NT * DLAGP_TILE_COLS + 1] = logd;
-        }
+    if (slot == 0 && wave * 16 + s_loc < rows_left) {
+        const long row = row_base + wave * 16 + s_loc;
+        base[(long)(DLAGP_MFMA_NT * DLAGP_TILE_COLS) * rows + row] = sum_r2;
+        base[(long)(DLAGP_MFMA_NT * DLAGP_TILE_COLS + 1) * rows + row] = logd;
     }
 }
 
