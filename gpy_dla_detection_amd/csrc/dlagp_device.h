@@ -37,6 +37,7 @@ struct SightlineDev {
     const int *pos;        // [n_pad]  first entry of the pixel's window; padding: pos[n - 1]
     const double *lam;     // [E]      observed wavelength of every entry, Angstrom
     const double *P;       // [nsteps][ntw + ntq][4][16] shared operand, see build_shared_operand
+    const double *aux;     // [n_pad][8] per-pixel records {y, mu, omega2, v, pos, 0, 0, 0} (MFMA path)
     double taps[DLAGP_NUM_TAPS];  // instrument profile (or {1, 0, ...})
 };
 

@@ -182,7 +182,7 @@ struct dlagp_ctx {
     int device = 0;
     int user_k = 0;            // rank the caller passed (k <= 20 is zero-padded to 20 internally)
     SightlineDev sl{};         // host copy of the descriptor (device pointers inside)
-    DeviceBuffer y, mu, omega2, v, pos, lam, P;
+    DeviceBuffer y, mu, omega2, v, pos, lam, P, aux;
     std::vector<int> h_pos;    // host copy of pos[], for planning
     bool mfma_ok = false;      // rank padded to 20 and every 8-pixel chunk fits one 64-entry pass
     std::map<int, std::unique_ptr<SightlinePlan>> plans;
@@ -289,8 +289,9 @@ static int choose_splits(const LaunchGroup &g, int64_t S) {
 // ------------------------------------------------------------------------------------------------
 template <int LINES, bool MULTI>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, GroupPlan *gp, int nsplit,
-                        long S, int kd, const double *prep, double *part, long rows) {
-    hipLaunchKernelGGL((accumulate_mfma<LINES, MULTI>), grid, dim3(DLAGP_MFMA_THREADS), 0, stream, table,
+                        long S, int kd, int num_lines, const double *prep, double *part, long rows) {
+    const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * kd * ((LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
+    hipLaunchKernelGGL((accumulate_mfma<LINES, MULTI>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream, table,
                        gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S, kd, prep,
                        part, rows);
 }
@@ -303,10 +304,13 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
     const long rows = (long)nb * S;
     const SightlineDev *table = g.d_table.as<SightlineDev>();
 
-    bool use_mfma = g.mfma_ok && kd >= 1;
+    // the MFMA kernel keeps 64 samples' per-absorber constants in LDS next to 66 KB of static LDS
+    const size_t mfma_prep_lds = (size_t)DLAGP_MFMA_GROUP * std::max(kd, 1) * (g.num_lines + 1) * sizeof(double);
+    bool use_mfma = g.mfma_ok && kd >= 1 && mfma_prep_lds <= 48 * 1024;
     if (g_opt_path == 1) use_mfma = false;
     if (g_opt_path == 2 && kd >= 1) {
-        if (!g.mfma_ok) return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (rank > 20 or ragged mask)");
+        if (!g.mfma_ok || mfma_prep_lds > 48 * 1024)
+            return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (rank > 20, ragged mask, or kd x lines too large)");
         use_mfma = true;
     }
     const int nsplit = use_mfma ? choose_splits(g, S) : 1;
@@ -344,11 +348,11 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
         double *part = ws.part.as<double>();
         const double *prep = ws.prep.as<double>();
         if (kd == 1) {
-            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, prep, part, rows);
-            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, prep, part, rows);
+            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
+            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
         } else {
-            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, prep, part, rows);
-            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, prep, part, rows);
+            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
+            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
         }
         HIP_TRY(hipGetLastError());
     } else {
@@ -518,6 +522,16 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
     if (!rc) rc = upload(ctx->v, hv.data(), hv.size() * sizeof(double));
     if (!rc) rc = upload(ctx->pos, hpos.data(), hpos.size() * sizeof(int));
     if (!rc) rc = upload(ctx->lam, wavelengths, (size_t)sl.num_entries * sizeof(double));
+    std::vector<double> haux((size_t)sl.n_pad * DLAGP_AUX_FIELDS, 0.0);
+    for (int i = 0; i < sl.n_pad; ++i) {
+        double *rec = &haux[(size_t)i * DLAGP_AUX_FIELDS];
+        rec[0] = hy[i];
+        rec[1] = hmu[i];
+        rec[2] = ho[i];
+        rec[3] = hv[i];
+        rec[4] = (double)hpos[i];
+    }
+    if (!rc) rc = upload(ctx->aux, haux.data(), haux.size() * sizeof(double));
     if (!rc) rc = upload(dM, hM.data(), hM.size() * sizeof(double));
     if (!rc) rc = ctx->P.reserve(p_bytes);
     if (rc) {
@@ -532,6 +546,7 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
     sl.pos = ctx->pos.as<int>();
     sl.lam = ctx->lam.as<double>();
     sl.P = ctx->P.as<double>();
+    sl.aux = ctx->aux.as<double>();
 
     hipLaunchKernelGGL(build_shared_operand, dim3(1024), dim3(256), 0, nullptr, dM.as<double>(), n, sl.n_pad, k_eff,
                        sl.ntw, sl.ntq, ctx->P.as<double>());
@@ -563,6 +578,7 @@ void dlagp_destroy(dlagp_ctx *ctx) {
     ctx->pos.release();
     ctx->lam.release();
     ctx->P.release();
+    ctx->aux.release();
     for (auto &kv : ctx->plans) {
         kv.second->passes.release();
         kv.second->splits.release();

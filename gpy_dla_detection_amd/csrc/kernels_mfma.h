@@ -42,6 +42,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define DLAGP_CHUNK_PIXELS 8     // P staging granule = 2 steps
 #define DLAGP_CHUNK_DOUBLES (2 * DLAGP_MFMA_NT * DLAGP_TILE_DOUBLES)
 #define DLAGP_MAX_PASS_CHUNKS 7  // 56 pixels
+#define DLAGP_AUX_FIELDS 8       // per-pixel record: y, mu, omega2, v, window start, 3 spare
+#define DLAGP_AUX_DOUBLES (DLAGP_CHUNK_PIXELS * DLAGP_AUX_FIELDS)
 
 struct PassDesc {
     int entry_start;  // first entry computed by phase 1
@@ -107,12 +109,23 @@ __device__ __forceinline__ double optical_depth(double lam, const double *__rest
     return tau;
 }
 
+// 7-tap (or 1-tap) window of the raw profile = instrument convolution (voigt.py:319)
+__device__ __forceinline__ double convolve_window(const double *win, int ntaps, const double (&tap)[DLAGP_NUM_TAPS]) {
+    double conv = win[0] * tap[0];
+    if (ntaps > 1) {
+#pragma unroll
+        for (int t = 1; t < DLAGP_NUM_TAPS; ++t) conv = fma(win[t], tap[t], conv);
+    }
+    return conv;
+}
+
 // grid: (ngroups * nsplit, nb); block: 256.
 //   block L -> split = L % nsplit (so that blocks sharing an XCD share a slice of P when nsplit
 //   is a multiple of 8), sample group = L / nsplit.
 // MULTI = false: exactly one absorber per sample, convolution fused into the MFMA loop.
 // MULTI = true : kd absorbers; each absorber's profile is convolved and multiplied into
 //                per-step registers before the MFMA loop (dla_gp.py:379-386).
+// Dynamic LDS: the wave's per-sample constants, 4 waves x 16 samples x kd x (L + 1) doubles.
 template <int LINES, bool MULTI>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
@@ -120,6 +133,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const double *__restrict__ prep, double *__restrict__ part, long rows) {
     __shared__ double raw_lds[DLAGP_MFMA_WAVES][16 * DLAGP_RAW_STRIDE];
     __shared__ double p_lds[2][DLAGP_CHUNK_DOUBLES];
+    __shared__ double aux_lds[2][DLAGP_AUX_DOUBLES];
+    extern __shared__ double prep_lds[];
 
     const int b = blockIdx.y;
     const SightlineDev &sl = sightlines[b];
@@ -131,10 +146,30 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const int s_loc = lane & 15;
     const int slot = lane >> 4;
 
+    // descriptor fields used in the loops, read once
+    const int num_entries = sl.num_entries;
+    const int ntaps = sl.ntaps;
+    const double *__restrict__ lam_ptr = sl.lam;
+    const double *__restrict__ p_ptr = sl.P;
+    const double *__restrict__ aux_ptr = sl.aux;
+    const int *__restrict__ pos_ptr = sl.pos;
+    double tap[DLAGP_NUM_TAPS];
+#pragma unroll
+    for (int t = 0; t < DLAGP_NUM_TAPS; ++t) tap[t] = sl.taps[t];
+
     const long sample0 = (long)group * DLAGP_MFMA_GROUP + wave * 16;  // first sample of this wave
     const int L = LINES > 0 ? LINES : sl.num_lines;
     const int prep_stride = L + 1;
     double *raw = raw_lds[wave];
+
+    // per-sample constants of this wave -> LDS (rows beyond S repeat the last sample; never stored)
+    const int wave_prep = 16 * kd * prep_stride;
+    double *my_prep = prep_lds + wave * wave_prep;
+    for (int i = lane; i < wave_prep; i += 64) {
+        long row = sample0 + i / (kd * prep_stride);
+        row = row < S ? row : S - 1;
+        my_prep[i] = prep[((long)b * S + row) * kd * prep_stride + i % (kd * prep_stride)];
+    }
 
     const PassDesc *passes = pass_tables[b];
     const int2 span = split_tables[b][split];  // passes [x, y)
@@ -145,22 +180,17 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     double sum_r2 = 0.0;
     LogProduct dprod;
 
-    const double tap0 = sl.taps[0], tap1 = sl.taps[1], tap2 = sl.taps[2], tap3 = sl.taps[3];
-    const double tap4 = sl.taps[4], tap5 = sl.taps[5], tap6 = sl.taps[6];
-    const int ntaps = sl.ntaps;
-
-    // stage the first chunk of this split
+    // stage the first chunk of this split: P block and the per-pixel record block
     const int first_chunk = span.x < span.y ? passes[span.x].chunk_begin : 0;
     const int end_chunk = span.x < span.y ? passes[span.y - 1].chunk_begin + passes[span.y - 1].nchunks : 0;
-    {
-        const double *src = sl.P + (long)first_chunk * DLAGP_CHUNK_DOUBLES;
-        if (first_chunk < end_chunk) {
+    if (first_chunk < end_chunk) {
+        const double *src = p_ptr + (long)first_chunk * DLAGP_CHUNK_DOUBLES;
 #pragma unroll
-            for (int q = 0; q < DLAGP_CHUNK_DOUBLES / DLAGP_MFMA_THREADS / 2; ++q) {
-                const int off = (q * DLAGP_MFMA_THREADS + tid) * 2;
-                *reinterpret_cast<double2 *>(&p_lds[0][off]) = *reinterpret_cast<const double2 *>(src + off);
-            }
+        for (int q = 0; q < DLAGP_CHUNK_DOUBLES / DLAGP_MFMA_THREADS / 2; ++q) {
+            const int off = (q * DLAGP_MFMA_THREADS + tid) * 2;
+            *reinterpret_cast<double2 *>(&p_lds[0][off]) = *reinterpret_cast<const double2 *>(src + off);
         }
+        if (tid < DLAGP_AUX_DOUBLES) aux_lds[0][tid] = aux_ptr[(long)first_chunk * DLAGP_AUX_DOUBLES + tid];
     }
     int buf = 0;
 
@@ -168,32 +198,24 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         const PassDesc pd = passes[pass];
 
         // ---------------- phase 1: raw profiles of the wave's 16 samples ----------------
-        {
-            int e = pd.entry_start + lane;
-            e = e < sl.num_entries ? e : sl.num_entries - 1;
-            const double lam = sl.lam[e];
-            if (!MULTI) {
+        int e = pd.entry_start + lane;
+        e = e < num_entries ? e : num_entries - 1;
+        const double lam = lam_ptr[e];
+        if (!MULTI) {
 #pragma unroll 2
-                for (int ss = 0; ss < 16; ++ss) {
-                    long row = sample0 + ss;
-                    row = row < S ? row : S - 1;
-                    const double *sp = prep + ((long)b * S + row) * prep_stride;
-                    const double tau = optical_depth<LINES>(lam, sp, L);
-                    raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp(-sp[L] * tau);  // voigt.py:309
-                }
+            for (int ss = 0; ss < 16; ++ss) {
+                const double *sp = my_prep + ss * prep_stride;
+                const double tau = optical_depth<LINES>(lam, sp, L);
+                raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp(-sp[L] * tau);  // voigt.py:309
             }
         }
 
         double a_reg[MULTI ? 2 * DLAGP_MAX_PASS_CHUNKS : 1];
         if (MULTI) {
-            int e = pd.entry_start + lane;
-            e = e < sl.num_entries ? e : sl.num_entries - 1;
-            const double lam = sl.lam[e];
             for (int jd = 0; jd < kd; ++jd) {
+#pragma unroll 2
                 for (int ss = 0; ss < 16; ++ss) {
-                    long row = sample0 + ss;
-                    row = row < S ? row : S - 1;
-                    const double *sp = prep + (((long)b * S + row) * kd + jd) * prep_stride;
+                    const double *sp = my_prep + (ss * kd + jd) * prep_stride;
                     const double tau = optical_depth<LINES>(lam, sp, L);
                     raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp(-sp[L] * tau);
                 }
@@ -203,16 +225,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 for (int st = 0; st < 2 * DLAGP_MAX_PASS_CHUNKS; ++st) {
                     if (st < 2 * pd.nchunks) {
                         const int pix = (pd.chunk_begin * 2 + st) * DLAGP_STEP_PIXELS + slot;
-                        const double *win = raw + s_loc * DLAGP_RAW_STRIDE + (sl.pos[pix] - pd.entry_start);
-                        double conv = win[0] * tap0;
-                        if (ntaps > 1) {
-                            conv = fma(win[1], tap1, conv);
-                            conv = fma(win[2], tap2, conv);
-                            conv = fma(win[3], tap3, conv);
-                            conv = fma(win[4], tap4, conv);
-                            conv = fma(win[5], tap5, conv);
-                            conv = fma(win[6], tap6, conv);
-                        }
+                        const double *win = raw + s_loc * DLAGP_RAW_STRIDE + (pos_ptr[pix] - pd.entry_start);
+                        const double conv = convolve_window(win, ntaps, tap);
                         a_reg[st] = jd == 0 ? conv : a_reg[st] * conv;
                     }
                 }
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        __syncthreads();  // raw[] visible to the whole wave; first P chunk staged
+        __syncthreads();  // raw[] visible to the whole wave; first chunk staged
 
         // ---------------- phase 2: weights and MFMAs, chunk by chunk ----------------
         constexpr int CHUNK_UNROLL = MULTI ? DLAGP_MAX_PASS_CHUNKS : 1;
@@ -228,36 +242,31 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         for (int c = 0; c < (MULTI ? DLAGP_MAX_PASS_CHUNKS : pd.nchunks); ++c) {
             if (MULTI && c >= pd.nchunks) break;
             const int chunk = pd.chunk_begin + c;
-            // prefetch the next chunk of P into registers
+            // prefetch the next chunk (P block + per-pixel records) into registers
             double2 pre[DLAGP_CHUNK_DOUBLES / DLAGP_MFMA_THREADS / 2];
+            double pre_aux = 0.0;
             const bool have_next = chunk + 1 < end_chunk;
             if (have_next) {
-                const double *src = sl.P + (long)(chunk + 1) * DLAGP_CHUNK_DOUBLES;
+                const double *src = p_ptr + (long)(chunk + 1) * DLAGP_CHUNK_DOUBLES;
 #pragma unroll
                 for (int q = 0; q < DLAGP_CHUNK_DOUBLES / DLAGP_MFMA_THREADS / 2; ++q)
                     pre[q] = *reinterpret_cast<const double2 *>(src + (q * DLAGP_MFMA_THREADS + tid) * 2);
+                if (tid < DLAGP_AUX_DOUBLES) pre_aux = aux_ptr[(long)(chunk + 1) * DLAGP_AUX_DOUBLES + tid];
             }
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                const int pix = (chunk * 2 + st) * DLAGP_STEP_PIXELS + slot;
+                // per-pixel record: y, mu, omega2, v, window start (as double)
+                const double *rec = &aux_lds[buf][(st * DLAGP_STEP_PIXELS + slot) * DLAGP_AUX_FIELDS];
                 double a;
                 if (MULTI) {
                     a = a_reg[2 * c + st];
                 } else {
-                    const double *win = raw + s_loc * DLAGP_RAW_STRIDE + (sl.pos[pix] - pd.entry_start);
-                    a = win[0] * tap0;
-                    if (ntaps > 1) {
-                        a = fma(win[1], tap1, a);
-                        a = fma(win[2], tap2, a);
-                        a = fma(win[3], tap3, a);
-                        a = fma(win[4], tap4, a);
-                        a = fma(win[5], tap5, a);
-                        a = fma(win[6], tap6, a);
-                    }
+                    const double *win = raw + s_loc * DLAGP_RAW_STRIDE + ((int)rec[4] - pd.entry_start);
+                    a = convolve_window(win, ntaps, tap);
                 }
-                const double d = fma(sl.omega2[pix] * a, a, sl.v[pix]);
+                const double d = fma(rec[2] * a, a, rec[3]);
                 const double h = fast_rcp(d);
-                const double r = fma(-sl.mu[pix], a, sl.y[pix]);
+                const double r = fma(-rec[1], a, rec[0]);
                 const double rh = r * h;
                 const double w = a * a * h;
                 const double q = a * rh;
@@ -274,6 +283,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
 #pragma unroll
                 for (int q = 0; q < DLAGP_CHUNK_DOUBLES / DLAGP_MFMA_THREADS / 2; ++q)
                     *reinterpret_cast<double2 *>(&p_lds[buf ^ 1][(q * DLAGP_MFMA_THREADS + tid) * 2]) = pre[q];
+                if (tid < DLAGP_AUX_DOUBLES) aux_lds[buf ^ 1][tid] = pre_aux;
             }
             __syncthreads();
             buf ^= 1;
