@@ -6,7 +6,7 @@
 //   pixel   one KEPT pixel i in [0, n): its absorption is the 7-tap (or 1-tap) window of raw
 //           profile values starting at entry pos[i]
 //   step    4 consecutive kept pixels = the K extent of one v_mfma_f64_16x16x4_f64
-//   tile    16 columns of the shared operand P; "w-tiles" hold vech(M_i M_i') and are weighted
+//   tile    16 columns of the shared operand P (stored as interleaved tile pairs); "w-tiles" hold vech(M_i M_i') and are weighted
 //           by a^2/d, "q-tiles" hold M_i and are weighted by a r/d
 #pragma once
 #include <stdint.h>
@@ -30,13 +30,14 @@ struct SightlineDev {
     int ntw;        // w-tiles: ceil(k (k + 1) / 2 / 16)
     int ntq;        // q-tiles: ceil(k / 16)
     int row_width;  // (ntw + ntq) * 16 + DLAGP_ROW_EXTRA doubles per partial row
+    int npair;      // ceil((ntw + ntq) / 2): tile pairs per step in P
     const double *y;       // [n_pad]  padding: 0
     const double *mu;      // [n_pad]  padding: 0
     const double *omega2;  // [n_pad]  padding: 0
     const double *v;       // [n_pad]  padding: 1  (so d = 1, log d = 0, r = 0)
     const int *pos;        // [n_pad]  first entry of the pixel's window; padding: pos[n - 1]
     const double *lam;     // [E]      observed wavelength of every entry, Angstrom
-    const double *P;       // [nsteps][ntw + ntq][4][16] shared operand, see build_shared_operand
+    const double *P;       // [nsteps][tile pairs][64][2] shared operand, see build_shared_operand
     const double *aux;     // [n_pad][8] per-pixel records {y, mu, omega2, v, pos, 0, 0, 0} (MFMA path)
     double taps[DLAGP_NUM_TAPS];  // instrument profile (or {1, 0, ...})
 };

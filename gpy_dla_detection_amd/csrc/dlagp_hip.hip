@@ -270,16 +270,16 @@ static int group_plan(LaunchGroup &g, int nsplit, GroupPlan **out) {
     return DLAGP_OK;
 }
 
-// Number of pixel splits.  A workgroup (64 samples) keeps 2 waves on every SIMD busy only when
-// all 512 resident workgroup slots (256 CUs x 2) are taken; a single sightline with S = 10 000
-// has just 157 sample groups, so its pixels are cut into floor(512 / groups) equal splits whose
+// Number of pixel splits.  Every SIMD holds 2 waves only when all 2048 resident wave slots are
+// taken; a single sightline with S = 10 000 has just 625 sample groups (one wave each), so its
+// pixels are cut into floor(2048 / groups) equal splits whose
 // partial sums the finalize kernel adds in a fixed order.  More splits than that would only add
 // partial-sum traffic and halo recomputation.
 static int choose_splits(const LaunchGroup &g, int64_t S) {
     const int max_h = std::max(1, g.max_chunks);
     if (g_opt_pixel_splits > 0) return (int)std::min<int64_t>(g_opt_pixel_splits, max_h);
     const long groups = (long)g.ctxs.size() * ((S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP);
-    const long slots = 512;
+    const long slots = 2048;  // 256 CUs x 4 SIMDs x 2 resident waves
     long h = groups >= slots ? 1 : slots / groups;
     return (int)std::min<long>(std::max<long>(1, h), std::max(1, max_h / DLAGP_MAX_PASS_CHUNKS));
 }
@@ -304,12 +304,12 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
     const long rows = (long)nb * S;
     const SightlineDev *table = g.d_table.as<SightlineDev>();
 
-    // the MFMA kernel keeps 64 samples' per-absorber constants in LDS next to 66 KB of static LDS
+    // the MFMA kernel keeps its 16 samples' per-absorber constants in dynamic LDS
     const size_t mfma_prep_lds = (size_t)DLAGP_MFMA_GROUP * std::max(kd, 1) * (g.num_lines + 1) * sizeof(double);
-    bool use_mfma = g.mfma_ok && kd >= 1 && mfma_prep_lds <= 48 * 1024;
+    bool use_mfma = g.mfma_ok && kd >= 1 && mfma_prep_lds <= 40 * 1024;
     if (g_opt_path == 1) use_mfma = false;
     if (g_opt_path == 2 && kd >= 1) {
-        if (!g.mfma_ok || mfma_prep_lds > 48 * 1024)
+        if (!g.mfma_ok || mfma_prep_lds > 40 * 1024)
             return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (rank > 20, ragged mask, or kd x lines too large)");
         use_mfma = true;
     }
@@ -481,6 +481,7 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
     sl.ntw = (k_eff * (k_eff + 1) / 2 + DLAGP_TILE_COLS - 1) / DLAGP_TILE_COLS;
     sl.ntq = (k_eff + DLAGP_TILE_COLS - 1) / DLAGP_TILE_COLS;
     sl.row_width = (sl.ntw + sl.ntq) * DLAGP_TILE_COLS + DLAGP_ROW_EXTRA;
+    sl.npair = (sl.ntw + sl.ntq + 1) / 2;
     for (int t = 0; t < DLAGP_NUM_TAPS; ++t) sl.taps[t] = broadening ? DLAGP_INSTRUMENT_PROFILE[t] : (t == 0 ? 1.0 : 0.0);
 
     // padded host images
@@ -514,8 +515,7 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
         return DLAGP_OK;
     };
     DeviceBuffer dM;
-    const int nt = sl.ntw + sl.ntq;
-    const size_t p_bytes = (size_t)sl.nsteps * nt * DLAGP_TILE_DOUBLES * sizeof(double);
+    const size_t p_bytes = (size_t)sl.nsteps * sl.npair * 2 * DLAGP_TILE_DOUBLES * sizeof(double);
     rc = upload(ctx->y, hy.data(), hy.size() * sizeof(double));
     if (!rc) rc = upload(ctx->mu, hmu.data(), hmu.size() * sizeof(double));
     if (!rc) rc = upload(ctx->omega2, ho.data(), ho.size() * sizeof(double));
@@ -549,7 +549,7 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
     sl.aux = ctx->aux.as<double>();
 
     hipLaunchKernelGGL(build_shared_operand, dim3(1024), dim3(256), 0, nullptr, dM.as<double>(), n, sl.n_pad, k_eff,
-                       sl.ntw, sl.ntq, ctx->P.as<double>());
+                       sl.ntw, sl.ntq, sl.npair, ctx->P.as<double>());
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) err = hipDeviceSynchronize();
     dM.release();

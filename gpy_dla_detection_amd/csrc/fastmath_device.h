@@ -19,6 +19,13 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
+// 1/x with a single Newton step: v_rcp_f64 is good to 4.6e-8, one step gives 2.2e-15
+// (profiles/r01_microbench_dp_pipe.txt) -- enough for weights and wing terms
+__device__ __forceinline__ double fast_rcp1(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(r, fma(-x, r, 1.0), r);
+}
+
 // exp(x) for x <= 0 (also correct for moderate x > 0); max relative error 5e-16.
 // x = k ln2 + r, |r| <= ln2/2, e^r by a degree-10 fit, scaled with v_ldexp_f64 (underflows to 0).
 __device__ __forceinline__ double fast_exp(double x) {

@@ -14,23 +14,27 @@ namespace dlagp {
 __host__ __device__ __forceinline__ int vech_col(int i, int j) { return i * (i + 1) / 2 + j; }
 
 // ---------------------------------------------------------------------------------------------
-// Shared operand P[step][tile][4][16] of one sightline, built once at dlagp_create:
+// Shared operand P of one sightline, built once at dlagp_create:
 //   w-tiles: P[i][vech_col(a, b)] = M[i][a] M[i][b]   -> B - I = sum_i w_i P_i   (null_gp.py:339)
 //   q-tiles: P[i][ntw*16 + c]     = M[i][c]           -> u     = sum_i q_i M_i   (null_gp.py:346-354)
 // Padding pixels and padding columns are zero, so they contribute exactly nothing.
-// M_dev is dense row-major [n][k].
-// ---------------------------------------------------------------------------------------------
+// Layout [step][tile pair j][lane][2]: lane = slot * 16 + column-in-tile is the MFMA B-operand
+// lane of pixel 4 step + slot, and the two doubles are tiles 2j and 2j + 1, so one 16-byte load
+// per lane fetches the operands of two MFMAs.  M_dev is dense row-major [n][k].
+__host__ __device__ __forceinline__ long shared_operand_index(int step, int tile, int slot, int cc, int npair) {
+    return (((long)step * npair + tile / 2) * DLAGP_TILE_DOUBLES + slot * DLAGP_TILE_COLS + cc) * 2 + (tile & 1);
+}
+
 __global__ void build_shared_operand(const double *__restrict__ M_dev, int n, int n_pad, int k, int ntw,
-                                     int ntq, double *__restrict__ P) {
-    const int nt = ntw + ntq;
+                                     int ntq, int npair, double *__restrict__ P) {
+    const int nt = 2 * npair;
     const long total = (long)n_pad * nt * DLAGP_TILE_COLS;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         const int cc = idx % DLAGP_TILE_COLS;
-        const int slot = (idx / DLAGP_TILE_COLS) % DLAGP_STEP_PIXELS;
-        const int tile = (idx / DLAGP_TILE_DOUBLES) % nt;
-        const int step = idx / ((long)DLAGP_TILE_DOUBLES * nt);
-        const int i = step * DLAGP_STEP_PIXELS + slot;
+        const int tile = (idx / DLAGP_TILE_COLS) % nt;
+        const int i = idx / ((long)DLAGP_TILE_COLS * nt);
+        const int step = i / DLAGP_STEP_PIXELS, slot = i % DLAGP_STEP_PIXELS;
         double val = 0.0;
         if (i < n) {
             if (tile < ntw) {
@@ -41,12 +45,12 @@ __global__ void build_shared_operand(const double *__restrict__ M_dev, int n, in
                 while (a * (a + 1) / 2 > col) --a;
                 const int b = col - a * (a + 1) / 2;
                 if (a < k) val = M_dev[(long)i * k + a] * M_dev[(long)i * k + b];
-            } else {
+            } else if (tile < ntw + ntq) {
                 const int c = (tile - ntw) * DLAGP_TILE_COLS + cc;
                 if (c < k) val = M_dev[(long)i * k + c];
             }
         }
-        P[idx] = val;
+        P[shared_operand_index(step, tile, slot, cc, npair)] = val;
     }
 }
 

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dlagp_device.h"
+#include "kernels_common.h"
 #include "voigt_device.h"
 
 namespace dlagp {
@@ -106,13 +107,12 @@ __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
         const int tile = c / DLAGP_TILE_COLS;
         const int cc = c % DLAGP_TILE_COLS;
         const double *weight = tile < sl.ntw ? w : a;
-        const double *col = sl.P + (long)tile * DLAGP_TILE_DOUBLES + cc;
         double acc = 0.0;
         for (int step = 0; step < sl.nsteps; ++step) {
-            const double *blk = col + (long)step * nt * DLAGP_TILE_DOUBLES;
 #pragma unroll
             for (int slot = 0; slot < DLAGP_STEP_PIXELS; ++slot)
-                acc = fma(weight[step * DLAGP_STEP_PIXELS + slot], blk[slot * DLAGP_TILE_COLS], acc);
+                acc = fma(weight[step * DLAGP_STEP_PIXELS + slot],
+                          sl.P[shared_operand_index(step, tile, slot, cc, sl.npair)], acc);
         }
         prow[c * rows] = acc;
     }
