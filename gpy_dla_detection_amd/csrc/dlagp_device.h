@@ -52,7 +52,7 @@ struct LineConstants {
     double k_core[DLAGP_MAX_LINES];      // lc_l / (sqrt(2 pi) sigma)
     double k_wing[DLAGP_MAX_LINES];      // k_core * y / sqrt(pi): prefactor of the asymptotic form
     // far wing, everything folded: tau_l = u W_l(u), u = 1/x^2,
-    // W_l(u) = k_wing [A(u) - y^2 u (1 + 5u + 26.25u^2)], A = degree-5 fit (faddeeva_table.h)
+    // W_l(u) = k_wing [A(u) - y^2 u (1 + 5u + 26.25u^2)], A = near-minimax fit (faddeeva_table.h)
     double wing[DLAGP_MAX_LINES][6];
     double inv_sqrt2_sigma;              // 1 / (sqrt2 sigma)
     double c;                            // speed of light, cm/s

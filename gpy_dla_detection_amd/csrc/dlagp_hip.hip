@@ -87,8 +87,9 @@ static int ensure_device(int device) {
         lc.k_wing[l] = lc.k_core[l] * lc.y[l] / std::sqrt(M_PI);
         const double a[DLAGP_WING_DEGREE + 1] = DLAGP_WING_COEF_INIT;
         const double y2 = lc.y[l] * lc.y[l];
-        const double corr[DLAGP_WING_DEGREE + 1] = {0.0, 1.0, 5.0, 26.25, 0.0, 0.0};
-        for (int m = 0; m <= DLAGP_WING_DEGREE; ++m) lc.wing[l][m] = lc.k_wing[l] * (a[m] - y2 * corr[m]);
+        const double corr[6] = {0.0, 1.0, 5.0, 26.25, 0.0, 0.0};  // y^2 u (1 + 5u + 26.25u^2)
+        for (int m = 0; m < 6; ++m)
+            lc.wing[l][m] = m <= DLAGP_WING_DEGREE ? lc.k_wing[l] * (a[m] - y2 * corr[m]) : 0.0;
     }
     lc.inv_sqrt2_sigma = 1.0 / sqrt2_sigma;
     lc.c = DLAGP_SPEED_OF_LIGHT_CGS;
@@ -163,6 +164,7 @@ struct LaunchGroup {
     std::vector<dlagp_ctx *> ctxs;
     DeviceBuffer d_table;  // SightlineDev[nb]
     int k = 0, row_width = 0, num_lines = 0;
+    bool broadening = true;
     int max_entries = 0, max_npad = 0, max_chunks = 0;
     bool mfma_ok = false;
     Workspace ws;
@@ -287,11 +289,11 @@ static int choose_splits(const LaunchGroup &g, int64_t S) {
 // ------------------------------------------------------------------------------------------------
 // launch sequence common to single-sightline and batch evaluation
 // ------------------------------------------------------------------------------------------------
-template <int LINES, bool MULTI>
+template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, GroupPlan *gp, int nsplit,
                         long S, int kd, int num_lines, const double *prep, double *part, long rows) {
     const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * kd * ((LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
-    hipLaunchKernelGGL((accumulate_mfma<LINES, MULTI>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream, table,
+    hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream, table,
                        gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S, kd, prep,
                        part, rows);
 }
@@ -347,12 +349,12 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
         const bool lines3 = g.num_lines == 3;
         double *part = ws.part.as<double>();
         const double *prep = ws.prep.as<double>();
-        if (kd == 1) {
-            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
-            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
-        } else {
+        if (g.broadening) {
             if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
             else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
+        } else {
+            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
+            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
         }
         HIP_TRY(hipGetLastError());
     } else {
@@ -418,13 +420,15 @@ static int finish_group(LaunchGroup &g) {
     g.k = g.ctxs[0]->sl.k;
     g.row_width = g.ctxs[0]->sl.row_width;
     g.num_lines = g.ctxs[0]->sl.num_lines;
+    g.broadening = g.ctxs[0]->sl.ntaps > 1;
     g.mfma_ok = true;
     for (dlagp_ctx *ctx : g.ctxs) {
         table.push_back(ctx->sl);
         g.max_entries = std::max(g.max_entries, ctx->sl.num_entries);
         g.max_npad = std::max(g.max_npad, ctx->sl.n_pad);
         g.max_chunks = std::max(g.max_chunks, ctx->sl.n_pad / DLAGP_CHUNK_PIXELS);
-        g.mfma_ok = g.mfma_ok && ctx->mfma_ok && ctx->sl.num_lines == g.num_lines;
+        g.mfma_ok = g.mfma_ok && ctx->mfma_ok && ctx->sl.num_lines == g.num_lines &&
+                    (ctx->sl.ntaps > 1) == g.broadening;
     }
     int rc = g.d_table.reserve(table.size() * sizeof(SightlineDev));
     if (rc) return rc;

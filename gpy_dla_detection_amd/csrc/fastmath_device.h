@@ -26,16 +26,25 @@ __device__ __forceinline__ double fast_rcp1(double x) {
     return fma(r, fma(-x, r, 1.0), r);
 }
 
-// exp(x) for x <= 0 (also correct for moderate x > 0); max relative error 5e-16.
-// x = k ln2 + r, |r| <= ln2/2, e^r by a degree-10 fit, scaled with v_ldexp_f64 (underflows to 0).
+// exp(x) for x <= 0 (also correct for moderate x > 0); max relative error 2e-14.
+// x = k ln2 + r, |r| <= ln2/2, e^r by a degree-9 fit, scaled with v_ldexp_f64 (underflows to 0).
+// One Horner step p * r + c with the coefficient forced into a scalar register pair.  hipcc
+// otherwise parks the ten coefficients in 20 VGPRs and emits a v_mov_b64 + v_fmac_f64 pair per
+// step; the VGPRs are needed for the MFMA accumulators and the copies cost issue slots.
+__device__ __forceinline__ double horner_sgpr(double p, double r, double c) {
+    double out;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(out) : "v"(p), "v"(r), "s"(c));
+    return out;
+}
+
 __device__ __forceinline__ double fast_exp(double x) {
     constexpr double c[DLAGP_EXP_DEGREE + 1] = DLAGP_EXP_COEF_INIT;
     const double k = __builtin_rint(x * 1.44269504088896338700e+00);
     double r = fma(k, -6.93147180369123816490e-01, x);
     r = fma(k, -1.90821492927058770002e-10, r);
-    double p = c[DLAGP_EXP_DEGREE];
+    double p = fma(c[DLAGP_EXP_DEGREE], r, c[DLAGP_EXP_DEGREE - 1]);
 #pragma unroll
-    for (int m = DLAGP_EXP_DEGREE - 1; m >= 0; --m) p = fma(p, r, c[m]);
+    for (int m = DLAGP_EXP_DEGREE - 2; m >= 0; --m) p = horner_sgpr(p, r, c[m]);
     // clamp the exponent so the int conversion is defined for -inf / huge arguments
     const double kc = fmax(k, -2200.0);
     return __builtin_amdgcn_ldexp(p, (int)kc);
@@ -56,4 +65,13 @@ struct LogProduct {
     }
 };
 
+// broadcast one lane's double to the whole wave through SGPRs (two v_readlane_b32); `src_lane`
+// must be wave-uniform
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
 }  // namespace dlagp
+

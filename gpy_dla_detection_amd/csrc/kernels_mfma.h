@@ -44,7 +44,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define DLAGP_MFMA_GROUP 16      // samples per wave / workgroup
 #define DLAGP_MFMA_THREADS 64
 #define DLAGP_PASS_ENTRIES 64
-#define DLAGP_RAW_STRIDE 66      // doubles per sample row in LDS; stride/2 odd -> conflict-free b64 reads
+#define DLAGP_RAW_STRIDE 67      // doubles per sample row in LDS; odd -> conflict-free ds_read2_b64 windows
 #define DLAGP_CHUNK_PIXELS 8     // planning granule = 2 steps
 #define DLAGP_MAX_PASS_CHUNKS 7  // 56 pixels
 #define DLAGP_MAX_PASS_STEPS (2 * DLAGP_MAX_PASS_CHUNKS)
@@ -71,76 +71,92 @@ __global__ void prepare_samples(const double *__restrict__ z, const double *__re
     dst[num_lines] = nhi[idx];
 }
 
-// optical depth per unit column density at one entry, all lines; `mult` is wave-uniform (LDS)
+// Far-wing term of one line, valid for x^2 >= 256; for smaller x^2 (and NaN) the reciprocal is clamped
+// so that the value stays finite and reproducible -- the caller replaces it on the core path.
+__device__ __forceinline__ double wing_term(double x2, const double *__restrict__ w) {
+    const double u = fmin(fast_rcp1(x2), 1.0 / (DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT));
+    double poly = w[DLAGP_WING_DEGREE];
+#pragma unroll
+    for (int m = DLAGP_WING_DEGREE - 1; m >= 0; --m) poly = fma(poly, u, w[m]);
+    return u * poly;
+}
+
+// Optical depth per unit column density at one entry, all lines (voigt.py:304-309 without the
+// sign and the N factor).  `mult[l]` are wave-uniform.  Every line first gets its far-wing term
+// unconditionally; if any lane of the wave sits within 16 Doppler widths of a line centre
+// (~6 entries per line and absorber) a wave-uniform branch swaps that lane's term for the
+// Taylor/table evaluation.
 template <int LINES>
 __device__ __forceinline__ double optical_depth(double lam, const double *__restrict__ mult, int num_lines) {
     const int L = LINES > 0 ? LINES : num_lines;
     const double x_offset = -DLAGP_LINES.c * DLAGP_LINES.inv_sqrt2_sigma;
+    constexpr double split2 = DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT;
     double tau = 0.0;
-    double xs[LINES > 0 ? LINES : 1];
-    bool any_core = false;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const double x = fma(lam, mult[l], x_offset);
-        if (LINES > 0) xs[l] = x;
-        const double x2 = x * x;
-        const bool core = !(x2 >= DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT);  // also catches NaN
-        // core lanes get a finite dummy argument; their term is discarded below
-        const double u = fast_rcp1(core ? DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT : x2);
-        const double *w = DLAGP_LINES.wing[l];
-        double poly = w[DLAGP_WING_DEGREE];
-#pragma unroll
-        for (int m = DLAGP_WING_DEGREE - 1; m >= 0; --m) poly = fma(poly, u, w[m]);
-        if (LINES > 0) {
-            any_core |= core;
-            tau = fma(core ? 0.0 : u, poly, tau);
-        } else {
-            double term = u * poly;
-            if (core) term = DLAGP_LINES.k_core[l] * core_taylor(x, DLAGP_LINES.y[l]);
-            if (term == term) tau += term;  // np.nansum (voigt.py:309)
-        }
-    }
     if (LINES > 0) {
-        // rare: some lane sits within 16 Doppler widths of a line centre (~6 entries per line)
+        double xs[LINES > 0 ? LINES : 1];
+        bool any_core = false;
+#pragma unroll
+        for (int l = 0; l < LINES; ++l) {
+            const double x = fma(lam, mult[l], x_offset);
+            xs[l] = x;
+            const double x2 = x * x;
+            any_core |= !(x2 >= split2);  // also catches NaN
+            tau += wing_term(x2, DLAGP_LINES.wing[l]);
+        }
         if (__builtin_amdgcn_ballot_w64(any_core)) {
 #pragma unroll
-            for (int l = 0; l < L; ++l) {
+            for (int l = 0; l < LINES; ++l) {
                 const double x = xs[l];
-                if (!(x * x >= DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT)) {
+                const double x2 = x * x;
+                if (!(x2 >= split2)) {
+                    tau -= wing_term(x2, DLAGP_LINES.wing[l]);
                     const double term = DLAGP_LINES.k_core[l] * core_taylor(x, DLAGP_LINES.y[l]);
-                    if (term == term) tau += term;
+                    if (term == term) tau += term;  // np.nansum (voigt.py:309)
                 }
             }
+        }
+    } else {
+        for (int l = 0; l < L; ++l) {
+            const double x = fma(lam, mult[l], x_offset);
+            const double x2 = x * x;
+            double term = wing_term(x2, DLAGP_LINES.wing[l]);
+            if (!(x2 >= split2)) term = DLAGP_LINES.k_core[l] * core_taylor(x, DLAGP_LINES.y[l]);
+            if (term == term) tau += term;
         }
     }
     return tau;
 }
 
-// 7-tap (or 1-tap) window of the raw profile = instrument convolution (voigt.py:319)
-__device__ __forceinline__ double convolve_window(const double *win, int ntaps, const double (&tap)[DLAGP_NUM_TAPS]) {
-    double conv = win[0] * tap[0];
-    if (ntaps > 1) {
-#pragma unroll
-        for (int t = 1; t < DLAGP_NUM_TAPS; ++t) conv = fma(win[t], tap[t], conv);
-    }
-    return conv;
+// Pointers read out of the descriptor table are generic to the compiler, which then emits flat_*
+// loads whose completion can only be awaited with vmcnt(0) + lgkmcnt(0) -- that serialises every
+// prefetch.  These typedefs pin them to the global address space.
+typedef const __attribute__((address_space(1))) double *gptr_d;
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) v2d *gptr_d2;
+typedef const __attribute__((address_space(1))) v4d *gptr_d4;
+
+template <typename G, typename T>
+__device__ __forceinline__ G as_global(const T *p) {
+    return (G)(__attribute__((address_space(1))) const void *)(p);
 }
 
 // grid: (ngroups * nsplit, nb); block: one wave.
 //   block L -> split = L % nsplit, sample group (16 samples) = L / nsplit.
-// MULTI = false: exactly one absorber per sample, convolution fused into the MFMA loop.
-// MULTI = true : kd absorbers; each absorber's profile is convolved and multiplied into an LDS
-//                buffer a[sample][pixel of the pass] before the MFMA loop (dla_gp.py:379-386).
+// BROADEN: 7-tap instrument convolution (true) or the raw profile itself (false).
+// Any number of absorbers kd >= 1: each absorber's profile is convolved and multiplied into the LDS
+// buffer a[sample][pixel of the pass] before the MFMA loop (dla_gp.py:370-388).
 // Dynamic LDS: the wave's per-sample constants, 16 samples x kd x (L + 1) doubles.
-template <int LINES, bool MULTI>
+template <int LINES, bool BROADEN>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
     const int2 *const *__restrict__ split_tables, int nsplit, long S, int kd,
     const double *__restrict__ prep, double *__restrict__ part, long rows) {
+    constexpr int A_STRIDE = 4 * DLAGP_MAX_PASS_STEPS + 2;  // 58: stride/2 odd -> conflict-free b64 reads
     __shared__ double raw[16 * DLAGP_RAW_STRIDE];
-    __shared__ double a_lds[MULTI ? 16 * (4 * DLAGP_MAX_PASS_STEPS + 2) : 2];
+    __shared__ double a_lds[16 * A_STRIDE];
+    __shared__ int pos_lds[64];
     extern __shared__ double prep_lds[];
-    constexpr int A_STRIDE = 4 * DLAGP_MAX_PASS_STEPS + 2;
 
     const int b = blockIdx.y;
     const SightlineDev &sl = sightlines[b];
@@ -152,10 +168,10 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
 
     // descriptor fields used in the loops, read once
     const int num_entries = sl.num_entries;
-    const int ntaps = sl.ntaps;
-    const double *__restrict__ lam_ptr = sl.lam;
-    const double2 *__restrict__ p_ptr = reinterpret_cast<const double2 *>(sl.P);
-    const double *__restrict__ aux_ptr = sl.aux;
+    const gptr_d lam_ptr = as_global<gptr_d>(sl.lam);
+    const gptr_d2 p_ptr = as_global<gptr_d2>(sl.P);
+    const gptr_d aux_ptr = as_global<gptr_d>(sl.aux);
+    const gptr_d prep_ptr = as_global<gptr_d>(prep);
     double tap[DLAGP_NUM_TAPS];
 #pragma unroll
     for (int t = 0; t < DLAGP_NUM_TAPS; ++t) tap[t] = sl.taps[t];
@@ -169,13 +185,13 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     for (int i = lane; i < wave_prep; i += 64) {
         long row = sample0 + i / (kd * prep_stride);
         row = row < S ? row : S - 1;
-        prep_lds[i] = prep[((long)b * S + row) * kd * prep_stride + i % (kd * prep_stride)];
+        prep_lds[i] = prep_ptr[((long)b * S + row) * kd * prep_stride + i % (kd * prep_stride)];
     }
 
     const PassDesc *passes = pass_tables[b];
-    const int2 span = split_tables[b][split];  // passes [x, y)
-    const int first_step = span.x < span.y ? 2 * passes[span.x].chunk_begin : 0;
-    const int end_step = span.x < span.y ? 2 * (passes[span.y - 1].chunk_begin + passes[span.y - 1].nchunks) : 0;
+    const int2 span_v = split_tables[b][split];  // passes [x, y)
+    const int pass_begin = __builtin_amdgcn_readfirstlane(span_v.x);
+    const int pass_end = __builtin_amdgcn_readfirstlane(span_v.y);
 
     d4 acc[DLAGP_MFMA_NT];
 #pragma unroll
@@ -183,92 +199,106 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     double sum_r2 = 0.0;
     LogProduct dprod;
 
-    // B operand of the first step: 8 x double2 per lane (tile pair j -> tiles 2j, 2j+1)
+    // B operand: 8 x double2 per lane and step (tile pair j -> tiles 2j, 2j+1); per-pixel record
+    // {y, mu, omega2, v}.  Both are (re)loaded one step ahead of use inside a pass, and for the
+    // first step of a pass during the convolution, so that they are not live in the Voigt loop.
     constexpr int NPAIR = DLAGP_MFMA_NT / 2;
-    double2 frag[NPAIR];
-    {
-        const double2 *src = p_ptr + (long)first_step * NPAIR * 64 + lane;
-#pragma unroll
-        for (int j = 0; j < NPAIR; ++j) frag[j] = src[j * 64];
-    }
-    // per-pixel record of the first step: y, mu, omega2, v, window start
-    const double *rec_src = aux_ptr + ((long)first_step * DLAGP_STEP_PIXELS + slot) * DLAGP_AUX_FIELDS;
-    double rec_y = rec_src[0], rec_mu = rec_src[1], rec_o = rec_src[2], rec_v = rec_src[3], rec_pos = rec_src[4];
+    v2d frag[NPAIR];
+    v4d rec;
 
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    for (int pass = pass_begin; pass < pass_end; ++pass) {
+        const PassDesc pd_v = passes[pass];
+        const int entry_start = __builtin_amdgcn_readfirstlane(pd_v.entry_start);
+        const int step0 = __builtin_amdgcn_readfirstlane(2 * pd_v.chunk_begin);
+        const int pass_steps = __builtin_amdgcn_readfirstlane(2 * pd_v.nchunks);
 
-    for (int pass = span.x; pass < span.y; ++pass) {
-        const PassDesc pd = passes[pass];
-        const int pass_steps = 2 * pd.nchunks;
-        const int step0 = 2 * pd.chunk_begin;
+        // window start of pixel (lane) of this pass, relative to the pass; consumed after the Voigt loop
+        int my_pix = step0 * DLAGP_STEP_PIXELS + lane;
+        my_pix = lane < pass_steps * DLAGP_STEP_PIXELS ? my_pix : step0 * DLAGP_STEP_PIXELS;
+        const int my_pos = (int)aux_ptr[(long)my_pix * DLAGP_AUX_FIELDS + 4] - entry_start;
 
-        // ---------------- phase 1: raw profiles of the wave's 16 samples ----------------
-        int e = pd.entry_start + lane;
+        // ---------------- phase 1: raw profile and convolution, absorber by absorber ----------------
+        int e = entry_start + lane;
         e = e < num_entries ? e : num_entries - 1;
         const double lam = lam_ptr[e];
-        if (!MULTI) {
-#pragma unroll 2
-            for (int ss = 0; ss < 16; ++ss) {
-                const double *sp = prep_lds + ss * prep_stride;
-                const double tau = optical_depth<LINES>(lam, sp, L);
-                raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp(-sp[L] * tau);  // voigt.py:309
-            }
-        } else {
-            for (int jd = 0; jd < kd; ++jd) {
+        for (int jd = 0; jd < kd; ++jd) {
+            if (LINES == 3) {
+                // lane i holds constant (i & 3) of sample (i >> 2): {m'_0, m'_1, m'_2, N}; each sample's
+                // four values are then broadcast through SGPRs (no memory latency in the loop)
+                const double pv = prep_lds[((lane >> 2) * kd + jd) * 4 + (lane & 3)];
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) here, not at the loop header
+#pragma unroll 1
+                for (int ss = 0; ss < 16; ++ss) {
+                    const double m[3] = {readlane_f64(pv, 4 * ss), readlane_f64(pv, 4 * ss + 1),
+                                         readlane_f64(pv, 4 * ss + 2)};
+                    const double tau = optical_depth<LINES>(lam, m, 3);
+                    raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp(-readlane_f64(pv, 4 * ss + 3) * tau);  // voigt.py:309
+                }
+            } else {
 #pragma unroll 2
                 for (int ss = 0; ss < 16; ++ss) {
                     const double *sp = prep_lds + (ss * kd + jd) * prep_stride;
                     const double tau = optical_depth<LINES>(lam, sp, L);
                     raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp(-sp[L] * tau);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                for (int st = 0; st < pass_steps; ++st) {
-                    const int pix = (step0 + st) * DLAGP_STEP_PIXELS + slot;
-                    const int p = (int)aux_ptr[(long)pix * DLAGP_AUX_FIELDS + 4] - pd.entry_start;
-                    const double conv = convolve_window(raw + s_loc * DLAGP_RAW_STRIDE + p, ntaps, tap);
+            }
+            if (jd == 0) {
+                pos_lds[lane] = my_pos;
+                // operands of the pass's first step: in flight during the convolution
+                const gptr_d2 src = p_ptr + (long)step0 * NPAIR * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < NPAIR; ++j) frag[j] = src[j * 64];
+                rec = *(gptr_d4)(aux_ptr + ((long)step0 * DLAGP_STEP_PIXELS + slot) * DLAGP_AUX_FIELDS);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // convolution (voigt.py:319) on the kept pixels (dla_gp.py:388), product over absorbers;
+            // fully unrolled so that the LDS reads of different steps overlap
+#pragma unroll
+            for (int st = 0; st < DLAGP_MAX_PASS_STEPS; ++st) {
+                if (st < pass_steps) {
+                    const double *win = raw + s_loc * DLAGP_RAW_STRIDE + pos_lds[st * DLAGP_STEP_PIXELS + slot];
+                    double conv;
+                    if (BROADEN) {
+                        conv = win[0] * tap[0];
+#pragma unroll
+                        for (int t = 1; t < DLAGP_NUM_TAPS; ++t) conv = fma(win[t], tap[t], conv);
+                    } else {
+                        conv = win[0];
+                    }
                     double *dst = &a_lds[s_loc * A_STRIDE + st * DLAGP_STEP_PIXELS + slot];
                     *dst = jd == 0 ? conv : *dst * conv;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
 
         // ---------------- phase 2: weights and MFMAs, step by step ----------------
+        const double *a_row = &a_lds[s_loc * A_STRIDE + slot];
+        double a = a_row[0];
         for (int st = 0; st < pass_steps; ++st) {
-            const int step = step0 + st;
-            double a;
-            if (MULTI) {
-                a = a_lds[s_loc * A_STRIDE + st * DLAGP_STEP_PIXELS + slot];
-            } else {
-                a = convolve_window(raw + s_loc * DLAGP_RAW_STRIDE + ((int)rec_pos - pd.entry_start), ntaps, tap);
-            }
             const double a2 = a * a;
-            const double d = fma(rec_o, a2, rec_v);
+            const double d = fma(rec.z, a2, rec.w);
             const double h = fast_rcp1(d);
-            const double r = fma(-rec_mu, a, rec_y);
+            const double r = fma(-rec.y, a, rec.x);
             const double rh = r * h;
             const double w = a2 * h;
             const double q = a * rh;
             sum_r2 = fma(r, rh, sum_r2);
             dprod.multiply(d);
 
-            // next step's operands (clamped at the end of the split: a harmless re-read)
-            const int nxt = step + 1 < end_step ? step + 1 : step;
-            const double *nrec = aux_ptr + ((long)nxt * DLAGP_STEP_PIXELS + slot) * DLAGP_AUX_FIELDS;
-            rec_y = nrec[0];
-            rec_mu = nrec[1];
-            rec_o = nrec[2];
-            rec_v = nrec[3];
-            rec_pos = nrec[4];
-            const double2 *src = p_ptr + (long)nxt * NPAIR * 64 + lane;
+            // next step's operands; the last step of a pass re-reads its own (harmless, never used)
+            const int nxt = step0 + (st + 1 < pass_steps ? st + 1 : st);
+            rec = *(gptr_d4)(aux_ptr + ((long)nxt * DLAGP_STEP_PIXELS + slot) * DLAGP_AUX_FIELDS);
+            a = a_row[(st + 1 < pass_steps ? st + 1 : st) * DLAGP_STEP_PIXELS];
+            // keep the two prefetches above in front of the MFMAs: their results are not needed
+            // before the next step, 16 MFMAs (>= 1024 cycles) from here
+            __builtin_amdgcn_sched_barrier(0);
+            const gptr_d2 src = p_ptr + (long)nxt * NPAIR * 64 + lane;
 #pragma unroll
             for (int j = 0; j < NPAIR; ++j) {
-                const double2 f = frag[j];
+                const v2d f = frag[j];
                 acc[2 * j] = __builtin_amdgcn_mfma_f64_16x16x4f64(2 * j < DLAGP_MFMA_NTW ? w : q, f.x, acc[2 * j], 0, 0, 0);
                 acc[2 * j + 1] =
                     __builtin_amdgcn_mfma_f64_16x16x4f64(2 * j + 1 < DLAGP_MFMA_NTW ? w : q, f.y, acc[2 * j + 1], 0, 0, 0);
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
             }
         }
         // the next pass overwrites raw[] / a_lds[]: order the LDS reads above before those writes
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -287,7 +317,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const int rw = sl.row_width;
     const long row_base = (long)b * S + sample0;
     const long rows_left = S - sample0;  // valid samples of this wave
-    double *base = part + (long)split * rw * rows;
+    __attribute__((address_space(1))) double *base =
+        (__attribute__((address_space(1))) double *)(part) + (long)split * rw * rows;
     constexpr int TR_STRIDE = 17;  // [16 columns][16 samples + 1]
 #pragma unroll
     for (int t = 0; t < DLAGP_MFMA_NT; ++t) {
