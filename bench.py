@@ -105,6 +105,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=NUM_SAMPLES, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--splits", type=int, default=0, help=argparse.SUPPRESS)  # tuning: force the pixel-split count
+    ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)  # timing experiments, wrong results
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,6 +141,10 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=device)
 
     dev = sl.DeviceSightline.from_state(sight, device=local_rank)
+    if args.splits:
+        sl.set_option("pixel_splits", args.splits)
+    if args.debug:
+        sl.set_option("debug", args.debug)
     z = torch.from_numpy(z_host).to(device)
     nhi = torch.from_numpy(nhi_host).to(device)
     out = torch.empty(S, dtype=torch.float64, device=device)
@@ -180,6 +186,11 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     sl.set_option("timing", 0)
     kernel_ms, launches = sl.timing_read(reset=True)
+    if args.debug & 2:
+        st = sl.debug_read()
+        if rank == 0 and st[5]:
+            names = ["voigt", "conv", "mfma_loop", "epilogue", "wave_total"]
+            print("stamps: waves=%d  " % st[5] + "  ".join("%s=%.0f" % (n, st[i] / st[5]) for i, n in enumerate(names)) + "  (cycles per wave)", file=sys.stderr)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)

@@ -53,6 +53,7 @@ static int fail(int code, const char *fmt, ...) {
 static int64_t g_opt_pixel_splits = 0;
 static int64_t g_opt_path = 0;
 static int64_t g_opt_timing = 0;
+static int64_t g_opt_debug = 0;  // timing experiments (results become wrong); see kernels_mfma.h
 
 struct EventPair {
     hipEvent_t start, stop;
@@ -295,7 +296,7 @@ static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table
     const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * kd * ((LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
     hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream, table,
                        gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S, kd, prep,
-                       part, rows);
+                       part, rows, (int)g_opt_debug);
 }
 
 static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, const double *d_nhi,
@@ -714,11 +715,24 @@ int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, con
     return sweep_from_host(batch->group, S, kd, z, nhi, out);
 }
 
+int dlagp_debug_read(uint64_t *out, int n, int reset) {
+    unsigned long long host[8] = {0};
+    HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(DLAGP_STAMPS), sizeof(host)));
+    for (int i = 0; i < n && i < 8; ++i)
+        if (out) out[i] = host[i];
+    if (reset) {
+        unsigned long long zero[8] = {0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(DLAGP_STAMPS), zero, sizeof(zero)));
+    }
+    return DLAGP_OK;
+}
+
 int dlagp_set_option(const char *name, int64_t value) {
     if (!name) return fail(DLAGP_EINVAL, "option name is NULL");
     if (!strcmp(name, "pixel_splits")) g_opt_pixel_splits = value;
     else if (!strcmp(name, "path")) g_opt_path = value;
     else if (!strcmp(name, "timing")) g_opt_timing = value;
+    else if (!strcmp(name, "debug")) g_opt_debug = value;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 }

@@ -49,6 +49,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define DLAGP_MAX_PASS_CHUNKS 7  // 56 pixels
 #define DLAGP_MAX_PASS_STEPS (2 * DLAGP_MAX_PASS_CHUNKS)
 #define DLAGP_AUX_FIELDS 8       // per-pixel record: y, mu, omega2, v, window start, 3 spare
+#define DLAGP_BUFFER_FLAGS 0x00020000  // word 3 of a raw buffer resource on gfx9-family targets
 
 struct PassDesc {
     int entry_start;  // first entry computed by phase 1
@@ -136,9 +137,34 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) v2d *gptr_d2;
 typedef const __attribute__((address_space(1))) v4d *gptr_d4;
 
+// ... and to scalar registers: the value is the same in every lane, but having come out of a
+// vector load the compiler would otherwise keep it (and every address derived from it) in VGPRs.
 template <typename G, typename T>
 __device__ __forceinline__ G as_global(const T *p) {
-    return (G)(__attribute__((address_space(1))) const void *)(p);
+    const unsigned long long bits = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bits);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(bits >> 32));
+    return (G)(__attribute__((address_space(1))) const void *)(((unsigned long long)hi << 32) | lo);
+}
+
+// Diagnostic cycle stamps (debug bit 1): per-phase shader-clock totals over all waves, read back with
+// dlagp_debug_read.  Slots: 0 Voigt sample loop, 1 convolution, 2 weights + MFMA loop, 3 epilogue,
+// 4 whole wave, 5 wave count.  Off in production launches (one scalar branch per phase).
+__device__ unsigned long long DLAGP_STAMPS[8];
+
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+// Orders this wave's LDS traffic: the LDS executes one wave's operations in issue order, so all
+// that is needed between a write and another lane's read is (a) that the compiler keeps the
+// program order and (b) an lgkmcnt wait.  A workgroup-scope fence would also drain vmcnt, i.e.
+// wait for the global prefetches in flight.
+__device__ __forceinline__ void lds_wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // grid: (ngroups * nsplit, nb); block: one wave.
@@ -151,7 +177,7 @@ template <int LINES, bool BROADEN>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
     const int2 *const *__restrict__ split_tables, int nsplit, long S, int kd,
-    const double *__restrict__ prep, double *__restrict__ part, long rows) {
+    const double *__restrict__ prep, double *__restrict__ part, long rows, int debug_flags) {
     constexpr int A_STRIDE = 4 * DLAGP_MAX_PASS_STEPS + 2;  // 58: stride/2 odd -> conflict-free b64 reads
     __shared__ double raw[16 * DLAGP_RAW_STRIDE];
     __shared__ double a_lds[16 * A_STRIDE];
@@ -169,9 +195,15 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     // descriptor fields used in the loops, read once
     const int num_entries = sl.num_entries;
     const gptr_d lam_ptr = as_global<gptr_d>(sl.lam);
-    const gptr_d2 p_ptr = as_global<gptr_d2>(sl.P);
-    const gptr_d aux_ptr = as_global<gptr_d>(sl.aux);
     const gptr_d prep_ptr = as_global<gptr_d>(prep);
+    // P and the per-pixel records are streamed with buffer loads: scalar resource + per-lane byte
+    // offset + scalar step offset + immediate, i.e. no vector address arithmetic in the loops
+    const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)as_global<gptr_d>(sl.P), 0, sl.nsteps * (DLAGP_MFMA_NT * DLAGP_TILE_DOUBLES * 8), DLAGP_BUFFER_FLAGS);
+    const __amdgpu_buffer_rsrc_t aux_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)as_global<gptr_d>(sl.aux), 0, sl.n_pad * (DLAGP_AUX_FIELDS * 8), DLAGP_BUFFER_FLAGS);
+    const int p_voff = lane * 16;                         // one double2 per lane and tile pair
+    const int rec_voff = slot * (DLAGP_AUX_FIELDS * 8);   // this lane's pixel within a step
     double tap[DLAGP_NUM_TAPS];
 #pragma unroll
     for (int t = 0; t < DLAGP_NUM_TAPS; ++t) tap[t] = sl.taps[t];
@@ -199,12 +231,18 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     double sum_r2 = 0.0;
     LogProduct dprod;
 
+    const bool stamps = (debug_flags & 2) != 0;
+    unsigned long long t_voigt = 0, t_conv = 0, t_mfma = 0, t_mark = 0, t_start = 0;
+    if (stamps) t_start = stamp_now();
+
     // B operand: 8 x double2 per lane and step (tile pair j -> tiles 2j, 2j+1); per-pixel record
-    // {y, mu, omega2, v}.  Both are (re)loaded one step ahead of use inside a pass, and for the
-    // first step of a pass during the convolution, so that they are not live in the Voigt loop.
+    // {y, mu | omega2, v}.  Inside a pass both are reloaded one step ahead of use; the first step
+    // of a pass is loaded after the convolution so that the registers are free during phase 1.
     constexpr int NPAIR = DLAGP_MFMA_NT / 2;
+    constexpr int STEP_BYTES = DLAGP_MFMA_NT * DLAGP_TILE_DOUBLES * 8;        // 8192
+    constexpr int REC_STEP_BYTES = DLAGP_STEP_PIXELS * DLAGP_AUX_FIELDS * 8;  // 256
     v2d frag[NPAIR];
-    v4d rec;
+    v2d rec_ym, rec_ov;
 
     for (int pass = pass_begin; pass < pass_end; ++pass) {
         const PassDesc pd_v = passes[pass];
@@ -213,15 +251,17 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         const int pass_steps = __builtin_amdgcn_readfirstlane(2 * pd_v.nchunks);
 
         // window start of pixel (lane) of this pass, relative to the pass; consumed after the Voigt loop
-        int my_pix = step0 * DLAGP_STEP_PIXELS + lane;
-        my_pix = lane < pass_steps * DLAGP_STEP_PIXELS ? my_pix : step0 * DLAGP_STEP_PIXELS;
-        const int my_pos = (int)aux_ptr[(long)my_pix * DLAGP_AUX_FIELDS + 4] - entry_start;
+        const int my_rel = lane < pass_steps * DLAGP_STEP_PIXELS ? lane : 0;
+        const double my_pos_f = __builtin_bit_cast(
+            double, __builtin_amdgcn_raw_buffer_load_b64(aux_rsrc, my_rel * (DLAGP_AUX_FIELDS * 8) + 32,
+                                                         step0 * REC_STEP_BYTES, 0));
 
         // ---------------- phase 1: raw profile and convolution, absorber by absorber ----------------
         int e = entry_start + lane;
         e = e < num_entries ? e : num_entries - 1;
         const double lam = lam_ptr[e];
         for (int jd = 0; jd < kd; ++jd) {
+            if (stamps) t_mark = stamp_now();
             if (LINES == 3) {
                 // lane i holds constant (i & 3) of sample (i >> 2): {m'_0, m'_1, m'_2, N}; each sample's
                 // four values are then broadcast through SGPRs (no memory latency in the loop)
@@ -242,36 +282,46 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                     raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp(-sp[L] * tau);
                 }
             }
-            if (jd == 0) {
-                pos_lds[lane] = my_pos;
-                // operands of the pass's first step: in flight during the convolution
-                const gptr_d2 src = p_ptr + (long)step0 * NPAIR * 64 + lane;
-#pragma unroll
-                for (int j = 0; j < NPAIR; ++j) frag[j] = src[j * 64];
-                rec = *(gptr_d4)(aux_ptr + ((long)step0 * DLAGP_STEP_PIXELS + slot) * DLAGP_AUX_FIELDS);
+            if (stamps) {
+                const unsigned long long now = stamp_now();
+                t_voigt += now - t_mark;
+                t_mark = now;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            // convolution (voigt.py:319) on the kept pixels (dla_gp.py:388), product over absorbers;
-            // fully unrolled so that the LDS reads of different steps overlap
+            if (jd == 0) pos_lds[lane] = (int)my_pos_f - entry_start;
+            lds_wave_sync();
+            // convolution (voigt.py:319) on the kept pixels (dla_gp.py:388), product over absorbers.
+            // Always all 14 steps, branch-free, so that the LDS reads of different steps overlap:
+            // lanes beyond the pass's pixels re-read a valid window and write unused slots.
+            const double *raw_row = raw + s_loc * DLAGP_RAW_STRIDE;
+            double *a_dst = &a_lds[s_loc * A_STRIDE + slot];
 #pragma unroll
             for (int st = 0; st < DLAGP_MAX_PASS_STEPS; ++st) {
-                if (st < pass_steps) {
-                    const double *win = raw + s_loc * DLAGP_RAW_STRIDE + pos_lds[st * DLAGP_STEP_PIXELS + slot];
-                    double conv;
-                    if (BROADEN) {
-                        conv = win[0] * tap[0];
+                const double *win = raw_row + pos_lds[st * DLAGP_STEP_PIXELS + slot];
+                double conv;
+                if (BROADEN) {
+                    conv = win[0] * tap[0];
 #pragma unroll
-                        for (int t = 1; t < DLAGP_NUM_TAPS; ++t) conv = fma(win[t], tap[t], conv);
-                    } else {
-                        conv = win[0];
-                    }
-                    double *dst = &a_lds[s_loc * A_STRIDE + st * DLAGP_STEP_PIXELS + slot];
-                    *dst = jd == 0 ? conv : *dst * conv;
+                    for (int t = 1; t < DLAGP_NUM_TAPS; ++t) conv = fma(win[t], tap[t], conv);
+                } else {
+                    conv = win[0];
                 }
+                const double prev = a_dst[st * DLAGP_STEP_PIXELS];
+                a_dst[st * DLAGP_STEP_PIXELS] = jd == 0 ? conv : prev * conv;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            lds_wave_sync();
+            if (stamps) t_conv += stamp_now() - t_mark;
+        }
+        if (stamps) t_mark = stamp_now();
+
+        // operands of the pass's first step
+        {
+            const int soff = step0 * STEP_BYTES;
+#pragma unroll
+            for (int j = 0; j < NPAIR; ++j)
+                frag[j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      p_rsrc, p_voff + (j & 3) * 1024, soff + (j >> 2) * 4096, 0));
+            rec_ym = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff, step0 * REC_STEP_BYTES, 0));
+            rec_ov = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff + 16, step0 * REC_STEP_BYTES, 0));
         }
 
         // ---------------- phase 2: weights and MFMAs, step by step ----------------
@@ -279,9 +329,9 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         double a = a_row[0];
         for (int st = 0; st < pass_steps; ++st) {
             const double a2 = a * a;
-            const double d = fma(rec.z, a2, rec.w);
+            const double d = fma(rec_ov.x, a2, rec_ov.y);
             const double h = fast_rcp1(d);
-            const double r = fma(-rec.y, a, rec.x);
+            const double r = fma(-rec_ym.y, a, rec_ym.x);
             const double rh = r * h;
             const double w = a2 * h;
             const double q = a * rh;
@@ -289,26 +339,37 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
             dprod.multiply(d);
 
             // next step's operands; the last step of a pass re-reads its own (harmless, never used)
-            const int nxt = step0 + (st + 1 < pass_steps ? st + 1 : st);
-            rec = *(gptr_d4)(aux_ptr + ((long)nxt * DLAGP_STEP_PIXELS + slot) * DLAGP_AUX_FIELDS);
-            a = a_row[(st + 1 < pass_steps ? st + 1 : st) * DLAGP_STEP_PIXELS];
-            // keep the two prefetches above in front of the MFMAs: their results are not needed
-            // before the next step, 16 MFMAs (>= 1024 cycles) from here
+            const int nst = st + 1 < pass_steps ? st + 1 : st;
+            const int nxt = step0 + nst;
+            rec_ym = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff, nxt * REC_STEP_BYTES, 0));
+            rec_ov = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff + 16, nxt * REC_STEP_BYTES, 0));
+            a = a_row[nst * DLAGP_STEP_PIXELS];
+            // keep the prefetches above in front of the MFMAs: their results are not needed before
+            // the next step, 16 MFMAs (>= 1024 cycles) from here
             __builtin_amdgcn_sched_barrier(0);
-            const gptr_d2 src = p_ptr + (long)nxt * NPAIR * 64 + lane;
+            const int soff = nxt * STEP_BYTES;
 #pragma unroll
             for (int j = 0; j < NPAIR; ++j) {
                 const v2d f = frag[j];
                 acc[2 * j] = __builtin_amdgcn_mfma_f64_16x16x4f64(2 * j < DLAGP_MFMA_NTW ? w : q, f.x, acc[2 * j], 0, 0, 0);
                 acc[2 * j + 1] =
                     __builtin_amdgcn_mfma_f64_16x16x4f64(2 * j + 1 < DLAGP_MFMA_NTW ? w : q, f.y, acc[2 * j + 1], 0, 0, 0);
-                frag[j] = src[j * 64];  // rolling prefetch: this pair is next used one full step later
+                // rolling prefetch: this register pair is next used one full step later
+                frag[j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      p_rsrc, p_voff + (j & 3) * 1024, soff + (j >> 2) * 4096, 0));
+            }
+            // pin the interleaving: two MFMAs, then the load that refills their operand pair
+#pragma unroll
+            for (int j = 0; j < NPAIR; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
             }
         }
         // the next pass overwrites raw[] / a_lds[]: order the LDS reads above before those writes
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        lds_wave_sync();
+        if (stamps) t_mfma += stamp_now() - t_mark;
     }
+    if (stamps) t_mark = stamp_now();
 
     // ---------------- epilogue: partial sums to part[split][column][row] ----------------
     // D layout: lane holds column (lane & 15) of rows (lane >> 4) + 4 r of the 16-sample tile.
@@ -324,16 +385,14 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     for (int t = 0; t < DLAGP_MFMA_NT; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) raw[s_loc * TR_STRIDE + slot + 4 * r] = acc[t][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        lds_wave_sync();
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
             const int col = cc * 4 + slot;  // lane -> (sample = s_loc, column = col)
             const double val = raw[col * TR_STRIDE + s_loc];
             if (s_loc < rows_left) base[(long)(t * DLAGP_TILE_COLS + col) * rows + row_base + s_loc] = val;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        lds_wave_sync();
     }
     double logd = dprod.log_value();
     sum_r2 += __shfl_xor(sum_r2, 16);
@@ -344,6 +403,15 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         const long row = row_base + s_loc;
         base[(long)(DLAGP_MFMA_NT * DLAGP_TILE_COLS) * rows + row] = sum_r2;
         base[(long)(DLAGP_MFMA_NT * DLAGP_TILE_COLS + 1) * rows + row] = logd;
+    }
+    if (stamps && lane == 0) {
+        const unsigned long long now = stamp_now();
+        atomicAdd(&DLAGP_STAMPS[0], t_voigt);
+        atomicAdd(&DLAGP_STAMPS[1], t_conv);
+        atomicAdd(&DLAGP_STAMPS[2], t_mfma);
+        atomicAdd(&DLAGP_STAMPS[3], now - t_mark);
+        atomicAdd(&DLAGP_STAMPS[4], now - t_start);
+        atomicAdd(&DLAGP_STAMPS[5], 1ULL);
     }
 }
 

@@ -186,3 +186,10 @@ def timing_read(reset: bool = True):
     launches = ctypes.c_int64()
     _lib.check(_lib.load().dlagp_timing_read(ctypes.byref(total), ctypes.byref(launches), int(reset)))
     return total.value, launches.value
+
+
+def debug_read(reset: bool = True):
+    """per-phase shader-clock totals recorded while option 'debug' bit 1 was set (diagnostics)"""
+    buf = (ctypes.c_uint64 * 8)()
+    _lib.check(_lib.load().dlagp_debug_read(buf, 8, int(reset)))
+    return list(buf)

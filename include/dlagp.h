@@ -131,12 +131,17 @@ int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, con
  * Tuning / measurement hooks.
  *   dlagp_set_option: "pixel_splits" (0 = automatic), "path" (0 = automatic, 1 = generic
  *                     kernel, 2 = MFMA kernel), "timing" (1 = bracket the accumulate kernel
- *                     of every launch with HIP events on its stream)
+ *                     of every launch with HIP events on its stream), "debug" (bit 0: timing
+ *                     experiment that re-reads one block of P -- wrong results; bit 1: phase stamps)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.
  */
 int dlagp_set_option(const char *name, int64_t value);
 int dlagp_timing_read(double *total_ms, int64_t *launches, int reset);
+/* Diagnostic build aid: with option "debug" bit 1 set the MFMA kernel sums shader-clock stamps per
+ * phase over all waves (current device): [0] Voigt loop, [1] convolution, [2] weights + MFMA loop,
+ * [3] epilogue, [4] whole wave, [5] waves.  Not for production launches. */
+int dlagp_debug_read(uint64_t *out, int n, int reset);
 
 #ifdef __cplusplus
 }
