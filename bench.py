@@ -150,13 +150,12 @@ def main() -> None:
     out = torch.empty(S, dtype=torch.float64, device=device)
     evidence = torch.zeros(1, dtype=torch.float64, device=device)
     gathered = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
-    log_s = math.log(S)
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
         dev.eval_device(S, 1, z.data_ptr(), nhi.data_ptr(), out.data_ptr(), stream)
-        # log-mean-exp model evidence of the level (reference dla_gp.py:180-190), on the device
-        evidence[0] = torch.logsumexp(out - log_s, dim=0) - log_s
+        # "- log S" and the log-mean-exp model evidence of the level (reference dla_gp.py:155-190)
+        sl.level_evidence_device(out.data_ptr(), 1, S, 0, evidence.data_ptr(), device=local_rank, stream=stream)
         if world > 1:
             return dist.all_gather(gathered, evidence, async_op=True)
         return None

@@ -37,6 +37,7 @@ SIGNATURES = {
     "dlagp_batch_destroy": (None, [c_void_p]),
     "dlagp_batch_eval_device": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dlagp_batch_eval": (c_int, [c_void_p, c_int64, c_int, _dp, _dp, _dp]),
+    "dlagp_level_evidence_device": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "dlagp_set_option": (c_int, [c_char_p, c_int64]),
     "dlagp_timing_read": (c_int, [_dp, POINTER(c_int64), c_int]),
     "dlagp_debug_read": (c_int, [POINTER(ctypes.c_uint64), c_int, c_int]),

@@ -133,12 +133,10 @@ struct DeviceBuffer {
 struct Workspace {
     DeviceBuffer part;    // partial rows [nsplit][rows][row_width]
     DeviceBuffer status;  // int flag raised by finalize on a non-PD pivot
-    DeviceBuffer prep;    // per-(sample, absorber) multipliers + column density (MFMA path)
     DeviceBuffer z, nhi, out;  // staging for the host-pointer entry points
     void release() {
         part.release();
         status.release();
-        prep.release();
         z.release();
         nhi.release();
         out.release();
@@ -292,10 +290,10 @@ static int choose_splits(const LaunchGroup &g, int64_t S) {
 // ------------------------------------------------------------------------------------------------
 template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, GroupPlan *gp, int nsplit,
-                        long S, int kd, int num_lines, const double *prep, double *part, long rows) {
+                        long S, int kd, int num_lines, const double *z, const double *nhi, double *part, long rows) {
     const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * kd * ((LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
     hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream, table,
-                       gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S, kd, prep,
+                       gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S, kd, z, nhi,
                        part, rows, (int)g_opt_debug);
 }
 
@@ -325,16 +323,8 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
     GroupPlan *gp = nullptr;
     if (use_mfma) {
         if ((rc = group_plan(g, nsplit, &gp))) return rc;
-        if ((rc = ws.prep.reserve((size_t)rows * kd * (g.num_lines + 1) * sizeof(double)))) return rc;
     }
     HIP_TRY(hipMemsetAsync(ws.status.ptr, 0, sizeof(int), stream));
-
-    if (use_mfma) {
-        const long count = rows * kd;
-        hipLaunchKernelGGL(prepare_samples, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, d_z, d_nhi,
-                           count, g.num_lines, ws.prep.as<double>());
-        HIP_TRY(hipGetLastError());
-    }
 
     EventPair ev{};
     const bool timing = g_opt_timing != 0;
@@ -349,13 +339,12 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
         dim3 grid((unsigned)(groups * nsplit), (unsigned)nb);
         const bool lines3 = g.num_lines == 3;
         double *part = ws.part.as<double>();
-        const double *prep = ws.prep.as<double>();
         if (g.broadening) {
-            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
-            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
+            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, rows);
+            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, rows);
         } else {
-            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
-            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, prep, part, rows);
+            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, rows);
+            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, rows);
         }
         HIP_TRY(hipGetLastError());
     } else {
@@ -713,6 +702,17 @@ int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, con
     if (S == 0) return DLAGP_OK;
     HIP_TRY(hipSetDevice(batch->group.device));
     return sweep_from_host(batch->group, S, kd, z, nhi, out);
+}
+
+int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, const uint8_t *d_too_close,
+                                double *d_evidence, int device, void *stream) {
+    if (!d_ll || !d_evidence) return fail(DLAGP_EINVAL, "NULL argument");
+    if (nb <= 0 || S <= 0 || level < 0) return fail(DLAGP_EINVAL, "need nb > 0, S > 0, level >= 0");
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(level_evidence, dim3((unsigned)nb), dim3(DLAGP_EVIDENCE_THREADS), 0,
+                       static_cast<hipStream_t>(stream), d_ll, (long)S, level, d_too_close, d_evidence);
+    HIP_TRY(hipGetLastError());
+    return DLAGP_OK;
 }
 
 int dlagp_debug_read(uint64_t *out, int n, int reset) {

@@ -239,4 +239,71 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     if (row < rows) out[row] = result;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Level evidence (reference dla_gp.py:155-190): one workgroup per sightline.
+//   ll[i] <- ll[i] - log S                      (the "additional Occam's razor", :157-159)
+//   ll[i] <- NaN where too_close[i]             (separation mask, :164-177; optional)
+//   evidence = nanmax + log(nanmean(exp(ll - nanmax))) - level * log S      (:180-190)
+// All-NaN levels give NaN, as np.nanmax / np.nanmean do.
+// ---------------------------------------------------------------------------------------------
+#define DLAGP_EVIDENCE_THREADS 1024
+
+__global__ __launch_bounds__(DLAGP_EVIDENCE_THREADS) void level_evidence(double *__restrict__ ll, long S, int level,
+                                                                       const unsigned char *__restrict__ too_close,
+                                                                       double *__restrict__ evidence) {
+    __shared__ double red[DLAGP_EVIDENCE_THREADS / 64];
+    __shared__ double red2[DLAGP_EVIDENCE_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    double *row = ll + blockIdx.x * S;
+    const unsigned char *mask = too_close ? too_close + blockIdx.x * S : nullptr;
+    const double log_s = log((double)S);
+
+    double top = -__builtin_inf();
+    bool any = false;
+    for (long i = tid; i < S; i += DLAGP_EVIDENCE_THREADS) {
+        double v = row[i] - log_s;
+        if (mask && mask[i]) v = __builtin_nan("");
+        row[i] = v;
+        if (v == v) {
+            top = fmax(top, v);
+            any = true;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) top = fmax(top, __shfl_xor(top, off));
+    if ((tid & 63) == 0) red[wave] = top;
+    __syncthreads();
+    top = red[0];
+    for (int w = 1; w < DLAGP_EVIDENCE_THREADS / 64; ++w) top = fmax(top, red[w]);
+    __syncthreads();
+
+    double sum = 0.0, count = 0.0;
+    for (long i = tid; i < S; i += DLAGP_EVIDENCE_THREADS) {
+        const double v = row[i];
+        if (v == v) {
+            sum += exp(v - top);
+            count += 1.0;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off);
+        count += __shfl_xor(count, off);
+    }
+    if ((tid & 63) == 0) {
+        red[wave] = sum;
+        red2[wave] = count;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double total = 0.0, n = 0.0;
+        for (int w = 0; w < DLAGP_EVIDENCE_THREADS / 64; ++w) {
+            total += red[w];
+            n += red2[w];
+        }
+        // an all-NaN level: nanmax and nanmean are NaN
+        evidence[blockIdx.x] = n > 0.0 ? top + log(total / n) - level * log_s : __builtin_nan("");
+    }
+    (void)any;
+}
+
 }  // namespace dlagp

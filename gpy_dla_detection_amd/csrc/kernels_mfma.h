@@ -58,19 +58,10 @@ struct PassDesc {
     int pad;
 };
 
-// Per-(sample, absorber) constants prepared once per launch:
+// Per-(sample, absorber) constants, computed by each wave for its 16 samples into LDS:
 //   m'_l = c / (lambda_l (1 + z)) / 1e8 / (sqrt2 sigma)   so that  x_l = lam m'_l - c / (sqrt2 sigma)
 // (voigt.py:299,305,247 folded into one FMA per line), followed by the column density.
-// Layout: prep[row][absorber][num_lines + 1].
-__global__ void prepare_samples(const double *__restrict__ z, const double *__restrict__ nhi, long count,
-                                int num_lines, double *__restrict__ prep) {
-    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (idx >= count) return;
-    const double zi = z[idx];
-    double *dst = prep + idx * (num_lines + 1);
-    for (int l = 0; l < num_lines; ++l) dst[l] = line_multiplier(l, zi) * DLAGP_LINES.inv_sqrt2_sigma;
-    dst[num_lines] = nhi[idx];
-}
+// Layout: prep_lds[sample][absorber][num_lines + 1].
 
 // Far-wing term of one line, valid for x^2 >= 256; for smaller x^2 (and NaN) the reciprocal is clamped
 // so that the value stays finite and reproducible -- the caller replaces it on the core path.
@@ -177,7 +168,8 @@ template <int LINES, bool BROADEN>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
     const int2 *const *__restrict__ split_tables, int nsplit, long S, int kd,
-    const double *__restrict__ prep, double *__restrict__ part, long rows, int debug_flags) {
+    const double *__restrict__ z, const double *__restrict__ nhi, double *__restrict__ part, long rows,
+    int debug_flags) {
     constexpr int A_STRIDE = 4 * DLAGP_MAX_PASS_STEPS + 2;  // 58: stride/2 odd -> conflict-free b64 reads
     __shared__ double raw[16 * DLAGP_RAW_STRIDE];
     __shared__ double a_lds[16 * A_STRIDE];
@@ -195,7 +187,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     // descriptor fields used in the loops, read once
     const int num_entries = sl.num_entries;
     const gptr_d lam_ptr = as_global<gptr_d>(sl.lam);
-    const gptr_d prep_ptr = as_global<gptr_d>(prep);
+    const gptr_d z_ptr = as_global<gptr_d>(z);
+    const gptr_d nhi_ptr = as_global<gptr_d>(nhi);
     // P and the per-pixel records are streamed with buffer loads: scalar resource + per-lane byte
     // offset + scalar step offset + immediate, i.e. no vector address arithmetic in the loops
     const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -215,9 +208,13 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     // per-sample constants of this wave -> LDS (rows beyond S repeat the last sample; never stored)
     const int wave_prep = 16 * kd * prep_stride;
     for (int i = lane; i < wave_prep; i += 64) {
-        long row = sample0 + i / (kd * prep_stride);
+        const int which = i % prep_stride;           // 0..L-1: line multiplier, L: column density
+        const int sample_abs = i / prep_stride;      // sample * kd + absorber
+        long row = sample0 + sample_abs / kd;
         row = row < S ? row : S - 1;
-        prep_lds[i] = prep_ptr[((long)b * S + row) * kd * prep_stride + i % (kd * prep_stride)];
+        const long src = ((long)b * S + row) * kd + sample_abs % kd;
+        prep_lds[i] = which == L ? nhi_ptr[src]
+                                 : line_multiplier(which, z_ptr[src]) * DLAGP_LINES.inv_sqrt2_sigma;
     }
 
     const PassDesc *passes = pass_tables[b];
@@ -292,21 +289,38 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
             // convolution (voigt.py:319) on the kept pixels (dla_gp.py:388), product over absorbers.
             // Always all 14 steps, branch-free, so that the LDS reads of different steps overlap:
             // lanes beyond the pass's pixels re-read a valid window and write unused slots.
+            // The reads of four steps are issued together (scheduling barriers keep hipcc from
+            // serialising them one ds_read + wait at a time), then the arithmetic runs on them.
             const double *raw_row = raw + s_loc * DLAGP_RAW_STRIDE;
             double *a_dst = &a_lds[s_loc * A_STRIDE + slot];
+            constexpr int CONV_GROUP = 4;
+            constexpr int NW = BROADEN ? DLAGP_NUM_TAPS : 1;
 #pragma unroll
-            for (int st = 0; st < DLAGP_MAX_PASS_STEPS; ++st) {
-                const double *win = raw_row + pos_lds[st * DLAGP_STEP_PIXELS + slot];
-                double conv;
-                if (BROADEN) {
-                    conv = win[0] * tap[0];
+            for (int g0 = 0; g0 < DLAGP_MAX_PASS_STEPS; g0 += CONV_GROUP) {
+                double wv[CONV_GROUP][NW];
+                double prev[CONV_GROUP];
 #pragma unroll
-                    for (int t = 1; t < DLAGP_NUM_TAPS; ++t) conv = fma(win[t], tap[t], conv);
-                } else {
-                    conv = win[0];
+                for (int u = 0; u < CONV_GROUP; ++u) {
+                    const int st = g0 + u;
+                    if (st < DLAGP_MAX_PASS_STEPS) {
+                        const double *win = raw_row + pos_lds[st * DLAGP_STEP_PIXELS + slot];
+#pragma unroll
+                        for (int t = 0; t < NW; ++t) wv[u][t] = win[t];
+                        prev[u] = a_dst[st * DLAGP_STEP_PIXELS];
+                    }
                 }
-                const double prev = a_dst[st * DLAGP_STEP_PIXELS];
-                a_dst[st * DLAGP_STEP_PIXELS] = jd == 0 ? conv : prev * conv;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < CONV_GROUP; ++u) {
+                    const int st = g0 + u;
+                    if (st < DLAGP_MAX_PASS_STEPS) {
+                        double conv = BROADEN ? wv[u][0] * tap[0] : wv[u][0];
+#pragma unroll
+                        for (int t = 1; t < NW; ++t) conv = fma(wv[u][t], tap[t], conv);
+                        a_dst[st * DLAGP_STEP_PIXELS] = jd == 0 ? conv : prev[u] * conv;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             lds_wave_sync();
             if (stamps) t_conv += stamp_now() - t_mark;

@@ -176,6 +176,16 @@ def log_mvnpdf_low_rank(y, mu, M, d, device: int = 0) -> float:
     return float(out[0])
 
 
+def level_evidence_device(d_ll: int, nb: int, S: int, level: int, d_evidence: int, d_too_close: int = 0,
+                          device: int = 0, stream: int = 0) -> None:
+    """
+    In-place `ll -= log S`, optional separation mask, and the level's log-mean-exp evidence per
+    sightline (reference dla_gp.py:155-190), all on device pointers; enqueued on `stream`.
+    """
+    _lib.check(_lib.load().dlagp_level_evidence_device(d_ll, nb, S, level, d_too_close or None, d_evidence,
+                                                       device, stream))
+
+
 def set_option(name: str, value: int) -> None:
     _lib.check(_lib.load().dlagp_set_option(name.encode(), int(value)))
 

@@ -128,6 +128,15 @@ int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, con
                      double *out);
 
 /*
+ * Level evidence on the device (reference dla_gp.py:155-190), for sweeps whose results stay in HBM.
+ * d_ll [nb][S] holds the sweep's log-likelihoods and is rewritten in place as the level's column of
+ * `sample_log_likelihoods`: minus log S, NaN where d_too_close[b][i] != 0 (NULL = no mask).
+ * d_evidence[b] = nanmax + log(nanmean(exp(ll - nanmax))) - level * log S.  Enqueued on `stream`.
+ */
+int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, const uint8_t *d_too_close,
+                                double *d_evidence, int device, void *stream);
+
+/*
  * Tuning / measurement hooks.
  *   dlagp_set_option: "pixel_splits" (0 = automatic), "path" (0 = automatic, 1 = generic
  *                     kernel, 2 = MFMA kernel), "timing" (1 = bracket the accumulate kernel

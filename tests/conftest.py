@@ -40,3 +40,38 @@ def oracle_state(sight, num_lines=3, broadening=True):
         num_lines=num_lines,
         broadening=broadening,
     )
+
+
+class HipBuffers:
+    """
+    Minimal device-memory helper for tests that pass HBM pointers through the C ABI: hipMalloc /
+    hipMemcpy from the HIP runtime the library itself is linked against (a second runtime in the
+    process -- e.g. the one bundled with torch, if torch were initialised after the library --
+    does not see the GPU).
+    """
+
+    def __init__(self):
+        import ctypes
+
+        self.ct = ctypes
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.ptrs = []
+
+    def to_device(self, array):
+        arr = np.ascontiguousarray(array)
+        ptr = self.ct.c_void_p()
+        assert self.hip.hipMalloc(self.ct.byref(ptr), self.ct.c_size_t(max(arr.nbytes, 8))) == 0
+        assert self.hip.hipMemcpy(ptr, arr.ctypes.data_as(self.ct.c_void_p), self.ct.c_size_t(arr.nbytes), 1) == 0
+        self.ptrs.append(ptr)
+        return ptr.value
+
+    def to_host(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        assert self.hip.hipDeviceSynchronize() == 0
+        assert self.hip.hipMemcpy(out.ctypes.data_as(self.ct.c_void_p), self.ct.c_void_p(ptr), self.ct.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def free(self):
+        for ptr in self.ptrs:
+            self.hip.hipFree(ptr)
+        self.ptrs = []

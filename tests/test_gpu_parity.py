@@ -365,3 +365,37 @@ def test_mfma_path_other_line_counts(restore_options):
         want = dev.eval(z, nhi)
         set_option("path", 2)
         np.testing.assert_allclose(dev.eval(z, nhi), want, rtol=1e-11)
+
+
+def test_level_evidence_kernel_matches_numpy():
+    """device log-mean-exp with the reference's NaN semantics (dla_gp.py:155-190)"""
+    import warnings
+
+    from gpy_dla_detection_amd import sightline as sl
+    from tests.conftest import HipBuffers
+
+    sl.set_option("timing", 0)  # loads the library, and with it the HIP runtime HipBuffers binds to
+    rng = np.random.default_rng(5)
+    nb, S = 3, 5000
+    ll = rng.normal(-800.0, 30.0, size=(nb, S))
+    mask = rng.random((nb, S)) < 0.1
+    mask[2, :] = True  # an all-masked level must come out NaN
+    bufs = HipBuffers()
+    try:
+        for level in (0, 2):
+            want_ll = ll - np.log(S)
+            want_ll[mask] = np.nan
+            with warnings.catch_warnings(), np.errstate(all="ignore"):
+                warnings.simplefilter("ignore")
+                top = np.nanmax(want_ll, axis=1)
+                want = top + np.log(np.nanmean(np.exp(want_ll - top[:, None]), axis=1)) - np.log(S) * level
+            d_ll = bufs.to_device(ll)
+            d_mask = bufs.to_device(mask.astype(np.uint8))
+            d_ev = bufs.to_device(np.zeros(nb))
+            sl.level_evidence_device(d_ll, nb, S, level, d_ev, d_too_close=d_mask)
+            got = bufs.to_host(d_ev, (nb,), np.float64)
+            np.testing.assert_allclose(got[:2], want[:2], rtol=1e-13)
+            assert np.isnan(got[2]) and np.isnan(want[2])
+            np.testing.assert_allclose(bufs.to_host(d_ll, (nb, S), np.float64), want_ll, rtol=1e-15, equal_nan=True)
+    finally:
+        bufs.free()
