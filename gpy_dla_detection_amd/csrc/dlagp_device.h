@@ -16,7 +16,7 @@
 #define DLAGP_TILE_COLS 16
 #define DLAGP_STEP_PIXELS 4
 #define DLAGP_TILE_DOUBLES (DLAGP_TILE_COLS * DLAGP_STEP_PIXELS) /* one (step, tile) block */
-#define DLAGP_ROW_EXTRA 8 /* trailing scalars of a partial row: [0] sum r^2/d, [1] sum log d */
+#define DLAGP_ROW_EXTRA 8 /* trailing scalars of a partial row: [0] sum r^2/d, [1] sum log d, [2] n log 2pi */
 
 // One sightline, as the kernels see it.  All pointers are device pointers.
 struct SightlineDev {

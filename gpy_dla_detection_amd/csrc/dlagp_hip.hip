@@ -95,7 +95,7 @@ static int ensure_device(int device) {
     lc.inv_sqrt2_sigma = 1.0 / sqrt2_sigma;
     lc.c = DLAGP_SPEED_OF_LIGHT_CGS;
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(DLAGP_LINES), &lc, sizeof(lc)));
-    // finalize_rank20 stages 117 KB per workgroup in LDS
+    // finalize_rank20 stages its partial sums in dynamic LDS
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_rank20),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double))));
@@ -371,7 +371,8 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
 
     if (g.k == DLAGP_FIN_K) {
         const size_t lds_bytes = DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double);
-        hipLaunchKernelGGL(finalize_rank20, dim3((unsigned)((rows + 63) / 64)), dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
+        hipLaunchKernelGGL(finalize_rank20, dim3((unsigned)((rows + DLAGP_FIN_SAMPLES - 1) / DLAGP_FIN_SAMPLES)),
+                           dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
                            ws.part.as<double>(), nsplit, rows, (long)S, table, d_out, ws.status.as<int>());
     } else {
         const int threads = DLAGP_FINALIZE_THREADS;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
             }
         }
     }
-    double result = -0.5 * ((sum_r2 - tt) + (sum_logd + 2.0 * log_diag) + sl.n * DLAGP_LOG_2PI);
+    double result = -0.5 * ((sum_r2 - tt) + (sum_logd + 2.0 * log_diag) + sl.n * DLAGP_LOG_2PI);  // one sightline per row here
     if (bad) {
         result = __builtin_nan("");
         atomicOr(status, 1);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
 }
 
 // ---------------------------------------------------------------------------------------------
-// Finalisation for the fixed rank K = 20 (the production path): one wave = 64 samples.
+// Finalisation for the fixed rank K = 20 (the production path): 16 samples per workgroup.
 //   stage   every column of [B - I | u | scalars], summed over the splits in index order, goes to
 //           LDS as lds[column][sample]: independent coalesced loads shared by the 4 waves of the
 //           workgroup, many in flight (a register-resident one-thread-per-sample variant
@@ -161,39 +161,44 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
 // ---------------------------------------------------------------------------------------------
 #define DLAGP_FIN_K 20
 #define DLAGP_FIN_COLS (DLAGP_FIN_K * (DLAGP_FIN_K + 1) / 2)
-#define DLAGP_FINALIZE_LDS_DOUBLES ((DLAGP_FIN_COLS + DLAGP_FIN_K + 2) * 64)
-
+#define DLAGP_FIN_SAMPLES 16   // samples per workgroup: small, so that every CU pulls partial sums
 #define DLAGP_FIN_THREADS 256
+#define DLAGP_FIN_STAGED (DLAGP_FIN_COLS + DLAGP_FIN_K + 3)  // vech(B - I), u, 3 scalars
+#define DLAGP_FINALIZE_LDS_DOUBLES (DLAGP_FIN_STAGED * DLAGP_FIN_SAMPLES)
+
 __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const double *__restrict__ part, int nsplit, long rows, long S,
                                                       const SightlineDev *__restrict__ sightlines,
                                                       double *__restrict__ out, int *__restrict__ status) {
     extern __shared__ double fin_lds[];
     constexpr int K = DLAGP_FIN_K;
     constexpr int NC = DLAGP_FIN_COLS;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const long row0 = blockIdx.x * 64L;
-    const long row = row0 + lane;
-    const long rclamp = row < rows ? row : rows - 1;
-    const SightlineDev &sl = sightlines[rclamp / S];
+    constexpr int NS = DLAGP_FIN_SAMPLES;
+    const int tid = threadIdx.x;
+    const long row0 = blockIdx.x * (long)NS;
+    const SightlineDev &sl = sightlines[(row0 < rows ? row0 : rows - 1) / S];
     const int rw = sl.row_width;
     const int qbase = sl.ntw * DLAGP_TILE_COLS;
     const int sbase = (sl.ntw + sl.ntq) * DLAGP_TILE_COLS;
     const long split_stride = rows * (long)rw;
-    const double *p0 = part + rclamp;
 
-    // ---- stage: lds[c][lane], c < NC: vech(B - I); NC..NC+K-1: u; NC+K: sum r^2/d; NC+K+1: sum log d
-    // the 4 waves share the columns so that 4x as many loads are in flight; wave 0 then factorises
-    double *mine = fin_lds + lane;
-#pragma unroll 6
-    for (int c = wave; c < NC + K + 2; c += DLAGP_FIN_THREADS / 64) {
+    // ---- stage: lds[c][sample], c < NC: vech(B - I); NC..NC+K-1: u; NC+K: sum r^2/d; NC+K+1: sum log d;
+    // NC+K+2: n log 2pi (written by split 0 of the accumulate kernel, so that no per-row lookup is needed).
+    // The reads are what this kernel costs (a CU sustains only tens of GB/s from HBM/MALL), hence
+    // the small workgroups: 625 of them for 10 000 samples instead of 157.
+    for (int idx = tid; idx < DLAGP_FIN_STAGED * NS; idx += DLAGP_FIN_THREADS) {
+        const int c = idx / NS, smp = idx % NS;
         const int src = c < NC ? c : (c < NC + K ? qbase + (c - NC) : sbase + (c - NC - K));
+        long row = row0 + smp;
+        row = row < rows ? row : rows - 1;
+        const double *p0 = part + row + (long)src * rows;
         double acc = 0.0;
-        for (int h = 0; h < nsplit; ++h) acc += p0[h * split_stride + (long)src * rows];
-        mine[c * 64] = acc;
+        for (int h = 0; h < nsplit; ++h) acc += p0[h * split_stride];
+        fin_lds[idx] = acc;
     }
     __syncthreads();
-    if (wave != 0) return;
+    if (tid >= NS) return;
+    const long row = row0 + tid;
+    double *mine = fin_lds + tid;
 
     double t[K], inv_diag[K];
     double tt = 0.0;
@@ -203,13 +208,13 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     for (int i = 0; i < K; ++i) {
         double r[K];
 #pragma unroll
-        for (int j = 0; j <= i; ++j) r[j] = mine[vech_col(i, j) * 64];
+        for (int j = 0; j <= i; ++j) r[j] = mine[vech_col(i, j) * NS];
         r[i] += 1.0;  // identity on the diagonal (null_gp.py:341)
 #pragma unroll
         for (int j = 0; j < i; ++j) {
             double s = r[j];
 #pragma unroll
-            for (int m = 0; m < j; ++m) s = fma(-r[m], mine[vech_col(j, m) * 64], s);
+            for (int m = 0; m < j; ++m) s = fma(-r[m], mine[vech_col(j, m) * NS], s);
             r[j] = s * inv_diag[j];
         }
         double s = r[i];
@@ -221,17 +226,18 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
         const double inv = fast_rcp(diag);
         inv_diag[i] = inv;
 #pragma unroll
-        for (int j = 0; j < i; ++j) mine[vech_col(i, j) * 64] = r[j];
-        double ti = mine[(NC + i) * 64];
+        for (int j = 0; j < i; ++j) mine[vech_col(i, j) * NS] = r[j];
+        double ti = mine[(NC + i) * NS];
 #pragma unroll
         for (int m = 0; m < i; ++m) ti = fma(-r[m], t[m], ti);
         ti *= inv;
         t[i] = ti;
         tt = fma(ti, ti, tt);
     }
-    const double sum_r2 = mine[(NC + K) * 64];
-    const double sum_logd = mine[(NC + K + 1) * 64];
-    double result = -0.5 * ((sum_r2 - tt) + (sum_logd + pivots.log_value()) + sl.n * DLAGP_LOG_2PI);
+    const double sum_r2 = mine[(NC + K) * NS];
+    const double sum_logd = mine[(NC + K + 1) * NS];
+    const double n_log_2pi = mine[(NC + K + 2) * NS];
+    double result = -0.5 * ((sum_r2 - tt) + (sum_logd + pivots.log_value()) + n_log_2pi);
     if (bad) {
         result = __builtin_nan("");
         atomicOr(status, 1);

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
     if (tid == 0) {
         prow[(long)(nt * DLAGP_TILE_COLS) * rows] = sum_r2;
         prow[(long)(nt * DLAGP_TILE_COLS + 1) * rows] = sum_logd;
+        prow[(long)(nt * DLAGP_TILE_COLS + 2) * rows] = sl.n * DLAGP_LOG_2PI;
     }
 }
 

@@ -32,6 +32,7 @@
 
 #include "dlagp_device.h"
 #include "fastmath_device.h"
+#include "kernels_common.h"
 #include "voigt_device.h"
 
 namespace dlagp {
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         const long row = row_base + s_loc;
         base[(long)(DLAGP_MFMA_NT * DLAGP_TILE_COLS) * rows + row] = sum_r2;
         base[(long)(DLAGP_MFMA_NT * DLAGP_TILE_COLS + 1) * rows + row] = logd;
+        base[(long)(DLAGP_MFMA_NT * DLAGP_TILE_COLS + 2) * rows + row] = split == 0 ? sl.n * DLAGP_LOG_2PI : 0.0;
     }
     if (stamps && lane == 0) {
         const unsigned long long now = stamp_now();
