@@ -72,44 +72,78 @@ class _AbsorberGP(NullGP):
 
     # -- the sweep -----------------------------------------------------------------------------
     def _sweep(self, max_dlas: int):
-        S = self.params.num_dla_samples
-        log_s = np.log(S)
-        evidences = np.full((max_dlas,), np.nan)
-        base_sample_inds = np.zeros((max_dlas - 1, S), dtype=np.int32)
-        sample_log_likelihoods = np.full((S, max_dlas), np.nan)
-
         sample_z = np.asarray(self._sample_redshifts(), dtype=np.float64)
         sample_nhi = np.asarray(self.dla_samples.nhi_samples, dtype=np.float64)
+        return occupation_sweep(
+            self._level_log_likelihoods, sample_z, sample_nhi, max_dlas, self.min_z_separation,
+            num_samples=self.params.num_dla_samples,
+        )
 
-        for level in range(max_dlas):
-            # parameters of the level's samples: the i-th QMC point plus `level` points drawn
-            # from the previous levels' posteriors (reference :135-150)
-            idx = np.concatenate([np.arange(S)[None, :], base_sample_inds[:level, :]], axis=0)  # (kd, S)
-            z = np.ascontiguousarray(sample_z[idx].T)
-            nhi = np.ascontiguousarray(sample_nhi[idx].T)
-            sample_log_likelihoods[:, level] = self._level_log_likelihoods(z, nhi) - log_s  # :155-159
 
-            if level > 0:  # reference :164-177
-                too_close = np.any(np.diff(np.sort(sample_z[idx], axis=0), axis=0) < self.min_z_separation, axis=0)
-                sample_log_likelihoods[too_close, level] = np.nan
+def level_parameters(sample_z: np.ndarray, sample_nhi: np.ndarray, base_sample_inds: np.ndarray, level: int):
+    """
+    (z, nhi), each (S, level + 1): the i-th QMC point plus `level` points drawn from the previous
+    levels' posteriors (reference dla_gp.py:135-150).  Also returns the (level + 1, S) index table.
+    """
+    S = sample_z.shape[0]
+    idx = np.concatenate([np.arange(S)[None, :], base_sample_inds[:level, :]], axis=0)
+    return np.ascontiguousarray(sample_z[idx].T), np.ascontiguousarray(sample_nhi[idx].T), idx
 
-            top = np.nanmax(sample_log_likelihoods[:, level])
-            probabilities = np.exp(sample_log_likelihoods[:, level] - top)
-            evidences[level] = top + np.log(np.nanmean(probabilities)) - log_s * level  # :186-190
 
-            if level + 1 == max_dlas:
-                break
-            if np.isnan(evidences[level]):  # reference :200-206
-                print("Finish the loop earlier because NaN value in log p(D | z_QSO, {} DLAs)".format(level))
-                break
+def finish_level(sample_log_likelihoods: np.ndarray, level: int, sample_z: np.ndarray, idx: np.ndarray,
+                 min_z_separation: float, max_dlas: int, base_sample_inds: np.ndarray):
+    """
+    Host half of one occupation level (reference dla_gp.py:164-218), given the level's column of
+    `sample_log_likelihoods` already holding `log-likelihood - log S`:
+    separation masking, log-mean-exp evidence, and -- unless this is the last level or the evidence is
+    NaN -- the posterior resampling of base indices with the legacy global NumPy RNG.
 
-            weights = probabilities
-            weights[np.isnan(weights)] = 0.0
-            base_sample_inds[level, :] = np.random.choice(  # reference :213-218, legacy global RNG
-                np.arange(S).astype(np.int32), size=S, replace=True, p=weights / weights.sum()
-            )
+    :return: (evidence, keep_going)
+    """
+    S = sample_z.shape[0]
+    if level > 0:  # reference :164-177
+        too_close = np.any(np.diff(np.sort(sample_z[idx], axis=0), axis=0) < min_z_separation, axis=0)
+        sample_log_likelihoods[too_close, level] = np.nan
 
-        return evidences, sample_log_likelihoods, base_sample_inds
+    top = np.nanmax(sample_log_likelihoods[:, level])
+    probabilities = np.exp(sample_log_likelihoods[:, level] - top)
+    evidence = top + np.log(np.nanmean(probabilities)) - np.log(S) * level  # :186-190
+
+    if level + 1 == max_dlas:
+        return evidence, False
+    if np.isnan(evidence):  # reference :200-206
+        print("Finish the loop earlier because NaN value in log p(D | z_QSO, {} DLAs)".format(level))
+        return evidence, False
+
+    weights = probabilities
+    weights[np.isnan(weights)] = 0.0
+    base_sample_inds[level, :] = np.random.choice(  # reference :213-218, legacy global RNG
+        np.arange(S).astype(np.int32), size=S, replace=True, p=weights / weights.sum()
+    )
+    return evidence, True
+
+
+def occupation_sweep(level_log_likelihoods, sample_z: np.ndarray, sample_nhi: np.ndarray, max_dlas: int,
+                     min_z_separation: float, num_samples: int):
+    """
+    The occupation sweep of reference dla_gp.py:92-225 around a batched evaluator
+    `level_log_likelihoods(z (S, kd), nhi (S, kd)) -> (S,)`.
+
+    :return: (evidences (max_dlas,), sample_log_likelihoods (S, max_dlas), base_sample_inds (max_dlas - 1, S) int32)
+    """
+    S = num_samples
+    evidences = np.full((max_dlas,), np.nan)
+    base_sample_inds = np.zeros((max_dlas - 1, S), dtype=np.int32)
+    sample_log_likelihoods = np.full((S, max_dlas), np.nan)
+    for level in range(max_dlas):
+        z, nhi, idx = level_parameters(sample_z, sample_nhi, base_sample_inds, level)
+        sample_log_likelihoods[:, level] = level_log_likelihoods(z, nhi) - np.log(S)  # :155-159
+        evidences[level], keep_going = finish_level(
+            sample_log_likelihoods, level, sample_z, idx, min_z_separation, max_dlas, base_sample_inds
+        )
+        if not keep_going:
+            break
+    return evidences, sample_log_likelihoods, base_sample_inds
 
 
 class DLAGP(_AbsorberGP):

@@ -399,3 +399,17 @@ def test_level_evidence_kernel_matches_numpy():
             np.testing.assert_allclose(bufs.to_host(d_ll, (nb, S), np.float64), want_ll, rtol=1e-15, equal_nan=True)
     finally:
         bufs.free()
+
+
+def test_sharded_driver_on_device_matches_oracle_driver():
+    """parallel.model_evidences_sharded through DeviceBatch (single process) vs the oracle evaluator"""
+    from gpy_dla_detection_amd import parallel
+    from tests.test_host_logic import OracleBatch
+
+    sights = [make_sightline(i, n_unmasked=150 + 10 * i, n_masked=4) for i in range(3)]
+    got = parallel.model_evidences_sharded(sights, num_samples=64, max_dlas=3)
+    want = parallel.model_evidences_sharded(sights, num_samples=64, max_dlas=3,
+                                            make_batch=lambda s, device: OracleBatch(s))
+    assert got.shape == (3, 5)
+    np.testing.assert_allclose(got, want, rtol=RTOL_LL)
+    assert np.array_equal(np.argmax(got, axis=1), np.argmax(want, axis=1))  # identical model selection
