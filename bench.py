@@ -43,6 +43,20 @@ def algorithmic_flops_per_eval(n: int, k: int) -> float:
     return float(n * k * (k + 1) + 2 * n * k)
 
 
+def measured_hbm_traffic():
+    """
+    HBM bytes per accumulate-kernel launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE,
+    collected in their own rocprofv3 runs of this same command, gfx950 read-side correction applied):
+    profiles/r01_pmc_traffic.json.  None when the file is absent.
+    """
+    path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(sight, z, nhi, budget_s: float = 12.0):
     """oracle timed on host cores: all cores (one process per core, BLAS pinned to 1 thread)"""
     import multiprocessing as mp
@@ -228,7 +242,8 @@ def main() -> None:
                 "peak": PEAK_FP64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": measured_hbm_traffic() if S == NUM_SAMPLES else None,
+                "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
                 "kernel": "accumulate",
                 "kernel_ms": kernel_s * 1e3,
                 "flop_per_eval": flops,
