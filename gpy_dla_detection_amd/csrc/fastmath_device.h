@@ -50,6 +50,21 @@ __device__ __forceinline__ double fast_exp(double x) {
     return __builtin_amdgcn_ldexp(p, (int)kc);
 }
 
+// 2^t for t <= 0 (the kernel folds log2(e) into the column density, saving the range-reduction
+// multiplies of fast_exp): k = rint(t), f = t - k exactly, 2^f by a degree-9 fit, v_ldexp_f64.
+// v_cvt_i32_f64 saturates, so -inf / huge arguments give 2^INT_MIN = 0 and NaN stays NaN.
+__device__ __forceinline__ double fast_exp2(double t) {
+    constexpr double c[DLAGP_EXP_DEGREE + 1] = DLAGP_EXP2_COEF_INIT;
+    const double k = __builtin_rint(t);
+    const double f = t - k;
+    double p = fma(c[DLAGP_EXP_DEGREE], f, c[DLAGP_EXP_DEGREE - 1]);
+#pragma unroll
+    for (int m = DLAGP_EXP_DEGREE - 2; m >= 0; --m) p = horner_sgpr(p, f, c[m]);
+    int ki;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(ki) : "v"(k));
+    return __builtin_amdgcn_ldexp(p, ki);
+}
+
 // Running product with explicit exponent: value = mant * 2^expo.  sum(log d_i) = log(mant) + expo ln2.
 // 750 multiplications lose < 1e-13 absolutely in the logarithm (against |log p| ~ 1e3).
 struct LogProduct {

@@ -61,7 +61,8 @@ struct PassDesc {
 
 // Per-(sample, absorber) constants, computed by each wave for its 16 samples into LDS:
 //   m'_l = c / (lambda_l (1 + z)) / 1e8 / (sqrt2 sigma)   so that  x_l = lam m'_l - c / (sqrt2 sigma)
-// (voigt.py:299,305,247 folded into one FMA per line), followed by the column density.
+// (voigt.py:299,305,247 folded into one FMA per line), followed by N log2(e) (the profile is then
+// 2^(-N log2e tau), voigt.py:309).
 // Layout: prep_lds[sample][absorber][num_lines + 1].
 
 // Far-wing term of one line, valid for x^2 >= 256; for smaller x^2 (and NaN) the reciprocal is clamped
@@ -85,7 +86,49 @@ __device__ __forceinline__ double optical_depth(double lam, const double *__rest
     const double x_offset = -DLAGP_LINES.c * DLAGP_LINES.inv_sqrt2_sigma;
     constexpr double split2 = DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT;
     double tau = 0.0;
-    if (LINES > 0) {
+    if (LINES == 3) {
+        // one reciprocal for the three lines: 1/X_l = (1/(X_0 X_1 X_2)) * (product of the other two),
+        // with every X clamped to >= 256 so that a lane inside one line's core still gets the other
+        // two lines right (its own clamped term is replaced below)
+        double xs[3], xc[3], us[3];
+        bool any_core = false;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            xs[l] = fma(lam, mult[l], x_offset);
+            const double x2 = xs[l] * xs[l];
+            any_core |= !(x2 >= split2);  // also catches NaN
+            xc[l] = fmax(x2, split2);
+        }
+        const double p01 = xc[0] * xc[1];
+        const double r = fast_rcp1(p01 * xc[2]);
+        const double r2 = r * xc[2];
+        us[0] = r2 * xc[1];
+        us[1] = r2 * xc[0];
+        us[2] = r * p01;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const double *w = DLAGP_LINES.wing[l];
+            double poly = w[DLAGP_WING_DEGREE];
+#pragma unroll
+            for (int m = DLAGP_WING_DEGREE - 1; m >= 0; --m) poly = fma(poly, us[l], w[m]);
+            tau = fma(us[l], poly, tau);
+        }
+        if (__builtin_amdgcn_ballot_w64(any_core)) {
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const double x = xs[l];
+                if (!(x * x >= split2)) {
+                    const double *w = DLAGP_LINES.wing[l];
+                    double poly = w[DLAGP_WING_DEGREE];
+#pragma unroll
+                    for (int m = DLAGP_WING_DEGREE - 1; m >= 0; --m) poly = fma(poly, us[l], w[m]);
+                    tau = fma(-us[l], poly, tau);  // take the clamped wing term back out
+                    const double term = DLAGP_LINES.k_core[l] * core_taylor(x, DLAGP_LINES.y[l]);
+                    if (term == term) tau += term;  // np.nansum (voigt.py:309)
+                }
+            }
+        }
+    } else if (LINES > 0) {
         double xs[LINES > 0 ? LINES : 1];
         bool any_core = false;
 #pragma unroll
@@ -214,7 +257,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         long row = sample0 + sample_abs / kd;
         row = row < S ? row : S - 1;
         const long src = ((long)b * S + row) * kd + sample_abs % kd;
-        prep_lds[i] = which == L ? nhi_ptr[src]
+        prep_lds[i] = which == L ? nhi_ptr[src] * 1.44269504088896338700e+00
                                  : line_multiplier(which, z_ptr[src]) * DLAGP_LINES.inv_sqrt2_sigma;
     }
 
@@ -261,23 +304,24 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         for (int jd = 0; jd < kd; ++jd) {
             if (stamps) t_mark = stamp_now();
             if (LINES == 3) {
-                // lane i holds constant (i & 3) of sample (i >> 2): {m'_0, m'_1, m'_2, N}; each sample's
-                // four values are then broadcast through SGPRs (no memory latency in the loop)
-                const double pv = prep_lds[((lane >> 2) * kd + jd) * 4 + (lane & 3)];
-                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) here, not at the loop header
+                // the sample's four constants {m'_0, m'_1, m'_2, N log2e} are one 32-byte LDS broadcast
+                // read, fetched one sample ahead so that the loop never waits on it
+                const v4d *sp4 = reinterpret_cast<const v4d *>(prep_lds) + jd;
+                v4d cur = sp4[0];
 #pragma unroll 1
                 for (int ss = 0; ss < 16; ++ss) {
-                    const double m[3] = {readlane_f64(pv, 4 * ss), readlane_f64(pv, 4 * ss + 1),
-                                         readlane_f64(pv, 4 * ss + 2)};
+                    const v4d nxt = sp4[(ss < 15 ? ss + 1 : ss) * kd];
+                    const double m[3] = {cur.x, cur.y, cur.z};
                     const double tau = optical_depth<LINES>(lam, m, 3);
-                    raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp(-readlane_f64(pv, 4 * ss + 3) * tau);  // voigt.py:309
+                    raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp2(-cur.w * tau);  // voigt.py:309
+                    cur = nxt;
                 }
             } else {
 #pragma unroll 2
                 for (int ss = 0; ss < 16; ++ss) {
                     const double *sp = prep_lds + (ss * kd + jd) * prep_stride;
                     const double tau = optical_depth<LINES>(lam, sp, L);
-                    raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp(-sp[L] * tau);
+                    raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp2(-sp[L] * tau);
                 }
             }
             if (stamps) {
