@@ -73,8 +73,8 @@ def cpu_baseline(sight, z, nhi, cpu_seconds: float = 24.0):
         # warm the workers (imports, BLAS init), calibrate, then size the sample
         pool.map(_cpu_worker_eval, [(z[:2], nhi[:2])] * workers)
         t0 = time.perf_counter()
-        pool.map(_cpu_worker_eval, [(z[i:i + 4], nhi[i:i + 4]) for i in range(0, 4 * workers, 4)])
-        per_eval = (time.perf_counter() - t0) / 4.0
+        pool.map(_cpu_worker_eval, [(z[i:i + 16], nhi[i:i + 16]) for i in range(0, 16 * workers, 16)])
+        per_eval = (time.perf_counter() - t0) / 16.0
         per_worker = int(max(8, cpu_seconds / workers / max(per_eval, 1e-6)))
         idx = [np.arange(w * per_worker, (w + 1) * per_worker) % len(z) for w in range(workers)]
         t0 = time.perf_counter()
