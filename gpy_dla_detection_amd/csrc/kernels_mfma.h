@@ -372,15 +372,21 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         }
         if (stamps) t_mark = stamp_now();
 
-        // operands of the pass's first step
+        // operands of the pass's first step, issued in exactly the order the loop below issues them
+        // (records first, then tile pairs 0..7): loads complete in order and the wait counts at the
+        // loop header are the minimum over both incoming edges, so any other order here makes
+        // every step wait for all eight of its predecessor's prefetches instead of the oldest.
         {
             const int soff = step0 * STEP_BYTES;
-#pragma unroll
-            for (int j = 0; j < NPAIR; ++j)
-                frag[j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(
-                                                      p_rsrc, p_voff + (j & 3) * 1024, soff + (j >> 2) * 4096, 0));
             rec_ym = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff, step0 * REC_STEP_BYTES, 0));
             rec_ov = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff + 16, step0 * REC_STEP_BYTES, 0));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NPAIR; ++j) {
+                frag[j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      p_rsrc, p_voff + (j & 3) * 1024, soff + (j >> 2) * 4096, 0));
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         // ---------------- phase 2: weights and MFMAs, step by step ----------------
