@@ -292,9 +292,15 @@ template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, GroupPlan *gp, int nsplit,
                         long S, int kd, int num_lines, const double *z, const double *nhi, double *part, long rows) {
     const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * kd * ((LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
-    hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream, table,
-                       gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S, kd, z, nhi,
-                       part, rows, (int)g_opt_debug);
+    if (g_opt_debug & 2) {  // diagnostic instantiation with per-phase cycle stamps
+        hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, true>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
+                           table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
+                           kd, z, nhi, part, rows, (int)g_opt_debug);
+    } else {
+        hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, false>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
+                           table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
+                           kd, z, nhi, part, rows, (int)g_opt_debug);
+    }
 }
 
 static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, const double *d_nhi,
@@ -478,6 +484,10 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
     sl.row_width = (sl.ntw + sl.ntq) * DLAGP_TILE_COLS + DLAGP_ROW_EXTRA;
     sl.npair = (sl.ntw + sl.ntq + 1) / 2;
     for (int t = 0; t < DLAGP_NUM_TAPS; ++t) sl.taps[t] = broadening ? DLAGP_INSTRUMENT_PROFILE[t] : (t == 0 ? 1.0 : 0.0);
+    static_assert(DLAGP_NUM_TAPS == 7, "the MFMA kernel folds the symmetric 7-tap profile into 4 coefficients");
+    for (int t = 0; t < 3; ++t)
+        if (DLAGP_INSTRUMENT_PROFILE[t] != DLAGP_INSTRUMENT_PROFILE[6 - t])
+            return fail(DLAGP_EINVAL, "instrument profile is not symmetric");
 
     // padded host images
     std::vector<double> hy(sl.n_pad, 0.0), hmu(sl.n_pad, 0.0), ho(sl.n_pad, 0.0), hv(sl.n_pad, 1.0);

@@ -184,7 +184,7 @@ __device__ __forceinline__ G as_global(const T *p) {
 
 // Diagnostic cycle stamps (debug bit 1): per-phase shader-clock totals over all waves, read back with
 // dlagp_debug_read.  Slots: 0 Voigt sample loop, 1 convolution, 2 weights + MFMA loop, 3 epilogue,
-// 4 whole wave, 5 wave count.  Off in production launches (one scalar branch per phase).
+// 4 whole wave, 5 wave count.  Compiled only into the STAMPS instantiations of the kernel.
 __device__ unsigned long long DLAGP_STAMPS[8];
 
 __device__ __forceinline__ unsigned long long stamp_now() {
@@ -208,7 +208,7 @@ __device__ __forceinline__ void lds_wave_sync() {
 // Any number of absorbers kd >= 1: each absorber's profile is convolved and multiplied into the LDS
 // buffer a[sample][pixel of the pass] before the MFMA loop (dla_gp.py:370-388).
 // Dynamic LDS: the wave's per-sample constants, 16 samples x kd x (L + 1) doubles.
-template <int LINES, bool BROADEN>
+template <int LINES, bool BROADEN, bool STAMPS>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
     const int2 *const *__restrict__ split_tables, int nsplit, long S, int kd,
@@ -241,9 +241,9 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         (void *)as_global<gptr_d>(sl.aux), 0, sl.n_pad * (DLAGP_AUX_FIELDS * 8), DLAGP_BUFFER_FLAGS);
     const int p_voff = lane * 16;                         // one double2 per lane and tile pair
     const int rec_voff = slot * (DLAGP_AUX_FIELDS * 8);   // this lane's pixel within a step
-    double tap[DLAGP_NUM_TAPS];
+    double tap[4];  // symmetric profile: taps 0..3 (tap[t] == tap[6 - t], checked in dlagp_create)
 #pragma unroll
-    for (int t = 0; t < DLAGP_NUM_TAPS; ++t) tap[t] = sl.taps[t];
+    for (int t = 0; t < 4; ++t) tap[t] = sl.taps[t];
 
     const long sample0 = group * DLAGP_MFMA_GROUP;  // first sample of this wave
     const int L = LINES > 0 ? LINES : sl.num_lines;
@@ -272,7 +272,9 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     double sum_r2 = 0.0;
     LogProduct dprod;
 
-    const bool stamps = (debug_flags & 2) != 0;
+    // compile-time switch: the stamp accumulators would otherwise hold ~12 SGPRs in production too
+    constexpr bool stamps = STAMPS;
+    (void)debug_flags;
     unsigned long long t_voigt = 0, t_conv = 0, t_mfma = 0, t_mark = 0, t_start = 0;
     if (stamps) t_start = stamp_now();
 
@@ -359,9 +361,14 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 for (int u = 0; u < CONV_GROUP; ++u) {
                     const int st = g0 + u;
                     if (st < DLAGP_MAX_PASS_STEPS) {
-                        double conv = BROADEN ? wv[u][0] * tap[0] : wv[u][0];
-#pragma unroll
-                        for (int t = 1; t < NW; ++t) conv = fma(wv[u][t], tap[t], conv);
+                        // the instrument profile is symmetric (voigt.py:214-224): 4 coefficients, not 7
+                        double conv = wv[u][0];
+                        if (BROADEN) {
+                            conv = (wv[u][0] + wv[u][6]) * tap[0];
+                            conv = fma(wv[u][1] + wv[u][5], tap[1], conv);
+                            conv = fma(wv[u][2] + wv[u][4], tap[2], conv);
+                            conv = fma(wv[u][3], tap[3], conv);
+                        }
                         a_dst[st * DLAGP_STEP_PIXELS] = jd == 0 ? conv : prev[u] * conv;
                     }
                 }
