@@ -413,3 +413,58 @@ def test_sharded_driver_on_device_matches_oracle_driver():
     assert got.shape == (3, 5)
     np.testing.assert_allclose(got, want, rtol=RTOL_LL)
     assert np.array_equal(np.argmax(got, axis=1), np.argmax(want, axis=1))  # identical model selection
+
+
+def test_ragged_mask_falls_back_to_generic_path(restore_options):
+    """a masked run longer than one 64-entry pass makes the sightline ineligible for the MFMA kernel"""
+    from oracle import ref_like as R
+
+    set_option = restore_options
+    sight = make_sightline(4, n_unmasked=600, n_masked=0)
+    keep = sight.keep.copy()
+    keep[203:333] = False          # 130 consecutive masked pixels, straddled by an 8-pixel chunk
+    keep[400:420:2] = False        # and a comb
+    idx = np.cumsum(sight.keep) - 1  # all kept originally: index map is the identity
+    sel = keep[sight.keep]
+    sight.keep = keep
+    sight.y, sight.v = sight.y[sel], sight.v[sel]
+    sight.this_mu, sight.this_M, sight.this_omega2 = sight.this_mu[sel], sight.this_M[sel], sight.this_omega2[sel]
+    dev = device_sightline(sight)
+    z, _, nhi = make_qmc_samples(sight, 40)
+    got = dev.eval(z, nhi)  # automatic path selection
+    st = oracle_state(sight)
+    want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in range(40)])
+    np.testing.assert_allclose(got, want, rtol=RTOL_LL)
+    set_option("path", 2)
+    with pytest.raises(ValueError):
+        dev.eval(z, nhi)           # the MFMA kernel cannot plan this mask
+    del idx
+
+
+def test_config3_batch_of_sightlines_full_size():
+    """BASELINE config 3 at reduced width: 16 sightlines x 10 000 samples, DLA(1) and sub-DLA in one batch each"""
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+    from oracle import ref_like as R
+
+    sights = [make_sightline(i) for i in range(16)]
+    devs = [device_sightline(s) for s in sights]
+    batch = DeviceBatch(devs)
+    S = 10000
+    z = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    for sub in (False, True):
+        nhi = np.broadcast_to(make_qmc_samples(sights[0], S, sub_dla=sub)[2], z.shape)
+        ll = batch.eval(z, nhi)
+        assert ll.shape == (16, S) and np.all(np.isfinite(ll))
+        # the batch launch (one pixel split) agrees with a single-sightline launch (three splits)
+        np.testing.assert_allclose(ll[5], devs[5].eval(z[5], nhi[5]), rtol=1e-13)
+        # spot check against the oracle
+        st = oracle_state(sights[11])
+        pick = np.arange(7, S, 1111)
+        want = np.array([R.sample_log_likelihood_k_dlas(st, [z[11, i]], [nhi[11, i]]) for i in pick])
+        np.testing.assert_allclose(ll[11, pick], want, rtol=RTOL_LL)
+    # sightlines with an injected absorber prefer the DLA model at the injected redshift
+    nhi = np.broadcast_to(make_qmc_samples(sights[0], S)[2], z.shape)
+    ll = batch.eval(z, nhi)
+    for b in (1, 4, 7):  # index % 3 == 1: one injected absorber
+        best = int(np.argmax(ll[b]))
+        assert abs(z[b, best] - sights[b].injected_z[0]) < 0.02
