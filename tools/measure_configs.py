@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""
+Throughput of the BASELINE.json configurations other than the bench line (configs[1]) on one GPU:
+device-resident timings of batches and of sweeps with 1..4 absorbers, and the end-to-end model
+selection rate through the drop-in classes (host resampling included).  Prints one JSON object.
+"""
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np
+import torch
+
+torch.cuda.init()
+from gpy_dla_detection_amd import parallel, sightline as sl
+from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline
+
+S = 10000
+dev = torch.device("cuda", 0)
+stream = torch.cuda.current_stream().cuda_stream
+out = {}
+
+
+def timed(fn, reps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+# one sightline, 1..4 absorbers per sample (config 5's levels)
+sight = make_sightline(1)
+ds = sl.DeviceSightline.from_state(sight)
+z, _, nhi = make_qmc_samples(sight, S)
+rng = np.random.default_rng(0)
+for kd in (1, 2, 3, 4):
+    zz = np.stack([z] + [z[rng.permutation(S)] for _ in range(kd - 1)], axis=1)
+    nn = np.stack([nhi] + [nhi[rng.permutation(S)] for _ in range(kd - 1)], axis=1)
+    d_z, d_n = torch.from_numpy(zz).to(dev), torch.from_numpy(nn).to(dev)
+    d_o = torch.empty(S, dtype=torch.float64, device=dev)
+    t = timed(lambda: ds.eval_device(S, kd, d_z.data_ptr(), d_n.data_ptr(), d_o.data_ptr(), stream))
+    out["one_sightline_kd%d_evals_per_s" % kd] = S / t
+
+# config 3: 64 sightlines x 10 000 samples, DLA(1) + sub-DLA
+nb = 64
+sights = [make_sightline(i) for i in range(nb)]
+devs = [sl.DeviceSightline.from_state(s) for s in sights]
+batch = sl.DeviceBatch(devs)
+zb = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+d_z = torch.from_numpy(zb).to(dev)
+d_dla = torch.from_numpy(np.broadcast_to(make_qmc_samples(sights[0], S)[2], zb.shape).copy()).to(dev)
+d_sub = torch.from_numpy(np.broadcast_to(make_qmc_samples(sights[0], S, sub_dla=True)[2], zb.shape).copy()).to(dev)
+d_o = torch.empty((nb, S), dtype=torch.float64, device=dev)
+
+
+def config3():
+    batch.eval_device(S, 1, d_z.data_ptr(), d_dla.data_ptr(), d_o.data_ptr(), stream)
+    batch.eval_device(S, 1, d_z.data_ptr(), d_sub.data_ptr(), d_o.data_ptr(), stream)
+
+
+t = timed(config3, reps=5, warm=1)
+out["config3_64x10000_dla_plus_subdla_evals_per_s"] = 2 * nb * S / t
+out["config3_ms"] = t * 1e3
+
+# end-to-end model selection [null, sub-DLA, DLA(1..4)] through the batch driver, host resampling included
+nsel = 16
+t0 = time.perf_counter()
+ev = parallel.model_evidences_sharded(sights[:nsel], num_samples=S, max_dlas=4)
+t = time.perf_counter() - t0
+out["model_selection_spectra_per_s"] = nsel / t
+out["model_selection_evals_per_s"] = nsel * (1 + S + 4 * S) / t
+out["model_selection_argmax"] = np.argmax(ev, axis=1).tolist()
+print(json.dumps(out))
