@@ -290,16 +290,16 @@ static int choose_splits(const LaunchGroup &g, int64_t S) {
 // ------------------------------------------------------------------------------------------------
 template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, GroupPlan *gp, int nsplit,
-                        long S, int kd, int num_lines, const double *z, const double *nhi, double *part, long rows) {
+                        long S, int kd, int num_lines, const double *z, const double *nhi, double *part, int *status) {
     const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * kd * ((LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
     if (g_opt_debug & 2) {  // diagnostic instantiation with per-phase cycle stamps
         hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, true>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
                            table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
-                           kd, z, nhi, part, rows, (int)g_opt_debug);
+                           kd, z, nhi, part, status, (int)g_opt_debug);
     } else {
         hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, false>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
                            table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
-                           kd, z, nhi, part, rows, (int)g_opt_debug);
+                           kd, z, nhi, part, status, (int)g_opt_debug);
     }
 }
 
@@ -322,7 +322,9 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
     }
     const int nsplit = use_mfma ? choose_splits(g, S) : 1;
 
-    int rc = ws.part.reserve((size_t)nsplit * rows * g.row_width * sizeof(double));
+    // partial sums: [split][sightline x ceil(S/16) blocks][row_width columns][16 samples]
+    const size_t nblocks = (size_t)nb * ((S + 15) / 16);
+    int rc = ws.part.reserve((size_t)nsplit * nblocks * g.row_width * 16 * sizeof(double));
     if (rc) return rc;
     rc = ws.status.reserve(sizeof(int));
     if (rc) return rc;
@@ -330,7 +332,6 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
     if (use_mfma) {
         if ((rc = group_plan(g, nsplit, &gp))) return rc;
     }
-    HIP_TRY(hipMemsetAsync(ws.status.ptr, 0, sizeof(int), stream));
 
     EventPair ev{};
     const bool timing = g_opt_timing != 0;
@@ -346,11 +347,11 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
         const bool lines3 = g.num_lines == 3;
         double *part = ws.part.as<double>();
         if (g.broadening) {
-            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, rows);
-            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, rows);
+            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, ws.status.as<int>());
+            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, ws.status.as<int>());
         } else {
-            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, rows);
-            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, rows);
+            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, ws.status.as<int>());
+            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, ws.status.as<int>());
         }
         HIP_TRY(hipGetLastError());
     } else {
@@ -365,7 +366,7 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         dim3 grid((unsigned)S, (unsigned)nb);
         hipLaunchKernelGGL(accumulate_generic, grid, dim3(DLAGP_GENERIC_THREADS), lds_bytes, stream, table, (long)S,
-                           kd, d_z, d_nhi, ws.part.as<double>(), rows, lds_entries, lds_pixels);
+                           kd, d_z, d_nhi, ws.part.as<double>(), ws.status.as<int>(), lds_entries, lds_pixels);
         HIP_TRY(hipGetLastError());
     }
 
@@ -377,7 +378,7 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
 
     if (g.k == DLAGP_FIN_K) {
         const size_t lds_bytes = DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double);
-        hipLaunchKernelGGL(finalize_rank20, dim3((unsigned)((rows + DLAGP_FIN_SAMPLES - 1) / DLAGP_FIN_SAMPLES)),
+        hipLaunchKernelGGL(finalize_rank20, dim3((unsigned)nblocks),
                            dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
                            ws.part.as<double>(), nsplit, rows, (long)S, table, d_out, ws.status.as<int>());
     } else {

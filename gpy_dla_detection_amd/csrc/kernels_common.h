@@ -10,6 +10,14 @@ namespace dlagp {
 
 #define DLAGP_LOG_2PI 1.83787706640934534  // reference null_gp.py:325
 
+// Partial sums live in blocks of 16 consecutive samples of one sightline:
+//   part[split][block][column][16],  block = sightline * ngroups + sample / 16,  ngroups = ceil(S / 16)
+// so that one accumulate wave writes, and one finalize workgroup reads, a single contiguous block.
+__host__ __device__ __forceinline__ long partial_index(long split, long nblocks, long block, int row_width, int col,
+                                                       int lane16) {
+    return (((split * nblocks + block) * row_width) + col) * 16 + lane16;
+}
+
 // column of B(i, j), j <= i, inside the w-tiles
 __host__ __device__ __forceinline__ int vech_col(int i, int j) { return i * (i + 1) / 2 + j; }
 
@@ -56,8 +64,7 @@ __global__ void build_shared_operand(const double *__restrict__ M_dev, int n, in
 
 // ---------------------------------------------------------------------------------------------
 // Finalisation: one thread per sample.
-//   partials: part[split][column][row], row = sightline * S + sample (column-major over the
-//   samples, so that consecutive threads read consecutive addresses)
+//   partials: part[split][block][column][16] (partial_index), row = sightline * S + sample
 //   B = I + sum_splits (w-tiles),  u = sum_splits (q-tiles),
 //   L L' = B (lower, null_gp.py:343), t = L^-1 u,
 //   log p = -1/2 ( sum r^2/d - t't + sum log d + 2 sum log L_ii + n log 2pi )  (null_gp.py:354-358)
@@ -74,13 +81,17 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
                                  double *__restrict__ out, int *__restrict__ status) {
     const long row = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (row >= rows) return;
-    const SightlineDev &sl = sightlines[row / S];
+    const long b = row / S, smp = row % S;
+    const SightlineDev &sl = sightlines[b];
     const int k = KT > 0 ? KT : sl.k;
     const int rw = sl.row_width;
     const int qbase = sl.ntw * DLAGP_TILE_COLS;
     const int sbase = (sl.ntw + sl.ntq) * DLAGP_TILE_COLS;
-    const long split_stride = rows * (long)rw;
-    const double *p0 = part + row;  // element (split h, column c) at p0[h * split_stride + c * rows]
+    const long ngroups = (S + 15) / 16;
+    const long nblocks = (rows / S) * ngroups;
+    const long block = b * ngroups + smp / 16;
+    const int lane16 = (int)(smp % 16);
+    auto partial = [&](int h, int col) { return part[partial_index(h, nblocks, block, rw, col, lane16)]; };
 
     constexpr int KMAX = KT > 0 ? KT : DLAGP_MAX_RANK;
     // fixed rank: unroll everything so L and t live in registers; runtime rank: keep the loops
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
     for (int c = 0; c < KMAX * (KMAX + 1) / 2; ++c) {
         if (c < k * (k + 1) / 2) {
             double acc = 0.0;
-            for (int h = 0; h < nsplit; ++h) acc += p0[h * split_stride + c * rows];
+            for (int h = 0; h < nsplit; ++h) acc += partial(h, c);
             L[c] = acc;
         }
     }
@@ -101,13 +112,13 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
     for (int c = 0; c < KMAX; ++c) {
         if (c < k) {
             double acc = 0.0;
-            for (int h = 0; h < nsplit; ++h) acc += p0[h * split_stride + (qbase + c) * rows];
+            for (int h = 0; h < nsplit; ++h) acc += partial(h, qbase + c);
             t[c] = acc;
         }
     }
     for (int h = 0; h < nsplit; ++h) {
-        sum_r2 += p0[h * split_stride + sbase * rows];
-        sum_logd += p0[h * split_stride + (sbase + 1) * rows];
+        sum_r2 += partial(h, sbase);
+        sum_logd += partial(h, sbase + 1);
     }
 
     bool bad = false;
@@ -174,29 +185,29 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     constexpr int NC = DLAGP_FIN_COLS;
     constexpr int NS = DLAGP_FIN_SAMPLES;
     const int tid = threadIdx.x;
-    const long row0 = blockIdx.x * (long)NS;
-    const SightlineDev &sl = sightlines[(row0 < rows ? row0 : rows - 1) / S];
+    const long ngroups = (S + NS - 1) / NS;
+    const long nblocks = (rows / S) * ngroups;
+    const long block = blockIdx.x;
+    const long b = block / ngroups, g = block % ngroups;
+    const long row0 = b * S + g * NS;          // first output row of this workgroup
+    const int valid = (int)((S - g * NS) < NS ? (S - g * NS) : NS);
+    const SightlineDev &sl = sightlines[b];
     const int rw = sl.row_width;
     const int qbase = sl.ntw * DLAGP_TILE_COLS;
     const int sbase = (sl.ntw + sl.ntq) * DLAGP_TILE_COLS;
-    const long split_stride = rows * (long)rw;
 
     // ---- stage: lds[c][sample], c < NC: vech(B - I); NC..NC+K-1: u; NC+K: sum r^2/d; NC+K+1: sum log d;
-    // NC+K+2: n log 2pi (written by split 0 of the accumulate kernel, so that no per-row lookup is needed).
-    // The reads are what this kernel costs (a CU sustains only tens of GB/s from HBM/MALL), hence
-    // the small workgroups: 625 of them for 10 000 samples instead of 157.
+    // NC+K+2: n log 2pi.  One contiguous 33 KB block per split: fully coalesced reads, which are what
+    // this kernel costs (a CU sustains only tens of GB/s from HBM/MALL, hence also the small workgroups).
     for (int idx = tid; idx < DLAGP_FIN_STAGED * NS; idx += DLAGP_FIN_THREADS) {
         const int c = idx / NS, smp = idx % NS;
         const int src = c < NC ? c : (c < NC + K ? qbase + (c - NC) : sbase + (c - NC - K));
-        long row = row0 + smp;
-        row = row < rows ? row : rows - 1;
-        const double *p0 = part + row + (long)src * rows;
         double acc = 0.0;
-        for (int h = 0; h < nsplit; ++h) acc += p0[h * split_stride];
+        for (int h = 0; h < nsplit; ++h) acc += part[partial_index(h, nblocks, block, rw, src, smp)];
         fin_lds[idx] = acc;
     }
     __syncthreads();
-    if (tid >= NS) return;
+    if (tid >= valid) return;  // lanes beyond the sightline's last sample hold unwritten partials
     const long row = row0 + tid;
     double *mine = fin_lds + tid;
 
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
         result = __builtin_nan("");
         atomicOr(status, 1);
     }
-    if (row < rows) out[row] = result;
+    out[row] = result;
 }
 
 // ---------------------------------------------------------------------------------------------

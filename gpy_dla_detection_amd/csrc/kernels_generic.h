@@ -9,7 +9,7 @@
 //            sum r^2/d, sum log d (dla_gp.py:392-394, null_gp.py:329-333,356)
 //   phase C  one thread per column of P: sum_i w_i P_i (B - I) and sum_i q_i M_i (u)
 // and writes one partial column set [B-I | u | sum r^2/d, sum log d] for finalize_samples
-// (layout part[column][row], see kernels_common.h).
+// (layout partial_index, see kernels_common.h).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -69,12 +69,14 @@ __device__ __forceinline__ double block_sum(double x, double *red) {
 // grid: (S, nb).  Dynamic LDS: (num_entries + n_pad + MAX_LINES + 8) doubles (max over sightlines).
 __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
     const SightlineDev *__restrict__ sightlines, long S, int kd, const double *__restrict__ z,
-    const double *__restrict__ nhi, double *__restrict__ part, long rows, int lds_entries, int lds_pixels) {
+    const double *__restrict__ nhi, double *__restrict__ part, int *__restrict__ status, int lds_entries,
+    int lds_pixels) {
     extern __shared__ double lds[];
     double *raw = lds;
     double *a = raw + lds_entries;
     double *mult = a + lds_pixels;
     double *red = mult + DLAGP_MAX_LINES + 1;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = 0;  // finalize raises it
 
     const SightlineDev &sl = sightlines[blockIdx.y];
     const long row = blockIdx.y * S + blockIdx.x;
@@ -102,7 +104,10 @@ __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
 
     // phase C: columns
     const int nt = sl.ntw + sl.ntq;
-    double *prow = part + row;  // column c of this sample at prow[c * rows]
+    const long ngroups = (S + 15) / 16;
+    const long block = blockIdx.y * ngroups + blockIdx.x / 16;
+    const long nblocks = gridDim.y * ngroups;
+    const int lane16 = blockIdx.x % 16;
     for (int c = tid; c < nt * DLAGP_TILE_COLS; c += DLAGP_GENERIC_THREADS) {
         const int tile = c / DLAGP_TILE_COLS;
         const int cc = c % DLAGP_TILE_COLS;
@@ -114,12 +119,12 @@ __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
                 acc = fma(weight[step * DLAGP_STEP_PIXELS + slot],
                           sl.P[shared_operand_index(step, tile, slot, cc, sl.npair)], acc);
         }
-        prow[c * rows] = acc;
+        part[partial_index(0, nblocks, block, sl.row_width, c, lane16)] = acc;
     }
     if (tid == 0) {
-        prow[(long)(nt * DLAGP_TILE_COLS) * rows] = sum_r2;
-        prow[(long)(nt * DLAGP_TILE_COLS + 1) * rows] = sum_logd;
-        prow[(long)(nt * DLAGP_TILE_COLS + 2) * rows] = sl.n * DLAGP_LOG_2PI;
+        part[partial_index(0, nblocks, block, sl.row_width, nt * DLAGP_TILE_COLS, lane16)] = sum_r2;
+        part[partial_index(0, nblocks, block, sl.row_width, nt * DLAGP_TILE_COLS + 1, lane16)] = sum_logd;
+        part[partial_index(0, nblocks, block, sl.row_width, nt * DLAGP_TILE_COLS + 2, lane16)] = sl.n * DLAGP_LOG_2PI;
     }
 }
 

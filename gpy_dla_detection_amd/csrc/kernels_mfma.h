@@ -26,7 +26,7 @@
 //            a = sum_t taps_t raw[pos + t] (voigt.py:319, dla_gp.py:388), d = omega2 a^2 + v,
 //            r = y - mu a, w = a^2/d, q = a r/d, running sum r^2/d and product of d
 //            (dla_gp.py:392-394, null_gp.py:329-333,356), then 16 MFMAs   (null_gp.py:339-354)
-// Output: partial sums part[split][column][row] for the finalize kernel.
+// Output: partial sums part[split][block][column][16] (partial_index) for the finalize kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -212,7 +212,7 @@ template <int LINES, bool BROADEN, bool STAMPS>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
     const int2 *const *__restrict__ split_tables, int nsplit, long S, int kd,
-    const double *__restrict__ z, const double *__restrict__ nhi, double *__restrict__ part, long rows,
+    const double *__restrict__ z, const double *__restrict__ nhi, double *__restrict__ part, int *__restrict__ status,
     int debug_flags) {
     constexpr int A_STRIDE = 4 * DLAGP_MAX_PASS_STEPS + 2;  // 58: stride/2 odd -> conflict-free b64 reads
     __shared__ double raw[16 * DLAGP_RAW_STRIDE];
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     __shared__ int pos_lds[64];
     extern __shared__ double prep_lds[];
 
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = 0;  // finalize raises it
     const int b = blockIdx.y;
     const SightlineDev &sl = sightlines[b];
     const int split = blockIdx.x % nsplit;
@@ -443,15 +444,17 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     }
     if (stamps) t_mark = stamp_now();
 
-    // ---------------- epilogue: partial sums to part[split][column][row] ----------------
+    // ---------------- epilogue: partial sums to part[split][block][column][16] ----------------
     // D layout: lane holds column (lane & 15) of rows (lane >> 4) + 4 r of the 16-sample tile.
     // Transposed through LDS (raw[] is free now) so that each store writes 16 consecutive samples
     // of 4 columns (4 x 128 B segments).
     const int rw = sl.row_width;
-    const long row_base = (long)b * S + sample0;
     const long rows_left = S - sample0;  // valid samples of this wave
+    const long ngroups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
+    const long nblocks = gridDim.y * ngroups;
+    // this wave's block of the partial sums: [column][16 samples], contiguous
     __attribute__((address_space(1))) double *base =
-        (__attribute__((address_space(1))) double *)(part) + (long)split * rw * rows;
+        (__attribute__((address_space(1))) double *)(part) + partial_index(split, nblocks, b * ngroups + group, rw, 0, 0);
     constexpr int TR_STRIDE = 17;  // [16 columns][16 samples + 1]
 #pragma unroll
     for (int t = 0; t < DLAGP_MFMA_NT; ++t) {
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         for (int cc = 0; cc < 4; ++cc) {
             const int col = cc * 4 + slot;  // lane -> (sample = s_loc, column = col)
             const double val = raw[col * TR_STRIDE + s_loc];
-            if (s_loc < rows_left) base[(long)(t * DLAGP_TILE_COLS + col) * rows + row_base + s_loc] = val;
+            if (s_loc < rows_left) base[(t * DLAGP_TILE_COLS + col) * 16 + s_loc] = val;  // 512 contiguous bytes
         }
         lds_wave_sync();
     }
@@ -472,10 +475,9 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     logd += __shfl_xor(logd, 16);
     logd += __shfl_xor(logd, 32);
     if (slot == 0 && s_loc < rows_left) {
-        const long row = row_base + s_loc;
-        base[(long)(DLAGP_MFMA_NT * DLAGP_TILE_COLS) * rows + row] = sum_r2;
-        base[(long)(DLAGP_MFMA_NT * DLAGP_TILE_COLS + 1) * rows + row] = logd;
-        base[(long)(DLAGP_MFMA_NT * DLAGP_TILE_COLS + 2) * rows + row] = split == 0 ? sl.n * DLAGP_LOG_2PI : 0.0;
+        base[(DLAGP_MFMA_NT * DLAGP_TILE_COLS) * 16 + s_loc] = sum_r2;
+        base[(DLAGP_MFMA_NT * DLAGP_TILE_COLS + 1) * 16 + s_loc] = logd;
+        base[(DLAGP_MFMA_NT * DLAGP_TILE_COLS + 2) * 16 + s_loc] = split == 0 ? sl.n * DLAGP_LOG_2PI : 0.0;
     }
     if (stamps && lane == 0) {
         const unsigned long long now = stamp_now();
