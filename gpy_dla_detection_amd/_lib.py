@@ -11,7 +11,8 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_ssize_t, c_uby
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdlagp_hip.so")
+# DLAGP_LIB lets a tuning session load an alternative build of the same ABI (A/B runs on one device)
+LIB_PATH = os.environ.get("DLAGP_LIB") or os.path.join(_HERE, "csrc", "libdlagp_hip.so")
 
 # error codes of include/dlagp.h
 DLAGP_OK, DLAGP_EINVAL, DLAGP_EDEVICE, DLAGP_ELINALG = 0, -1, -2, -3
