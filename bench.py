@@ -125,7 +125,7 @@ def main() -> None:
     ap.add_argument("--samples", type=int, default=NUM_SAMPLES, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--splits", type=int, default=0, help=argparse.SUPPRESS)  # tuning: force the pixel-split count
-    ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)  # timing experiments, wrong results
+    ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)  # 2: per-phase cycle stamps (diagnostic)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

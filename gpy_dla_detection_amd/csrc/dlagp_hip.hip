@@ -53,7 +53,7 @@ static int fail(int code, const char *fmt, ...) {
 static int64_t g_opt_pixel_splits = 0;
 static int64_t g_opt_path = 0;
 static int64_t g_opt_timing = 0;
-static int64_t g_opt_debug = 0;  // timing experiments (results become wrong); see kernels_mfma.h
+static int64_t g_opt_debug = 0;  // bit 1: stamped instantiation of the MFMA kernel (diagnostics)
 
 struct EventPair {
     hipEvent_t start, stop;

@@ -140,8 +140,8 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
  * Tuning / measurement hooks.
  *   dlagp_set_option: "pixel_splits" (0 = automatic), "path" (0 = automatic, 1 = generic
  *                     kernel, 2 = MFMA kernel), "timing" (1 = bracket the accumulate kernel
- *                     of every launch with HIP events on its stream), "debug" (bit 0: timing
- *                     experiment that re-reads one block of P -- wrong results; bit 1: phase stamps)
+ *                     of every launch with HIP events on its stream), "debug" (bit 1: launch the
+ *                     stamped instantiation of the MFMA kernel, see dlagp_debug_read)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.
  */
