@@ -70,16 +70,16 @@ def cpu_baseline(sight, z, nhi, cpu_seconds: float = 24.0):
     workers = max(1, min(cores, 16))  # a one-GPU box gives this job a 16-core share
     ctx = mp.get_context("fork")
     with ctx.Pool(workers, initializer=_cpu_worker_init, initargs=(sight,)) as pool:
-        # warm the workers (imports, BLAS init), calibrate, then size the sample
+        # warm the workers (imports, BLAS init), then time rounds of 32 evals per worker until the
+        # CPU-time budget is spent
         pool.map(_cpu_worker_eval, [(z[:2], nhi[:2])] * workers)
-        t0 = time.perf_counter()
-        pool.map(_cpu_worker_eval, [(z[i:i + 16], nhi[i:i + 16]) for i in range(0, 16 * workers, 16)])
-        per_eval = (time.perf_counter() - t0) / 16.0
-        per_worker = int(max(8, cpu_seconds / workers / max(per_eval, 1e-6)))
-        idx = [np.arange(w * per_worker, (w + 1) * per_worker) % len(z) for w in range(workers)]
-        t0 = time.perf_counter()
-        done = sum(pool.map(_cpu_worker_eval, [(z[i], nhi[i]) for i in idx]))
-        elapsed = time.perf_counter() - t0
+        done, elapsed, cursor = 0, 0.0, 0
+        while elapsed * workers < cpu_seconds:
+            idx = [np.arange(cursor + w * 32, cursor + (w + 1) * 32) % len(z) for w in range(workers)]
+            cursor += 32 * workers
+            t0 = time.perf_counter()
+            done += sum(pool.map(_cpu_worker_eval, [(z[i], nhi[i]) for i in idx]))
+            elapsed += time.perf_counter() - t0
     return {
         "value": done / elapsed,
         "unit": "evals/s",
