@@ -42,6 +42,35 @@ struct SightlineDev {
     double taps[DLAGP_NUM_TAPS];  // instrument profile (or {1, 0, ...})
 };
 
+// Where a launch finds the absorber parameters of sample (sightline b, sample s, absorber j).
+//   direct:  z[(b S + s) kd + j], nhi[...]                       (dlagp_eval*: the caller laid them out)
+//   indexed: absorber 0 is QMC point s, absorber j > 0 is QMC point base[b][j-1][s] drawn from the
+//            previous levels' posteriors (reference dla_gp.py:135-150); z[b S + point],
+//            nhi[nhi_stride b + point]                            (device-resident multi-level sweep)
+struct SampleSource {
+    const double *z;
+    const double *nhi;
+    const int *base;   // indexed mode: [nb][base_levels][S] int32
+    int indexed;       // 0 = direct
+    long nhi_stride;   // 0 when all sightlines share one column-density table, else S
+    int base_levels;   // rows of `base` per sightline (max_dlas - 1)
+};
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ long sample_point(const SampleSource &src, long b, long s, int j, long S, int kd) {
+    if (!src.indexed) return (b * S + s) * kd + j;
+    return j == 0 ? s : (long)src.base[(b * src.base_levels + (j - 1)) * S + s];
+}
+__device__ __forceinline__ double sample_z(const SampleSource &src, long b, long s, int j, long S, int kd) {
+    const long p = sample_point(src, b, s, j, S, kd);
+    return src.indexed ? src.z[b * S + p] : src.z[p];
+}
+__device__ __forceinline__ double sample_nhi(const SampleSource &src, long b, long s, int j, long S, int kd) {
+    const long p = sample_point(src, b, s, j, S, kd);
+    return src.indexed ? src.nhi[b * src.nhi_stride + p] : src.nhi[p];
+}
+#endif
+
 // Per-line constants of the Voigt profile, identical for every sightline; lives in constant memory.
 //   velocity_l = lam * mult_l(z) - c,  mult_l(z) = c / (lambda_l (1 + z)) / 1e8   (voigt.py:299,305)
 //   x = velocity / (sqrt2 sigma),  y_l = gamma_l / (sqrt2 sigma)                  (voigt.py:247)

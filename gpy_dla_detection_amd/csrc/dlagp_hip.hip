@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -134,7 +135,17 @@ struct Workspace {
     DeviceBuffer part;    // partial rows [nsplit][rows][row_width]
     DeviceBuffer status;  // int flag raised by finalize on a non-PD pivot
     DeviceBuffer z, nhi, out;  // staging for the host-pointer entry points
+    // device-resident occupation sweep: raw level log-likelihoods, cdf scratch, per-sightline alive flag,
+    // and staging of its host-pointer variant
+    DeviceBuffer level_ll, cdf, alive, uniforms, evidences, sample_ll, base;
     void release() {
+        level_ll.release();
+        cdf.release();
+        alive.release();
+        uniforms.release();
+        evidences.release();
+        sample_ll.release();
+        base.release();
         part.release();
         status.release();
         z.release();
@@ -290,21 +301,21 @@ static int choose_splits(const LaunchGroup &g, int64_t S) {
 // ------------------------------------------------------------------------------------------------
 template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, GroupPlan *gp, int nsplit,
-                        long S, int kd, int num_lines, const double *z, const double *nhi, double *part, int *status) {
+                        long S, int kd, int num_lines, const SampleSource &src, double *part, int *status) {
     const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * kd * ((LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
     if (g_opt_debug & 2) {  // diagnostic instantiation with per-phase cycle stamps
         hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, true>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
                            table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
-                           kd, z, nhi, part, status, (int)g_opt_debug);
+                           kd, src, part, status, (int)g_opt_debug);
     } else {
         hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, false>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
                            table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
-                           kd, z, nhi, part, status, (int)g_opt_debug);
+                           kd, src, part, status, (int)g_opt_debug);
     }
 }
 
-static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, const double *d_nhi,
-                        double *d_out, hipStream_t stream) {
+static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &src, double *d_out,
+                        hipStream_t stream) {
     if (S <= 0) return DLAGP_OK;
     Workspace &ws = g.ws;
     const int nb = (int)g.ctxs.size();
@@ -347,11 +358,11 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
         const bool lines3 = g.num_lines == 3;
         double *part = ws.part.as<double>();
         if (g.broadening) {
-            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, ws.status.as<int>());
-            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, ws.status.as<int>());
+            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>());
+            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>());
         } else {
-            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, ws.status.as<int>());
-            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, d_z, d_nhi, part, ws.status.as<int>());
+            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>());
+            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>());
         }
         HIP_TRY(hipGetLastError());
     } else {
@@ -366,7 +377,7 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const double *d_z, co
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         dim3 grid((unsigned)S, (unsigned)nb);
         hipLaunchKernelGGL(accumulate_generic, grid, dim3(DLAGP_GENERIC_THREADS), lds_bytes, stream, table, (long)S,
-                           kd, d_z, d_nhi, ws.part.as<double>(), ws.status.as<int>(), lds_entries, lds_pixels);
+                           kd, src, ws.part.as<double>(), ws.status.as<int>(), lds_entries, lds_pixels);
         HIP_TRY(hipGetLastError());
     }
 
@@ -403,12 +414,49 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
         HIP_TRY(hipMemcpy(ws.z.ptr, z, nsamp * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ws.nhi.ptr, nhi, nsamp * sizeof(double), hipMemcpyHostToDevice));
     }
-    rc = launch_sweep(g, S, kd, ws.z.as<double>(), ws.nhi.as<double>(), ws.out.as<double>(), nullptr);
+    rc = launch_sweep(g, S, kd, SampleSource{ws.z.as<double>(), ws.nhi.as<double>(), nullptr, 0, 0, 0},
+                      ws.out.as<double>(), nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, ws.out.ptr, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost));
     int status = 0;
     HIP_TRY(hipMemcpy(&status, ws.status.ptr, sizeof(int), hipMemcpyDeviceToHost));
     if (status) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
+    return DLAGP_OK;
+}
+
+// The whole occupation sweep of reference dla_gp.py:92-225 for every sightline of the group, enqueued on
+// `stream` with no host round trip between levels: per level one accumulate + finalize + level_finish.
+// All pointers are device addresses; d_base may not be NULL when max_dlas > 1.
+static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d_sample_z, const double *d_sample_nhi,
+                        int64_t nhi_stride, double min_z_separation, const double *d_uniforms, double *d_evidences,
+                        double *d_sample_ll, int *d_base, hipStream_t stream) {
+    Workspace &ws = g.ws;
+    const int nb = (int)g.ctxs.size();
+    const size_t rows = (size_t)nb * S;
+    int rc;
+    if ((rc = ws.level_ll.reserve(rows * sizeof(double)))) return rc;
+    if ((rc = ws.cdf.reserve(rows * sizeof(double)))) return rc;
+    if ((rc = ws.alive.reserve((size_t)(nb + 1) * sizeof(int)))) return rc;  // [nb] = sticky non-PD flag
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    const long n_ll = (long)rows * max_dlas, n_base = (long)rows * (max_dlas - 1);
+    hipLaunchKernelGGL(fill_f64, dim3((unsigned)std::min<long>((n_ll + 255) / 256, 2048)), dim3(256), 0, stream,
+                       d_sample_ll, n_ll, nan);
+    hipLaunchKernelGGL(fill_f64, dim3(1), dim3(256), 0, stream, d_evidences, (long)nb * max_dlas, nan);
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(256), 0, stream, ws.alive.as<int>(), (long)nb, 1);
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, stream, ws.alive.as<int>() + nb, 1L, 0);
+    if (n_base > 0)
+        hipLaunchKernelGGL(fill_i32, dim3((unsigned)std::min<long>((n_base + 255) / 256, 2048)), dim3(256), 0, stream,
+                           d_base, n_base, 0);
+    HIP_TRY(hipGetLastError());
+    const SampleSource src{d_sample_z, d_sample_nhi, d_base, 1, (int)nhi_stride, max_dlas - 1};
+    for (int level = 0; level < max_dlas; ++level) {
+        if ((rc = launch_sweep(g, S, level + 1, src, ws.level_ll.as<double>(), stream))) return rc;
+        hipLaunchKernelGGL(level_finish, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS), 0, stream,
+                           ws.level_ll.as<const double>(), (long)S, level, max_dlas, src, min_z_separation, d_uniforms,
+                           d_sample_ll, d_evidences, d_base, ws.cdf.as<double>(), ws.alive.as<int>(), ws.status.as<const int>(),
+                           ws.alive.as<int>() + nb);
+        HIP_TRY(hipGetLastError());
+    }
     return DLAGP_OK;
 }
 
@@ -666,7 +714,8 @@ int dlagp_eval_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, cons
     int rc = check_eval_args(ctx, S, kd, d_z, d_nhi, d_out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    return launch_sweep(ctx->self, S, kd, d_z, d_nhi, d_out, static_cast<hipStream_t>(stream));
+    return launch_sweep(ctx->self, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0}, d_out,
+                        static_cast<hipStream_t>(stream));
 }
 
 int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
@@ -705,7 +754,8 @@ int dlagp_batch_eval_device(dlagp_batch *batch, int64_t S, int kd, const double 
     int rc = check_eval_args(batch, S, kd, d_z, d_nhi, d_out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(batch->group.device));
-    return launch_sweep(batch->group, S, kd, d_z, d_nhi, d_out, static_cast<hipStream_t>(stream));
+    return launch_sweep(batch->group, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0}, d_out,
+                        static_cast<hipStream_t>(stream));
 }
 
 int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, const double *nhi, double *out) {
@@ -714,6 +764,66 @@ int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, con
     if (S == 0) return DLAGP_OK;
     HIP_TRY(hipSetDevice(batch->group.device));
     return sweep_from_host(batch->group, S, kd, z, nhi, out);
+}
+
+static int check_sweep_args(const dlagp_batch *batch, int64_t S, int max_dlas, const void *sample_z,
+                            const void *sample_nhi, int64_t nhi_stride, const void *uniforms, const void *evidences) {
+    if (!batch) return fail(DLAGP_EINVAL, "NULL batch");
+    if (S <= 0) return fail(DLAGP_EINVAL, "S = %lld, need S > 0", (long long)S);
+    if (S > INT32_MAX) return fail(DLAGP_EINVAL, "S = %lld does not fit the int32 base indices", (long long)S);
+    if (max_dlas < 1 || max_dlas > DLAGP_MAX_ABSORBERS)
+        return fail(DLAGP_EINVAL, "max_dlas = %d outside [1, %d]", max_dlas, DLAGP_MAX_ABSORBERS);
+    if (nhi_stride != 0 && nhi_stride < S) return fail(DLAGP_EINVAL, "nhi_stride must be 0 (shared) or >= S");
+    if (!sample_z || !sample_nhi || !evidences) return fail(DLAGP_EINVAL, "NULL argument");
+    if (max_dlas > 1 && !uniforms) return fail(DLAGP_EINVAL, "uniforms are required when max_dlas > 1");
+    return DLAGP_OK;
+}
+
+int dlagp_batch_sweep_device(dlagp_batch *batch, int64_t S, int max_dlas, const double *d_sample_z,
+                             const double *d_sample_nhi, int64_t nhi_stride, double min_z_separation,
+                             const double *d_uniforms, double *d_evidences, double *d_sample_ll, int32_t *d_base_inds,
+                             void *stream) {
+    int rc = check_sweep_args(batch, S, max_dlas, d_sample_z, d_sample_nhi, nhi_stride, d_uniforms, d_evidences);
+    if (rc) return rc;
+    if (!d_sample_ll || (max_dlas > 1 && !d_base_inds))
+        return fail(DLAGP_EINVAL, "the device variant needs d_sample_ll and d_base_inds (they are its working state)");
+    HIP_TRY(hipSetDevice(batch->group.device));
+    return sweep_levels(batch->group, S, max_dlas, d_sample_z, d_sample_nhi, nhi_stride, min_z_separation, d_uniforms,
+                        d_evidences, d_sample_ll, d_base_inds, static_cast<hipStream_t>(stream));
+}
+
+int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double *sample_z, const double *sample_nhi,
+                      int64_t nhi_stride, double min_z_separation, const double *uniforms, double *evidences,
+                      double *sample_ll, int32_t *base_inds) {
+    int rc = check_sweep_args(batch, S, max_dlas, sample_z, sample_nhi, nhi_stride, uniforms, evidences);
+    if (rc) return rc;
+    LaunchGroup &g = batch->group;
+    HIP_TRY(hipSetDevice(g.device));
+    Workspace &ws = g.ws;
+    const size_t nb = g.ctxs.size();
+    const size_t rows = nb * (size_t)S;
+    const size_t n_nhi = nhi_stride ? (size_t)nhi_stride * (nb - 1) + S : (size_t)S;
+    const size_t n_base = rows * (max_dlas - 1);
+    if ((rc = ws.z.reserve(rows * sizeof(double)))) return rc;
+    if ((rc = ws.nhi.reserve(n_nhi * sizeof(double)))) return rc;
+    if ((rc = ws.uniforms.reserve(std::max<size_t>(n_base, 1) * sizeof(double)))) return rc;
+    if ((rc = ws.evidences.reserve(nb * max_dlas * sizeof(double)))) return rc;
+    if ((rc = ws.sample_ll.reserve(rows * max_dlas * sizeof(double)))) return rc;
+    if ((rc = ws.base.reserve(std::max<size_t>(n_base, 1) * sizeof(int32_t)))) return rc;
+    HIP_TRY(hipMemcpy(ws.z.ptr, sample_z, rows * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ws.nhi.ptr, sample_nhi, n_nhi * sizeof(double), hipMemcpyHostToDevice));
+    if (n_base) HIP_TRY(hipMemcpy(ws.uniforms.ptr, uniforms, n_base * sizeof(double), hipMemcpyHostToDevice));
+    rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), nhi_stride, min_z_separation,
+                      ws.uniforms.as<double>(), ws.evidences.as<double>(), ws.sample_ll.as<double>(),
+                      ws.base.as<int>(), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(evidences, ws.evidences.ptr, nb * max_dlas * sizeof(double), hipMemcpyDeviceToHost));
+    if (sample_ll) HIP_TRY(hipMemcpy(sample_ll, ws.sample_ll.ptr, rows * max_dlas * sizeof(double), hipMemcpyDeviceToHost));
+    if (base_inds && n_base) HIP_TRY(hipMemcpy(base_inds, ws.base.ptr, n_base * sizeof(int32_t), hipMemcpyDeviceToHost));
+    int status = 0;
+    HIP_TRY(hipMemcpy(&status, ws.alive.as<int>() + nb, sizeof(int), hipMemcpyDeviceToHost));
+    if (status) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
+    return DLAGP_OK;
 }
 
 int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, const uint8_t *d_too_close,

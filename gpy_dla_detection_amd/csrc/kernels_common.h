@@ -9,6 +9,7 @@
 namespace dlagp {
 
 #define DLAGP_LOG_2PI 1.83787706640934534  // reference null_gp.py:325
+#define DLAGP_MAX_ABSORBERS_DEV 8           // = DLAGP_MAX_ABSORBERS of include/dlagp.h
 
 // Partial sums live in blocks of 16 consecutive samples of one sightline:
 //   part[split][block][column][16],  block = sightline * ngroups + sample / 16,  ngroups = ceil(S / 16)
@@ -321,6 +322,142 @@ __global__ __launch_bounds__(DLAGP_EVIDENCE_THREADS) void level_evidence(double 
         evidence[blockIdx.x] = n > 0.0 ? top + log(total / n) - level * log_s : __builtin_nan("");
     }
     (void)any;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident occupation sweep: everything the reference does between two levels
+// (dla_gp.py:155-218), one workgroup per sightline, no host round trip.
+//   1. ll[i] - log S -> sample_ll[b][level][i]; NaN where two absorbers of the sample are closer than
+//      min_z_separation (sorted-difference test on the sample's redshifts, :164-177)
+//   2. evidence = nanmax + log(nanmean(exp(ll - nanmax))) - level log S (:180-190); a NaN evidence ends
+//      the sightline's sweep (:200-206): later levels keep their NaN / zero fill
+//   3. unless this is the last level: resample base indices in proportion to exp(ll - nanmax) (NaN -> 0)
+//      exactly as np.random.choice(S, S, p = W / W.sum()) does -- cdf = cumsum(p) / cumsum(p)[-1],
+//      index = searchsorted(cdf, u, side="right") -- with the uniforms u drawn on the host from the
+//      legacy global RNG, so that the indices are the reference's (:213-218).  The cumulative sum
+//      is a parallel scan: its rounding differs from NumPy's sequential one at the 1e-16 level, far
+//      below the 1e-13 differences of the log-likelihoods themselves.
+// ---------------------------------------------------------------------------------------------
+#define DLAGP_LEVEL_THREADS 1024
+
+__device__ __forceinline__ double block_reduce(double x, bool take_max, double *red) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(x, off);
+        x = take_max ? fmax(x, o) : x + o;
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = x;
+    __syncthreads();
+    double total = red[0];
+    for (int w = 1; w < DLAGP_LEVEL_THREADS / 64; ++w) total = take_max ? fmax(total, red[w]) : total + red[w];
+    return total;
+}
+
+__global__ __launch_bounds__(DLAGP_LEVEL_THREADS) void level_finish(
+    const double *__restrict__ ll, long S, int level, int max_dlas, SampleSource src, double min_z_separation,
+    const double *__restrict__ uniforms, double *__restrict__ sample_ll, double *__restrict__ evidences,
+    int *__restrict__ base, double *__restrict__ cdf_scratch, int *__restrict__ alive,
+    const int *__restrict__ status, int *__restrict__ sticky_status) {
+    __shared__ double red[DLAGP_LEVEL_THREADS / 64];
+    __shared__ double scan[DLAGP_LEVEL_THREADS];
+    const int tid = threadIdx.x;
+    const long b = blockIdx.x;
+    if (b == 0 && tid == 0 && *status) *sticky_status = 1;  // the next level's accumulate clears *status
+    if (!alive[b]) return;  // an earlier level's evidence was NaN: the reference stopped there
+    const double log_s = log((double)S);
+    const double *in = ll + b * S;
+    double *col = sample_ll + (b * max_dlas + level) * S;
+    const int kd = level + 1;
+
+    // 1. Occam term, separation mask, running maximum
+    double top = -__builtin_inf();
+    for (long i = tid; i < S; i += DLAGP_LEVEL_THREADS) {
+        double v = in[i] - log_s;
+        if (level > 0) {
+            double zs[DLAGP_MAX_ABSORBERS_DEV];
+            for (int j = 0; j < kd; ++j) {  // insertion sort of the sample's redshifts
+                double zj = sample_z(src, b, i, j, S, kd);
+                int m = j;
+                while (m > 0 && zs[m - 1] > zj) {
+                    zs[m] = zs[m - 1];
+                    --m;
+                }
+                zs[m] = zj;
+            }
+            bool close = false;
+            for (int j = 1; j < kd; ++j) close |= (zs[j] - zs[j - 1]) < min_z_separation;
+            if (close) v = __builtin_nan("");
+        }
+        col[i] = v;
+        if (v == v) top = fmax(top, v);
+    }
+    top = block_reduce(top, true, red);
+
+    // 2. evidence
+    double sum = 0.0, count = 0.0;
+    for (long i = tid; i < S; i += DLAGP_LEVEL_THREADS) {
+        const double v = col[i];
+        if (v == v) {
+            sum += exp(v - top);
+            count += 1.0;
+        }
+    }
+    sum = block_reduce(sum, false, red);
+    count = block_reduce(count, false, red);
+    const double evidence = count > 0.0 ? top + log(sum / count) - level * log_s : __builtin_nan("");
+    if (tid == 0) {
+        evidences[b * max_dlas + level] = evidence;
+        if (!(evidence == evidence)) alive[b] = 0;
+    }
+    if (level + 1 == max_dlas || !(evidence == evidence)) return;
+
+    // 3. resample: cdf of W / sum(W) by a blocked scan (each thread owns a contiguous chunk)
+    double *cdf = cdf_scratch + b * S;
+    const long chunk = (S + DLAGP_LEVEL_THREADS - 1) / DLAGP_LEVEL_THREADS;
+    const long lo = tid * chunk, hi = lo + chunk < S ? lo + chunk : S;
+    double local = 0.0;
+    for (long i = lo; i < hi; ++i) {
+        const double v = col[i];
+        local += (v == v ? exp(v - top) : 0.0) / sum;
+    }
+    scan[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < DLAGP_LEVEL_THREADS; off <<= 1) {  // inclusive Hillis-Steele scan
+        const double add = tid >= off ? scan[tid - off] : 0.0;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
+    }
+    const double last = scan[DLAGP_LEVEL_THREADS - 1];
+    double running = tid > 0 ? scan[tid - 1] : 0.0;
+    for (long i = lo; i < hi; ++i) {
+        const double v = col[i];
+        running += (v == v ? exp(v - top) : 0.0) / sum;
+        cdf[i] = running / last;
+    }
+    __syncthreads();
+    __threadfence_block();
+    int *out = base + (b * (max_dlas - 1) + level) * S;
+    const double *u = uniforms + (b * (max_dlas - 1) + level) * S;
+    for (long i = tid; i < S; i += DLAGP_LEVEL_THREADS) {
+        const double ui = u[i];
+        long left = 0, right = S;  // first index with cdf[index] > u  (searchsorted side="right")
+        while (left < right) {
+            const long mid = (left + right) >> 1;
+            if (cdf[mid] <= ui) left = mid + 1;
+            else right = mid;
+        }
+        out[i] = (int)(left < S ? left : S - 1);
+    }
+}
+
+__global__ void fill_f64(double *__restrict__ dst, long n, double value) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = value;
+}
+
+__global__ void fill_i32(int *__restrict__ dst, long n, int value) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = value;
 }
 
 }  // namespace dlagp

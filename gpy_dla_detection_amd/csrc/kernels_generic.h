@@ -23,9 +23,8 @@ namespace dlagp {
 
 // Absorption vector of one sample into LDS a[0..n_pad) (padding pixels get 1).
 // raw[] is scratch of num_entries doubles; mult[] of DLAGP_MAX_LINES doubles.
-__device__ __forceinline__ void sample_absorption(const SightlineDev &sl, int kd, const double *z,
-                                                  const double *nhi, double *raw, double *a,
-                                                  double *mult) {
+__device__ __forceinline__ void sample_absorption(const SightlineDev &sl, int kd, const SampleSource &src, long b,
+                                                  long smp, long S, double *raw, double *a, double *mult) {
     const int tid = threadIdx.x;
     if (kd == 0) {  // null model: a = 1 exactly
         for (int i = tid; i < sl.n_pad; i += DLAGP_GENERIC_THREADS) a[i] = 1.0;
@@ -33,8 +32,8 @@ __device__ __forceinline__ void sample_absorption(const SightlineDev &sl, int kd
         return;
     }
     for (int j = 0; j < kd; ++j) {
-        const double zj = z[j];
-        const double nj = nhi[j];
+        const double zj = sample_z(src, b, smp, j, S, kd);
+        const double nj = sample_nhi(src, b, smp, j, S, kd);
         if (tid < sl.num_lines) mult[tid] = line_multiplier(tid, zj);
         __syncthreads();
         for (int e = tid; e < sl.num_entries; e += DLAGP_GENERIC_THREADS) {
@@ -68,9 +67,8 @@ __device__ __forceinline__ double block_sum(double x, double *red) {
 
 // grid: (S, nb).  Dynamic LDS: (num_entries + n_pad + MAX_LINES + 8) doubles (max over sightlines).
 __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
-    const SightlineDev *__restrict__ sightlines, long S, int kd, const double *__restrict__ z,
-    const double *__restrict__ nhi, double *__restrict__ part, int *__restrict__ status, int lds_entries,
-    int lds_pixels) {
+    const SightlineDev *__restrict__ sightlines, long S, int kd, SampleSource src, double *__restrict__ part,
+    int *__restrict__ status, int lds_entries, int lds_pixels) {
     extern __shared__ double lds[];
     double *raw = lds;
     double *a = raw + lds_entries;
@@ -79,10 +77,9 @@ __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = 0;  // finalize raises it
 
     const SightlineDev &sl = sightlines[blockIdx.y];
-    const long row = blockIdx.y * S + blockIdx.x;
     const int tid = threadIdx.x;
 
-    sample_absorption(sl, kd, z + row * kd, nhi + row * kd, raw, a, mult);
+    sample_absorption(sl, kd, src, blockIdx.y, blockIdx.x, S, raw, a, mult);
 
     // phase B: per-pixel weights; w overwrites raw[], q overwrites a[]
     double *w = raw;
@@ -137,7 +134,8 @@ __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void absorption_generic(
     double *a = raw + lds_entries;
     double *mult = a + lds_pixels;
     const SightlineDev &sl = sightlines[0];
-    sample_absorption(sl, kd, z, nhi, raw, a, mult);
+    const SampleSource src{z, nhi, nullptr, 0, 0, 0};
+    sample_absorption(sl, kd, src, 0, 0, 1, raw, a, mult);
     for (int i = threadIdx.x; i < sl.n; i += DLAGP_GENERIC_THREADS) out[i] = a[i];
 }
 

@@ -212,8 +212,7 @@ template <int LINES, bool BROADEN, bool STAMPS>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
     const int2 *const *__restrict__ split_tables, int nsplit, long S, int kd,
-    const double *__restrict__ z, const double *__restrict__ nhi, double *__restrict__ part, int *__restrict__ status,
-    int debug_flags) {
+    SampleSource src, double *__restrict__ part, int *__restrict__ status, int debug_flags) {
     constexpr int A_STRIDE = 4 * DLAGP_MAX_PASS_STEPS + 2;  // 58: stride/2 odd -> conflict-free b64 reads
     __shared__ double raw[16 * DLAGP_RAW_STRIDE];
     __shared__ double a_lds[16 * A_STRIDE];
@@ -232,8 +231,6 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     // descriptor fields used in the loops, read once
     const int num_entries = sl.num_entries;
     const gptr_d lam_ptr = as_global<gptr_d>(sl.lam);
-    const gptr_d z_ptr = as_global<gptr_d>(z);
-    const gptr_d nhi_ptr = as_global<gptr_d>(nhi);
     // P and the per-pixel records are streamed with buffer loads: scalar resource + per-lane byte
     // offset + scalar step offset + immediate, i.e. no vector address arithmetic in the loops
     const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -255,11 +252,11 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     for (int i = lane; i < wave_prep; i += 64) {
         const int which = i % prep_stride;           // 0..L-1: line multiplier, L: column density
         const int sample_abs = i / prep_stride;      // sample * kd + absorber
-        long row = sample0 + sample_abs / kd;
-        row = row < S ? row : S - 1;
-        const long src = ((long)b * S + row) * kd + sample_abs % kd;
-        prep_lds[i] = which == L ? nhi_ptr[src] * 1.44269504088896338700e+00
-                                 : line_multiplier(which, z_ptr[src]) * DLAGP_LINES.inv_sqrt2_sigma;
+        long smp = sample0 + sample_abs / kd;
+        smp = smp < S ? smp : S - 1;
+        const int j = sample_abs % kd;
+        prep_lds[i] = which == L ? sample_nhi(src, b, smp, j, S, kd) * 1.44269504088896338700e+00
+                                 : line_multiplier(which, sample_z(src, b, smp, j, S, kd)) * DLAGP_LINES.inv_sqrt2_sigma;
     }
 
     const PassDesc *passes = pass_tables[b];

@@ -112,6 +112,69 @@ def sweep_batch(
     return evidences, sample_ll, base_inds
 
 
+def resampling_uniforms(nb: int, max_dlas: int, S: int, seed: Optional[int] = 0) -> np.ndarray:
+    """
+    (nb, max_dlas - 1, S) uniforms that make the device resampling draw the reference's indices:
+    legacy `np.random.choice(S, S, p=p)` is `searchsorted(cumsum(p) / cumsum(p)[-1], random_sample(S),
+    side="right")`, one `random_sample(S)` per level.  With `seed` every sightline gets the stream it
+    would see if processed alone after `np.random.seed(seed)` (run_bayes_select.py:144) and the global
+    RNG is left as found; with None the draws advance the global RNG sightline by sightline.
+    """
+    levels = max(max_dlas - 1, 0)
+    if seed is None:
+        return np.random.random_sample((nb, levels, S))
+    outer_state = np.random.get_state()
+    np.random.seed(seed)
+    one = np.random.random_sample((levels, S))
+    np.random.set_state(outer_state)
+    return np.broadcast_to(one, (nb, levels, S)).copy()
+
+
+def sweep_batch_device(batch, sample_z: np.ndarray, sample_nhi: np.ndarray, max_dlas: int,
+                       min_z_separation: float, seed: Optional[int] = 0):
+    """
+    `sweep_batch` with every level's host half moved to the device (`DeviceBatch.sweep`,
+    C ABI dlagp_batch_sweep): same arguments, same return values, one call into the library.
+    """
+    nb, S = sample_z.shape
+    return batch.sweep(sample_z, sample_nhi, max_dlas, min_z_separation,
+                       resampling_uniforms(nb, max_dlas, S, seed))
+
+
+class ShardRunner:
+    """
+    One rank's share of a catalogue: its sightlines resident on one GPU (contexts, batch, workspace
+    are built once and reused), the synthetic Halton QMC sets of SURVEY.md §8(d), and `run()` =
+    log-evidences [null, sub-DLA, DLA(1..max_dlas)] of every local sightline.
+    """
+
+    def __init__(self, sightlines: Sequence, num_samples: int, max_dlas: int = 4,
+                 min_z_separation_kms: float = 3000.0, device: int = 0, make_batch: Optional[Callable] = None):
+        from .synthetic import make_qmc_samples
+
+        self.sightlines = list(sightlines)
+        self.max_dlas = max_dlas
+        self.min_sep = min_z_separation_kms * 1000.0 / 299792458.0
+        self.batch = None
+        if self.sightlines:
+            self.batch = (make_batch or _device_batch)(self.sightlines, device)
+            self.z = np.stack([make_qmc_samples(s, num_samples)[0] for s in self.sightlines])
+            self.nhi_dla = make_qmc_samples(self.sightlines[0], num_samples)[2]
+            self.nhi_sub = make_qmc_samples(self.sightlines[0], num_samples, sub_dla=True)[2]
+
+    def run(self) -> np.ndarray:
+        local = np.full((len(self.sightlines), 2 + self.max_dlas), np.nan)
+        if self.batch is not None:
+            local[:, 0] = self.batch.nulls()
+            if hasattr(self.batch, "sweep"):  # levels chained on the device
+                local[:, 1] = sweep_batch_device(self.batch, self.z, self.nhi_sub, 1, self.min_sep)[0][:, 0]
+                local[:, 2:] = sweep_batch_device(self.batch, self.z, self.nhi_dla, self.max_dlas, self.min_sep)[0]
+            else:  # an evaluator that only offers eval(): host half per level
+                local[:, 1] = sweep_batch(self.batch.eval, self.z, self.nhi_sub, 1, self.min_sep)[0][:, 0]
+                local[:, 2:] = sweep_batch(self.batch.eval, self.z, self.nhi_dla, self.max_dlas, self.min_sep)[0]
+        return local
+
+
 def model_evidences_sharded(
     sightlines: Sequence,
     num_samples: int,
@@ -128,28 +191,13 @@ def model_evidences_sharded(
     the post-set_data attributes, e.g. synthetic.SyntheticSightline), computed by the rank that owns
     the sightline and all-gathered: returns (len(sightlines), 2 + max_dlas) on every rank.
 
-    The QMC samples are the synthetic Halton sets of SURVEY.md §8(d) (`synthetic.make_qmc_samples`).
     `make_batch(list of sightlines, device)` must return an object with `.eval(z, nhi)` and
-    `.nulls()`; the default builds DeviceSightline / DeviceBatch (GPU).
+    `.nulls()` (and optionally `.sweep(...)`); the default builds DeviceSightline / DeviceBatch (GPU).
     """
-    from .synthetic import make_qmc_samples
-
     total = len(sightlines)
     lo, hi = shard_range(total, world_size, rank)
-    mine = list(sightlines[lo:hi])
-    local = np.full((len(mine), 2 + max_dlas), np.nan)
-    if mine:
-        if make_batch is None:
-            make_batch = _device_batch
-        batch = make_batch(mine, device)
-        min_sep = min_z_separation_kms * 1000.0 / 299792458.0
-        z_dla = np.stack([make_qmc_samples(s, num_samples)[0] for s in mine])
-        nhi_dla = make_qmc_samples(mine[0], num_samples)[2]
-        nhi_sub = make_qmc_samples(mine[0], num_samples, sub_dla=True)[2]
-        local[:, 0] = batch.nulls()
-        local[:, 1] = sweep_batch(batch.eval, z_dla, nhi_sub, 1, min_sep)[0][:, 0]
-        local[:, 2:] = sweep_batch(batch.eval, z_dla, nhi_dla, max_dlas, min_sep)[0]
-    return gather_rows(local, total, group=group)
+    runner = ShardRunner(sightlines[lo:hi], num_samples, max_dlas, min_z_separation_kms, device, make_batch)
+    return gather_rows(runner.run(), total, group=group)
 
 
 class _DeviceBatchAdapter:
@@ -161,6 +209,9 @@ class _DeviceBatchAdapter:
 
     def eval(self, z, nhi):
         return self.batch.eval(z, nhi)
+
+    def sweep(self, *args):
+        return self.batch.sweep(*args)
 
     def nulls(self):
         return np.array([d.null() for d in self.devs])

@@ -162,6 +162,51 @@ class DeviceBatch:
         _lib.check(_lib.load().dlagp_batch_eval_device(self._handle, S, kd, d_z, d_nhi, d_out, stream))
 
 
+    def sweep(self, sample_z, sample_nhi, max_dlas: int, min_z_separation: float, uniforms=None):
+        """
+        Occupation sweep of every sightline with all levels on the device (reference dla_gp.py:92-225).
+
+        :param sample_z: (nb, S) QMC redshifts;  sample_nhi: (S,) shared or (nb, S)
+        :param uniforms: (nb, max_dlas - 1, S) U[0,1) draws that stand in for the reference's
+            `np.random.choice` (see `parallel.resampling_uniforms`)
+        :return: evidences (nb, max_dlas), sample_log_likelihoods (nb, S, max_dlas),
+            base_sample_inds (nb, max_dlas - 1, S) int32 -- the reference's per-spectrum arrays, stacked
+        """
+        sample_z = np.ascontiguousarray(_lib.as_f64(sample_z))
+        sample_nhi = np.ascontiguousarray(_lib.as_f64(sample_nhi))
+        if sample_z.ndim != 2 or sample_z.shape[0] != self.nb:
+            raise ValueError("sample_z must be (nb, S)")
+        S = sample_z.shape[1]
+        if sample_nhi.shape == (S,):
+            stride = 0
+        elif sample_nhi.shape == (self.nb, S):
+            stride = S
+        else:
+            raise ValueError("sample_nhi must be (S,) or (nb, S)")
+        max_dlas = int(max_dlas)
+        if max_dlas > 1:
+            if uniforms is None:
+                raise ValueError("uniforms are required when max_dlas > 1")
+            uniforms = np.ascontiguousarray(_lib.as_f64(uniforms))
+            if uniforms.shape != (self.nb, max_dlas - 1, S):
+                raise ValueError("uniforms must be (nb, max_dlas - 1, S)")
+        evidences = np.empty((self.nb, max_dlas), dtype=np.float64)
+        sample_ll = np.empty((self.nb, max_dlas, S), dtype=np.float64)
+        base = np.zeros((self.nb, max(max_dlas - 1, 0), S), dtype=np.int32)
+        _lib.check(_lib.load().dlagp_batch_sweep(
+            self._handle, S, max_dlas, _lib.ptr(sample_z), _lib.ptr(sample_nhi), stride, float(min_z_separation),
+            _lib.ptr(uniforms) if max_dlas > 1 else None, _lib.ptr(evidences), _lib.ptr(sample_ll),
+            base.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) if max_dlas > 1 else None))
+        return evidences, np.ascontiguousarray(sample_ll.transpose(0, 2, 1)), base
+
+    def sweep_device(self, S: int, max_dlas: int, d_sample_z: int, d_sample_nhi: int, nhi_stride: int,
+                     min_z_separation: float, d_uniforms: int, d_evidences: int, d_sample_ll: int, d_base_inds: int,
+                     stream: int = 0) -> None:
+        _lib.check(_lib.load().dlagp_batch_sweep_device(
+            self._handle, S, max_dlas, d_sample_z, d_sample_nhi, nhi_stride, float(min_z_separation),
+            d_uniforms or None, d_evidences, d_sample_ll, d_base_inds or None, stream))
+
+
 def log_mvnpdf_low_rank(y, mu, M, d, device: int = 0) -> float:
     """stateless log N(y; mu, M M' + diag(d)) on the GPU (reference null_gp.py:307-360)"""
     y, mu, d = (_lib.as_f64(a) for a in (y, mu, d))

@@ -128,6 +128,36 @@ int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, con
                      double *out);
 
 /*
+ * The whole occupation sweep of DLAGP.log_model_evidences / SubDLAGP.log_model_evidences
+ * (reference dla_gp.py:92-225, subdla_gp.py:90-223) for every sightline of the batch, with no host
+ * round trip between levels: per level the accumulate + finalize launches, then one kernel that
+ * subtracts log S, masks samples whose absorbers are closer than min_z_separation (:164-177), forms
+ * the log-mean-exp evidence (:180-190), stops a sightline whose evidence is NaN (:200-206) and
+ * resamples the base indices for the next level (:213-218).
+ *
+ *   sample_z   [nb][S]                 QMC redshifts of every sightline (dla_samples.sample_z_dlas)
+ *   sample_nhi [S] (nhi_stride == 0, shared) or sightline b at sample_nhi + b * nhi_stride
+ *   uniforms   [nb][max_dlas-1][S]     U[0,1) draws standing in for the reference's global RNG:
+ *                                      np.random.random_sample(S) once per level, in level order,
+ *                                      reproduces np.random.choice(S, S, p = ...) index for index
+ *                                      (may be NULL when max_dlas == 1)
+ *   evidences  [nb][max_dlas]          log p(D | k absorbers), NaN after an early stop
+ *   sample_ll  [nb][max_dlas][S]       = sample_log_likelihoods[:, level] of the reference, transposed
+ *   base_inds  [nb][max_dlas-1][S]     = base_sample_inds of the reference
+ * The host variant is synchronous, sample_ll / base_inds may be NULL, and a non-PD B in any level
+ * returns DLAGP_ELINALG.  The device variant takes HBM pointers (all required), enqueues on `stream`
+ * and does not synchronise.  1 <= max_dlas <= DLAGP_MAX_ABSORBERS, S < 2^31.
+ */
+int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double *sample_z,
+                      const double *sample_nhi, int64_t nhi_stride, double min_z_separation,
+                      const double *uniforms, double *evidences, double *sample_ll,
+                      int32_t *base_inds);
+int dlagp_batch_sweep_device(dlagp_batch *batch, int64_t S, int max_dlas, const double *d_sample_z,
+                             const double *d_sample_nhi, int64_t nhi_stride,
+                             double min_z_separation, const double *d_uniforms, double *d_evidences,
+                             double *d_sample_ll, int32_t *d_base_inds, void *stream);
+
+/*
  * Level evidence on the device (reference dla_gp.py:155-190), for sweeps whose results stay in HBM.
  * d_ll [nb][S] holds the sweep's log-likelihoods and is rewritten in place as the level's column of
  * `sample_log_likelihoods`: minus log S, NaN where d_too_close[b][i] != 0 (NULL = no mask).

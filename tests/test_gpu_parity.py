@@ -468,3 +468,85 @@ def test_config3_batch_of_sightlines_full_size():
     for b in (1, 4, 7):  # index % 3 == 1: one injected absorber
         best = int(np.argmax(ll[b]))
         assert abs(z[b, best] - sights[b].injected_z[0]) < 0.02
+
+
+# ------------------------------------------------------------------------------------------------
+# device-resident occupation sweep (dlagp_batch_sweep): all of reference dla_gp.py:92-225 on the GPU
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["small", "full", "full2k"])
+def test_device_sweep_matches_reference_golden(tag):
+    """same golden vectors as the class-API test, but masking / evidence / resampling run on the device"""
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    g = load_golden("evidences_%s.npz" % tag)
+    kwargs = {k[len("sight_"):]: int(g[k]) for k in g.files if k.startswith("sight_") and k != "sight_crc"}
+    sight = make_sightline(**kwargs)
+    _, sub, dla = build_models(sight, int(g["S"]))
+    batch = DeviceBatch([dla.device_sightline()])
+    sample_z = dla.dla_samples.sample_z_dlas(dla.this_wavelengths, dla.z_qso)[None, :]
+
+    ev, ll, base = parallel.sweep_batch_device(batch, sample_z, dla.dla_samples.nhi_samples, 4,
+                                               dla.min_z_separation, seed=0)
+    np.testing.assert_array_equal(base[0], g["dla_base_inds"])  # the reference's np.random.choice draws
+    assert base.dtype == np.int32
+    np.testing.assert_allclose(ev[0], g["dla_evidences"], rtol=RTOL_LL)
+    assert np.array_equal(np.isnan(ll[0]), np.isnan(g["dla_sample_ll"]))
+    np.testing.assert_allclose(ll[0], g["dla_sample_ll"], rtol=RTOL_LL, equal_nan=True)
+    assert int(np.argmax(ev[0])) == int(np.argmax(g["dla_evidences"]))
+
+    ev_sub, ll_sub, base_sub = parallel.sweep_batch_device(batch, sample_z, sub.dla_samples.nhi_samples, 1,
+                                                           sub.min_z_separation, seed=0)
+    assert base_sub.shape == (1, 0, int(g["S"]))
+    np.testing.assert_allclose(ev_sub[0], g["sub_evidences"], rtol=RTOL_LL)
+    np.testing.assert_allclose(ll_sub[0], g["sub_sample_ll"], rtol=RTOL_LL)
+
+
+@pytest.mark.parametrize("path", [0, 1])
+def test_device_sweep_equals_host_level_logic(path, restore_options):
+    """several ragged sightlines, automatic and generic accumulate kernels: device levels == host levels"""
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    restore_options("path", path)
+    sights = [make_sightline(i, n_unmasked=n_u, n_masked=m) for i, (n_u, m) in enumerate([(300, 5), (411, 0), (257, 30)])]
+    devs = [device_sightline(s) for s in sights]
+    batch = DeviceBatch(devs)
+    S = 1200 if path == 0 else 150   # > 1024 exercises the blocked scan with several samples per thread
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    min_sep = 3000.0 * 1000.0 / 299792458.0
+    np.random.seed(77)
+    state = np.random.get_state()[1].copy()
+    want = parallel.sweep_batch(batch.eval, zs, nhi, 4, min_sep, seed=3)
+    got = parallel.sweep_batch_device(batch, zs, nhi, 4, min_sep, seed=3)
+    assert np.array_equal(np.random.get_state()[1], state)  # the caller's RNG stream is left as found
+    np.testing.assert_array_equal(got[2], want[2])
+    assert got[2].max() > 0 and np.isnan(want[1]).any()  # resampling and the separation mask both happened
+    assert np.array_equal(np.isnan(got[1]), np.isnan(want[1]))
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-12)
+
+
+def test_device_sweep_stops_a_sightline_on_nan_evidence():
+    """reference dla_gp.py:200-206: a NaN evidence ends that sightline's sweep; the others go on"""
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    sights = [make_sightline(i, n_unmasked=260, n_masked=3) for i in range(2)]
+    batch = DeviceBatch([device_sightline(s) for s in sights])
+    S = 96
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = np.stack([make_qmc_samples(sights[0], S)[2]] * 2)   # per-sightline column densities (nhi_stride = S)
+    nhi[1, :] = np.nan                                         # every sample of sightline 1 evaluates to NaN
+    min_sep = 3000.0 * 1000.0 / 299792458.0
+    ev, ll, base = parallel.sweep_batch_device(batch, zs, nhi, 3, min_sep, seed=0)
+    assert np.isnan(ev[1]).all() and np.isnan(ll[1]).all() and not base[1].any()
+    alone = parallel.sweep_batch_device(DeviceBatch([device_sightline(sights[0])]), zs[:1], nhi[0], 3, min_sep, seed=0)
+    np.testing.assert_array_equal(base[0], alone[2][0])
+    np.testing.assert_allclose(ev[0], alone[0][0], rtol=1e-12)
+    assert np.isfinite(ev[0]).all()
+    with pytest.raises(ValueError):
+        batch.sweep(zs, nhi[0], 9, min_sep, np.zeros((2, 8, S)))     # max_dlas > DLAGP_MAX_ABSORBERS
+    with pytest.raises(ValueError):
+        batch.sweep(zs, nhi[0], 2, min_sep)                          # uniforms missing
