@@ -69,17 +69,44 @@ t = timed(config3, reps=5, warm=1)
 out["config3_64x10000_dla_plus_subdla_evals_per_s"] = 2 * nb * S / t
 out["config3_ms"] = t * 1e3
 
-# end-to-end model selection [null, sub-DLA, DLA(1..4)] through the batch driver, host resampling
-# included; contexts and samples are built once (as a catalogue run would), only the sweeps are timed
+# end-to-end model selection [null, sub-DLA, DLA(1..4)] through the batch driver; contexts and samples
+# are built once (as a catalogue run would), only the sweeps are timed
 nsel = 16
-runner = parallel.ShardRunner(sights[:nsel], num_samples=S, max_dlas=4)
-runner.run()
-t0 = time.perf_counter()
-reps = 3
-for _ in range(reps):
-    ev = runner.run()
-t = (time.perf_counter() - t0) / reps
-out["model_selection_spectra_per_s"] = nsel / t
-out["model_selection_evals_per_s"] = nsel * (1 + S + 4 * S) / t
+
+
+def selection_rate(runner, reps=3):
+    runner.run()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ev = runner.run()
+    return nsel * reps / (time.perf_counter() - t0), ev
+
+
+class HostLevels:  # evaluator without .sweep: ShardRunner does the per-level host half (exact reference RNG path)
+    def __init__(self, inner):
+        self.eval, self.nulls = inner.eval, inner.nulls
+
+
+rate, ev_host = selection_rate(parallel.ShardRunner(
+    sights[:nsel], num_samples=S, max_dlas=4, make_batch=lambda s, d: HostLevels(parallel._device_batch(s, d))))
+out["model_selection_host_levels_spectra_per_s"] = rate
+rate, ev = selection_rate(parallel.ShardRunner(sights[:nsel], num_samples=S, max_dlas=4))
+out["model_selection_spectra_per_s"] = rate
+out["model_selection_evals_per_s"] = rate * (1 + S + 4 * S)
 out["model_selection_argmax"] = np.argmax(ev, axis=1).tolist()
+out["model_selection_device_equals_host_levels"] = bool(np.allclose(ev, ev_host, rtol=1e-12))
+
+# the same sweep with everything resident in HBM (dlagp_batch_sweep_device): 64 sightlines, DLA(1..4)
+max_dlas = 4
+d_nhi = torch.from_numpy(make_qmc_samples(sights[0], S)[2]).to(dev)
+d_u = torch.from_numpy(parallel.resampling_uniforms(nb, max_dlas, S, 0)).to(dev)
+d_ev = torch.empty((nb, max_dlas), dtype=torch.float64, device=dev)
+d_ll = torch.empty((nb, max_dlas, S), dtype=torch.float64, device=dev)
+d_base = torch.empty((nb, max_dlas - 1, S), dtype=torch.int32, device=dev)
+t = timed(lambda: batch.sweep_device(S, max_dlas, d_z.data_ptr(), d_nhi.data_ptr(), 0, 3000.0e3 / 299792458.0,
+                                     d_u.data_ptr(), d_ev.data_ptr(), d_ll.data_ptr(), d_base.data_ptr(), stream),
+          reps=3, warm=1)
+out["device_sweep_64x10000_dla1to4_ms"] = t * 1e3
+out["device_sweep_64x10000_dla1to4_evals_per_s"] = nb * S * max_dlas / t
+out["device_sweep_64x10000_dla1to4_spectra_per_s"] = nb / t
 print(json.dumps(out))
