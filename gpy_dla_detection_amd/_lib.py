@@ -26,6 +26,12 @@ SIGNATURES = {
     "dlagp_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, _dp, _dp, _dp, c_ssize_t, c_ssize_t,
                              _dp, _dp, _dp, POINTER(c_ubyte), c_int, c_int, c_int]),
     "dlagp_destroy": (None, [c_void_p]),
+    "dlagp_model_create": (c_int, [POINTER(c_void_p), c_int, c_int, _dp, _dp, _dp, c_ssize_t, c_ssize_t, _dp,
+                                   c_double, c_double, c_double, c_double, c_double, c_int, c_int]),
+    "dlagp_model_destroy": (None, [c_void_p]),
+    "dlagp_create_from_model": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int, _dp, _dp, _dp, _dp, c_double,
+                                        _dp, POINTER(c_ubyte), c_int, c_int]),
+    "dlagp_ctx_read_model": (c_int, [c_void_p, _dp, _dp, _dp]),
     "dlagp_ctx_n": (c_int, [c_void_p]),
     "dlagp_ctx_k": (c_int, [c_void_p]),
     "dlagp_ctx_device": (c_int, [c_void_p]),

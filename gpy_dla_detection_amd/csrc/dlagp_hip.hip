@@ -190,11 +190,20 @@ struct LaunchGroup {
     }
 };
 
+// learned GP model resident on one device (state of NullGP.__init__, reference null_gp.py:35-71)
+struct dlagp_model {
+    int device = 0;
+    ModelDev dev{};
+    DeviceBuffer grid, mu, log_omega, M;
+    double grid_min = 0.0, grid_max = 0.0;
+};
+
 struct dlagp_ctx {
     int device = 0;
     int user_k = 0;            // rank the caller passed (k <= 20 is zero-padded to 20 internally)
     SightlineDev sl{};         // host copy of the descriptor (device pointers inside)
     DeviceBuffer y, mu, omega2, v, pos, lam, P, aux;
+    DeviceBuffer dense_M;      // interpolated / uploaded factor, row-major [n][k], kept for dlagp_ctx_read_model
     std::vector<int> h_pos;    // host copy of pos[], for planning
     bool mfma_ok = false;      // rank padded to 20 and every 8-pixel chunk fits one 64-entry pass
     std::map<int, std::unique_ptr<SightlinePlan>> plans;
@@ -482,27 +491,15 @@ static int finish_group(LaunchGroup &g) {
     return DLAGP_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// C ABI
-// ------------------------------------------------------------------------------------------------
-extern "C" {
-
-int dlagp_abi_version(void) { return 1; }
-
-int dlagp_device_count(void) {
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
-    return count;
-}
-
-const char *dlagp_last_error(void) { return g_last_error.c_str(); }
-
-int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const double *mu, const double *M,
-                 ptrdiff_t m_row_stride, ptrdiff_t m_col_stride, const double *omega2, const double *v,
-                 const double *wavelengths, const uint8_t *keep, int num_lines, int broadening, int device) {
+// Everything of context creation that does not depend on where the model arrays come from:
+// descriptor, window starts, pass planning, wavelength grid; allocates the per-pixel device arrays.
+// `fill(ctx)` then has to leave y, mu, omega2, v (n_pad, padded 0/0/0/1) and dense_M ([n][sl.k]) on the device.
+template <typename Fill>
+static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *wavelengths, const uint8_t *keep,
+                          int num_lines, int broadening, int device, Fill fill) {
     if (!out) return fail(DLAGP_EINVAL, "out is NULL");
     *out = nullptr;
-    if (!y || !mu || !M || !omega2 || !v || !wavelengths || !keep) return fail(DLAGP_EINVAL, "NULL input array");
+    if (!wavelengths || !keep) return fail(DLAGP_EINVAL, "NULL input array");
     if (n <= 0 || n_u < n) return fail(DLAGP_EINVAL, "need 0 < n <= n_u (n=%d, n_u=%d)", n, n_u);
     if (k < 1 || k > DLAGP_MAX_RANK) return fail(DLAGP_EINVAL, "rank k=%d outside [1, %d]", k, DLAGP_MAX_RANK);
     if (num_lines < 1 || num_lines > DLAGP_MAX_LINES)
@@ -535,19 +532,11 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
     for (int t = 0; t < DLAGP_NUM_TAPS; ++t) sl.taps[t] = broadening ? DLAGP_INSTRUMENT_PROFILE[t] : (t == 0 ? 1.0 : 0.0);
     static_assert(DLAGP_NUM_TAPS == 7, "the MFMA kernel folds the symmetric 7-tap profile into 4 coefficients");
     for (int t = 0; t < 3; ++t)
-        if (DLAGP_INSTRUMENT_PROFILE[t] != DLAGP_INSTRUMENT_PROFILE[6 - t])
+        if (DLAGP_INSTRUMENT_PROFILE[t] != DLAGP_INSTRUMENT_PROFILE[6 - t]) {
+            delete ctx;
             return fail(DLAGP_EINVAL, "instrument profile is not symmetric");
+        }
 
-    // padded host images
-    std::vector<double> hy(sl.n_pad, 0.0), hmu(sl.n_pad, 0.0), ho(sl.n_pad, 0.0), hv(sl.n_pad, 1.0);
-    std::vector<double> hM((size_t)n * k_eff, 0.0);
-    for (int i = 0; i < n; ++i) {
-        hy[i] = y[i];
-        hmu[i] = mu[i];
-        ho[i] = omega2[i];
-        hv[i] = v[i];
-        for (int c = 0; c < k; ++c) hM[(size_t)i * k_eff + c] = M[i * m_row_stride + c * m_col_stride];
-    }
     // window start of kept pixel i = index of its unmasked pixel: with broadening the padded grid
     // has 3 extra entries in front, so the 7-tap "valid" window of unmasked pixel j is j .. j+6
     std::vector<int> &hpos = ctx->h_pos;
@@ -555,41 +544,29 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
     for (int j = 0, i = 0; j < n_u; ++j)
         if (keep[j]) hpos[i++] = j;
     for (int i = n; i < sl.n_pad; ++i) hpos[i] = hpos[n - 1];
-
     {
         std::vector<PassDesc> passes;
         std::vector<int2> splits;
         ctx->mfma_ok = k_eff == DLAGP_MFMA_RANK && plan_passes(hpos, sl.n_pad, sl.ntaps, 1, passes, splits);
     }
 
-    auto upload = [&](DeviceBuffer &buf, const void *src, size_t bytes) -> int {
-        int r = buf.reserve(bytes);
-        if (r) return r;
-        HIP_TRY(hipMemcpy(buf.ptr, src, bytes, hipMemcpyHostToDevice));
-        return DLAGP_OK;
-    };
-    DeviceBuffer dM;
+    const size_t px = (size_t)sl.n_pad * sizeof(double);
     const size_t p_bytes = (size_t)sl.nsteps * sl.npair * 2 * DLAGP_TILE_DOUBLES * sizeof(double);
-    rc = upload(ctx->y, hy.data(), hy.size() * sizeof(double));
-    if (!rc) rc = upload(ctx->mu, hmu.data(), hmu.size() * sizeof(double));
-    if (!rc) rc = upload(ctx->omega2, ho.data(), ho.size() * sizeof(double));
-    if (!rc) rc = upload(ctx->v, hv.data(), hv.size() * sizeof(double));
-    if (!rc) rc = upload(ctx->pos, hpos.data(), hpos.size() * sizeof(int));
-    if (!rc) rc = upload(ctx->lam, wavelengths, (size_t)sl.num_entries * sizeof(double));
-    std::vector<double> haux((size_t)sl.n_pad * DLAGP_AUX_FIELDS, 0.0);
-    for (int i = 0; i < sl.n_pad; ++i) {
-        double *rec = &haux[(size_t)i * DLAGP_AUX_FIELDS];
-        rec[0] = hy[i];
-        rec[1] = hmu[i];
-        rec[2] = ho[i];
-        rec[3] = hv[i];
-        rec[4] = (double)hpos[i];
-    }
-    if (!rc) rc = upload(ctx->aux, haux.data(), haux.size() * sizeof(double));
-    if (!rc) rc = upload(dM, hM.data(), hM.size() * sizeof(double));
+    rc = ctx->y.reserve(px);
+    if (!rc) rc = ctx->mu.reserve(px);
+    if (!rc) rc = ctx->omega2.reserve(px);
+    if (!rc) rc = ctx->v.reserve(px);
+    if (!rc) rc = ctx->pos.reserve((size_t)sl.n_pad * sizeof(int));
+    if (!rc) rc = ctx->lam.reserve((size_t)sl.num_entries * sizeof(double));
+    if (!rc) rc = ctx->aux.reserve(px * DLAGP_AUX_FIELDS);
+    if (!rc) rc = ctx->dense_M.reserve((size_t)n * k_eff * sizeof(double));
     if (!rc) rc = ctx->P.reserve(p_bytes);
+    if (!rc && hipMemcpy(ctx->pos.ptr, hpos.data(), (size_t)sl.n_pad * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(DLAGP_EDEVICE, "upload of the window starts failed");
+    if (!rc && hipMemcpy(ctx->lam.ptr, wavelengths, (size_t)sl.num_entries * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(DLAGP_EDEVICE, "upload of the wavelength grid failed");
+    if (!rc) rc = fill(ctx);
     if (rc) {
-        dM.release();
         dlagp_destroy(ctx);
         return rc;
     }
@@ -602,14 +579,15 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
     sl.P = ctx->P.as<double>();
     sl.aux = ctx->aux.as<double>();
 
-    hipLaunchKernelGGL(build_shared_operand, dim3(1024), dim3(256), 0, nullptr, dM.as<double>(), n, sl.n_pad, k_eff,
-                       sl.ntw, sl.ntq, sl.npair, ctx->P.as<double>());
+    hipLaunchKernelGGL(fill_records, dim3((sl.n_pad + 255) / 256), dim3(256), 0, nullptr, sl.n_pad, sl.y, sl.mu,
+                       sl.omega2, sl.v, sl.pos, ctx->aux.as<double>());
+    hipLaunchKernelGGL(build_shared_operand, dim3(1024), dim3(256), 0, nullptr, ctx->dense_M.as<double>(), n, sl.n_pad,
+                       k_eff, sl.ntw, sl.ntq, sl.npair, ctx->P.as<double>());
     hipError_t err = hipGetLastError();
     if (err == hipSuccess) err = hipDeviceSynchronize();
-    dM.release();
     if (err != hipSuccess) {
         dlagp_destroy(ctx);
-        return fail(DLAGP_EDEVICE, "build_shared_operand failed: %s", hipGetErrorString(err));
+        return fail(DLAGP_EDEVICE, "context set-up kernels failed: %s", hipGetErrorString(err));
     }
     ctx->self.device = device;
     ctx->self.ctxs.push_back(ctx);
@@ -619,6 +597,173 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
         return rc;
     }
     *out = ctx;
+    return DLAGP_OK;
+}
+
+// upload n doubles padded to n_pad with `pad`
+static int upload_padded(DeviceBuffer &buf, const double *src, int n, int n_pad, double pad) {
+    std::vector<double> host(n_pad, pad);
+    std::copy(src, src + n, host.begin());
+    HIP_TRY(hipMemcpy(buf.ptr, host.data(), (size_t)n_pad * sizeof(double), hipMemcpyHostToDevice));
+    return DLAGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int dlagp_abi_version(void) { return 1; }
+
+int dlagp_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+const char *dlagp_last_error(void) { return g_last_error.c_str(); }
+
+int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const double *mu, const double *M,
+                 ptrdiff_t m_row_stride, ptrdiff_t m_col_stride, const double *omega2, const double *v,
+                 const double *wavelengths, const uint8_t *keep, int num_lines, int broadening, int device) {
+    if (out) *out = nullptr;
+    if (!y || !mu || !M || !omega2 || !v) return fail(DLAGP_EINVAL, "NULL input array");
+    return create_context(out, n, n_u, k, wavelengths, keep, num_lines, broadening, device, [&](dlagp_ctx *ctx) -> int {
+        const SightlineDev &sl = ctx->sl;
+        int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0);
+        if (!rc) rc = upload_padded(ctx->mu, mu, n, sl.n_pad, 0.0);
+        if (!rc) rc = upload_padded(ctx->omega2, omega2, n, sl.n_pad, 0.0);
+        if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0);
+        if (rc) return rc;
+        std::vector<double> hM((size_t)n * sl.k, 0.0);
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < k; ++c) hM[(size_t)i * sl.k + c] = M[i * m_row_stride + c * m_col_stride];
+        HIP_TRY(hipMemcpy(ctx->dense_M.ptr, hM.data(), hM.size() * sizeof(double), hipMemcpyHostToDevice));
+        return DLAGP_OK;
+    });
+}
+
+int dlagp_model_create(dlagp_model **out, int n_grid, int k, const double *rest_wavelengths, const double *mu,
+                       const double *M, ptrdiff_t m_row_stride, ptrdiff_t m_col_stride, const double *log_omega,
+                       double log_c_0, double log_tau_0, double log_beta, double prev_tau_0, double prev_beta,
+                       int num_forest_lines, int device) {
+    if (!out) return fail(DLAGP_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!rest_wavelengths || !mu || !M || !log_omega) return fail(DLAGP_EINVAL, "NULL input array");
+    if (n_grid < 2) return fail(DLAGP_EINVAL, "the model grid needs at least two points");
+    if (k < 1 || k > DLAGP_MAX_RANK) return fail(DLAGP_EINVAL, "rank k=%d outside [1, %d]", k, DLAGP_MAX_RANK);
+    if (num_forest_lines < 1 || num_forest_lines > DLAGP_MAX_LINES)
+        return fail(DLAGP_EINVAL, "num_forest_lines=%d outside [1, %d]", num_forest_lines, DLAGP_MAX_LINES);
+    for (int i = 1; i < n_grid; ++i)
+        if (!(rest_wavelengths[i] > rest_wavelengths[i - 1]))
+            return fail(DLAGP_EINVAL, "rest_wavelengths must be strictly increasing");
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    dlagp_model *m = new dlagp_model();
+    m->device = device;
+    m->grid_min = rest_wavelengths[0];
+    m->grid_max = rest_wavelengths[n_grid - 1];
+    std::vector<double> cols((size_t)k * n_grid);
+    for (int c = 0; c < k; ++c)
+        for (int i = 0; i < n_grid; ++i) cols[(size_t)c * n_grid + i] = M[i * m_row_stride + c * m_col_stride];
+    const size_t gb = (size_t)n_grid * sizeof(double);
+    rc = m->grid.reserve(gb);
+    if (!rc) rc = m->mu.reserve(gb);
+    if (!rc) rc = m->log_omega.reserve(gb);
+    if (!rc) rc = m->M.reserve(cols.size() * sizeof(double));
+    hipError_t err = hipSuccess;
+    if (!rc) err = hipMemcpy(m->grid.ptr, rest_wavelengths, gb, hipMemcpyHostToDevice);
+    if (!rc && err == hipSuccess) err = hipMemcpy(m->mu.ptr, mu, gb, hipMemcpyHostToDevice);
+    if (!rc && err == hipSuccess) err = hipMemcpy(m->log_omega.ptr, log_omega, gb, hipMemcpyHostToDevice);
+    if (!rc && err == hipSuccess) err = hipMemcpy(m->M.ptr, cols.data(), cols.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (!rc && err != hipSuccess) rc = fail(DLAGP_EDEVICE, "model upload failed: %s", hipGetErrorString(err));
+    if (rc) {
+        dlagp_model_destroy(m);
+        return rc;
+    }
+    ModelDev &d = m->dev;
+    d.n_grid = n_grid;
+    d.k = k;
+    d.num_forest_lines = num_forest_lines;
+    d.grid = m->grid.as<double>();
+    d.mu = m->mu.as<double>();
+    d.log_omega = m->log_omega.as<double>();
+    d.M = m->M.as<double>();
+    d.prev_beta = prev_beta;
+    d.beta = std::exp(log_beta);
+    d.c_0 = std::exp(log_c_0);
+    const double tau_0 = std::exp(log_tau_0);
+    // effective_optical_depth.py:60-77: lines in Angstrom; scale = tau_0 * f / f[0] * lines / lines[0], left to right
+    const double line0 = DLAGP_TRANSITION_WAVELENGTHS_CM[0] * 1e8;
+    for (int l = 0; l < DLAGP_MAX_LINES; ++l) {
+        const double line = DLAGP_TRANSITION_WAVELENGTHS_CM[l] * 1e8;
+        const double f = DLAGP_OSCILLATOR_STRENGTHS[l], f0 = DLAGP_OSCILLATOR_STRENGTHS[0];
+        d.lines[l] = line;
+        d.scale_prev[l] = prev_tau_0 * f / f0 * line / line0;
+        d.scale_noise[l] = tau_0 * f / f0 * line / line0;
+    }
+    *out = m;
+    return DLAGP_OK;
+}
+
+void dlagp_model_destroy(dlagp_model *model) {
+    if (!model) return;
+    (void)hipSetDevice(model->device);
+    model->grid.release();
+    model->mu.release();
+    model->log_omega.release();
+    model->M.release();
+    delete model;
+}
+
+int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, int n_u, const double *x,
+                            const double *y, const double *v, const double *this_wavelengths, double z_qso,
+                            const double *wavelengths, const uint8_t *keep, int num_lines, int broadening) {
+    if (out) *out = nullptr;
+    if (!model) return fail(DLAGP_EINVAL, "model is NULL");
+    if (!x || !y || !v || !this_wavelengths) return fail(DLAGP_EINVAL, "NULL input array");
+    for (int i = 0; i < n; ++i)  // scipy's interp1d raises ValueError outside the grid (bounds_error)
+        if (!(x[i] >= model->grid_min && x[i] <= model->grid_max))
+            return fail(DLAGP_EINVAL, "rest wavelength %g outside the model grid [%g, %g]", x[i], model->grid_min,
+                        model->grid_max);
+    return create_context(out, n, n_u, model->dev.k, wavelengths, keep, num_lines, broadening, model->device,
+                          [&](dlagp_ctx *ctx) -> int {
+        const SightlineDev &sl = ctx->sl;
+        int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0);
+        if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0);
+        if (rc) return rc;
+        DeviceBuffer dx, dw;
+        rc = dx.reserve((size_t)n * sizeof(double));
+        if (!rc) rc = dw.reserve((size_t)n * sizeof(double));
+        hipError_t err = hipSuccess;
+        if (!rc) err = hipMemcpy(dx.ptr, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+        if (!rc && err == hipSuccess) err = hipMemcpy(dw.ptr, this_wavelengths, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+        if (!rc && err == hipSuccess) {
+            hipLaunchKernelGGL(interp_model, dim3((sl.n_pad + 63) / 64), dim3(64), 0, nullptr, model->dev, n, sl.n_pad,
+                               sl.k, dx.as<const double>(), dw.as<const double>(), z_qso, ctx->mu.as<double>(),
+                               ctx->omega2.as<double>(), ctx->dense_M.as<double>());
+            err = hipGetLastError();
+            if (err == hipSuccess) err = hipDeviceSynchronize();
+        }
+        dx.release();
+        dw.release();
+        if (!rc && err != hipSuccess) rc = fail(DLAGP_EDEVICE, "interp_model failed: %s", hipGetErrorString(err));
+        return rc;
+    });
+}
+
+int dlagp_ctx_read_model(dlagp_ctx *ctx, double *this_mu, double *this_M, double *this_omega2) {
+    if (!ctx) return fail(DLAGP_EINVAL, "context is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n = ctx->sl.n, k = ctx->user_k, ks = ctx->sl.k;
+    if (this_mu) HIP_TRY(hipMemcpy(this_mu, ctx->mu.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (this_omega2) HIP_TRY(hipMemcpy(this_omega2, ctx->omega2.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (this_M) {
+        std::vector<double> host((size_t)n * ks);
+        HIP_TRY(hipMemcpy(host.data(), ctx->dense_M.ptr, host.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < k; ++c) this_M[(size_t)i * k + c] = host[(size_t)i * ks + c];
+    }
     return DLAGP_OK;
 }
 
@@ -633,6 +778,7 @@ void dlagp_destroy(dlagp_ctx *ctx) {
     ctx->lam.release();
     ctx->P.release();
     ctx->aux.release();
+    ctx->dense_M.release();
     for (auto &kv : ctx->plans) {
         kv.second->passes.release();
         kv.second->splits.release();

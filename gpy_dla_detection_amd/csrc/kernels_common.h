@@ -64,6 +64,115 @@ __global__ void build_shared_operand(const double *__restrict__ M_dev, int n, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// Model interpolation: NullGP.get_interp (reference null_gp.py:179-242) on the device.
+// One thread per kept pixel i:
+//   linear interpolation of mu, log_omega and the k columns of M at the pixel's rest wavelength
+//     (scipy interp1d(kind="linear") = numpy.interp: slope = (f[j+1]-f[j])/(x[j+1]-x[j]),
+//      value = slope (x - x[j]) + f[j], null_gp.py:67-71,189-195) -- same operation order, no FMA;
+//   Lyman-series effective optical depth, effective_optical_depth.py:43-80:
+//     tau_l = scale_l (1 + z_l)^beta [z_l <= z_qso],  z_l = (lambda_obs - lambda_l)/lambda_l,
+//     summed over the series in numpy's order for a 31-element row (8 strided partial sums combined
+//     pairwise, then the tail);
+//   mean-flux suppression exp(-sum tau) on mu and M (null_gp.py:197-214), noise scaling
+//     omega2 = exp(2 log_omega) (1 - exp(-sum tau_noise) + c_0)^2 suppression^2 (:216-236).
+// Outputs in the layout dlagp_create builds from host arrays: mu, omega2 padded to n_pad with zeros,
+// M dense row-major [n][k_out] (columns >= k zero).
+// ---------------------------------------------------------------------------------------------
+struct ModelDev {
+    int n_grid, k, num_forest_lines;
+    const double *grid;       // [n_grid] rest wavelengths, increasing
+    const double *mu;         // [n_grid]
+    const double *log_omega;  // [n_grid]
+    const double *M;          // [k][n_grid]: one contiguous column per eigenvector
+    double prev_beta, beta, c_0;
+    double lines[DLAGP_MAX_LINES];        // series wavelengths, Angstrom
+    double scale_prev[DLAGP_MAX_LINES];   // prev_tau_0 f_l/f_0 lambda_l/lambda_0
+    double scale_noise[DLAGP_MAX_LINES];  // tau_0        f_l/f_0 lambda_l/lambda_0
+};
+
+__device__ __forceinline__ double numpy_row_sum(const double *t, int n) {
+    if (n < 8) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s = __dadd_rn(s, t[i]);
+        return s;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = t[j];
+    int i = 8;
+    for (; i + 8 <= n; i += 8)
+        for (int j = 0; j < 8; ++j) r[j] = __dadd_rn(r[j], t[i + j]);
+    double s = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                         __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+    for (; i < n; ++i) s = __dadd_rn(s, t[i]);
+    return s;
+}
+
+__device__ __forceinline__ double numpy_interp(const double *__restrict__ xp, const double *__restrict__ fp, int j,
+                                               int n_grid, double x) {
+    if (j >= n_grid - 1) return fp[n_grid - 1];
+    const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    return __dadd_rn(__dmul_rn(slope, x - xp[j]), fp[j]);
+}
+
+__global__ void interp_model(ModelDev model, int n, int n_pad, int k_out, const double *__restrict__ x,
+                             const double *__restrict__ wavelengths, double z_qso, double *__restrict__ mu_out,
+                             double *__restrict__ omega2_out, double *__restrict__ M_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    if (i >= n) {
+        mu_out[i] = 0.0;
+        omega2_out[i] = 0.0;
+        return;
+    }
+    const double xi = x[i];
+    // largest j with grid[j] <= xi (the host has checked grid[0] <= xi <= grid[n_grid - 1])
+    int lo = 0, hi = model.n_grid - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (model.grid[mid] <= xi) lo = mid;
+        else hi = mid - 1;
+    }
+    const int j = lo;
+
+    const double w = wavelengths[i];
+    double tau_prev[DLAGP_MAX_LINES], tau_noise[DLAGP_MAX_LINES];
+    const int L = model.num_forest_lines;
+    for (int l = 0; l < L; ++l) {
+        const double z_abs = (w - model.lines[l]) / model.lines[l];
+        const double base = 1.0 + z_abs;
+        const double inside = z_abs <= z_qso ? 1.0 : 0.0;
+        tau_prev[l] = model.scale_prev[l] * pow(base, model.prev_beta) * inside;
+        tau_noise[l] = model.scale_noise[l] * pow(base, model.beta) * inside;
+    }
+    const double absorption = exp(-numpy_row_sum(tau_prev, L));
+    const double scaling = __dadd_rn(1.0 - exp(-numpy_row_sum(tau_noise, L)), model.c_0);
+
+    mu_out[i] = numpy_interp(model.grid, model.mu, j, model.n_grid, xi) * absorption;
+    double o2 = exp(2.0 * numpy_interp(model.grid, model.log_omega, j, model.n_grid, xi));
+    o2 = __dmul_rn(o2, __dmul_rn(scaling, scaling));
+    omega2_out[i] = __dmul_rn(o2, __dmul_rn(absorption, absorption));
+    for (int c = 0; c < k_out; ++c)
+        M_out[(long)i * k_out + c] =
+            c < model.k ? numpy_interp(model.grid, model.M + (long)c * model.n_grid, j, model.n_grid, xi) * absorption
+                        : 0.0;
+}
+
+// per-pixel records {y, mu, omega2, v, window start, 3 spare} streamed by the MFMA kernel
+__global__ void fill_records(int n_pad, const double *__restrict__ y, const double *__restrict__ mu,
+                             const double *__restrict__ omega2, const double *__restrict__ v,
+                             const int *__restrict__ pos, double *__restrict__ aux) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    double *rec = aux + (long)i * 8;
+    rec[0] = y[i];
+    rec[1] = mu[i];
+    rec[2] = omega2[i];
+    rec[3] = v[i];
+    rec[4] = (double)pos[i];
+    rec[5] = rec[6] = rec[7] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Finalisation: one thread per sample.
 //   partials: part[split][block][column][16] (partial_index), row = sightline * S + sample
 //   B = I + sum_splits (w-tiles),  u = sum_splits (q-tiles),

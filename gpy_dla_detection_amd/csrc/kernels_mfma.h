@@ -361,7 +361,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                     if (st < DLAGP_MAX_PASS_STEPS) {
                         // the instrument profile is symmetric (voigt.py:214-224): 4 coefficients, not 7
                         double conv = wv[u][0];
-                        if (BROADEN) {
+                        if constexpr (BROADEN) {
                             conv = (wv[u][0] + wv[u][6]) * tap[0];
                             conv = fma(wv[u][1] + wv[u][5], tap[1], conv);
                             conv = fma(wv[u][2] + wv[u][4], tap[2], conv);

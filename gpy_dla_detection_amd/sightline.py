@@ -13,6 +13,39 @@ import numpy as np
 from . import _lib
 
 
+class DeviceModel:
+    """
+    The learned GP model on its rest-frame grid, resident on one device and shared by every
+    spectrum interpolated from it (arguments of NullGP.__init__, reference null_gp.py:35-71).
+    """
+
+    def __init__(self, rest_wavelengths, mu, M, log_omega, log_c_0: float, log_tau_0: float, log_beta: float,
+                 prev_tau_0: float = 0.0023, prev_beta: float = 3.65, num_forest_lines: int = 31, device: int = 0):
+        lib = _lib.load()
+        grid, mu, log_omega = (_lib.as_f64(a) for a in (rest_wavelengths, mu, log_omega))
+        M = _lib.strided_f64(M)
+        if M.ndim != 2 or M.shape[0] != grid.shape[0] or mu.shape != grid.shape or log_omega.shape != grid.shape:
+            raise ValueError("model arrays must be (n_grid,), (n_grid,), (n_grid, k), (n_grid,)")
+        handle = ctypes.c_void_p()
+        _lib.check(lib.dlagp_model_create(
+            ctypes.byref(handle), grid.shape[0], M.shape[1], _lib.ptr(grid), _lib.ptr(mu), _lib.ptr(M),
+            M.strides[0] // 8, M.strides[1] // 8, _lib.ptr(log_omega), float(log_c_0), float(log_tau_0),
+            float(log_beta), float(prev_tau_0), float(prev_beta), int(num_forest_lines), int(device)))
+        self._handle = handle
+        self.k, self.device = M.shape[1], int(device)
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            _lib.load().dlagp_model_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceSightline:
     """
     :param y, mu, omega2, v: (n,) flux, GP mean, absorption noise, instrumental noise variance
@@ -48,6 +81,44 @@ class DeviceSightline:
         self._handle = handle
         self.n, self.k, self.device = n, k, int(device)
         self.num_lines, self.broadening = int(num_lines), bool(broadening)
+
+    @classmethod
+    def from_model(cls, model: DeviceModel, x, y, v, this_wavelengths, z_qso: float, wavelengths, keep,
+                   num_lines: int = 3, broadening: bool = True):
+        """
+        NullGP.get_interp on the device (dlagp_create_from_model): the GP mean, factor and absorption
+        noise are interpolated from `model` at the kept pixels' rest wavelengths `x` and suppressed by
+        the Lyman-series mean flux at the observed `this_wavelengths` (reference null_gp.py:179-242).
+        """
+        lib = _lib.load()
+        x, y, v, this_wavelengths = (_lib.as_f64(a) for a in (x, y, v, this_wavelengths))
+        wavelengths = _lib.as_f64(wavelengths)
+        keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        n, n_u = x.shape[0], keep.shape[0]
+        for name, arr in (("y", y), ("v", v), ("this_wavelengths", this_wavelengths)):
+            if arr.shape != (n,):
+                raise ValueError("{} has shape {}, expected ({},)".format(name, arr.shape, n))
+        expected = n_u + 6 if broadening else n_u
+        if wavelengths.shape != (expected,):
+            raise ValueError("wavelengths has shape {}, expected ({},)".format(wavelengths.shape, expected))
+        handle = ctypes.c_void_p()
+        _lib.check(lib.dlagp_create_from_model(
+            ctypes.byref(handle), model._handle, n, n_u, _lib.ptr(x), _lib.ptr(y), _lib.ptr(v),
+            _lib.ptr(this_wavelengths), float(z_qso), _lib.ptr(wavelengths),
+            keep.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), int(num_lines), int(bool(broadening))))
+        self = cls.__new__(cls)
+        self._handle = handle
+        self.n, self.k, self.device = n, model.k, model.device
+        self.num_lines, self.broadening = int(num_lines), bool(broadening)
+        return self
+
+    def read_model(self):
+        """(this_mu (n,), this_M (n, k), this_omega2 (n,)) as they sit on the device"""
+        mu = np.empty(self.n)
+        M = np.empty((self.n, self.k))
+        omega2 = np.empty(self.n)
+        _lib.check(_lib.load().dlagp_ctx_read_model(self._handle, _lib.ptr(mu), _lib.ptr(M), _lib.ptr(omega2)))
+        return mu, M, omega2
 
     @classmethod
     def from_state(cls, st, num_lines: int = 3, broadening: bool = True, device: int = 0):

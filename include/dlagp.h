@@ -51,6 +51,7 @@ extern "C" {
 
 typedef struct dlagp_ctx dlagp_ctx;     /* one sightline's model + data, resident in HBM    */
 typedef struct dlagp_batch dlagp_batch; /* a launch group of sightlines on one device       */
+typedef struct dlagp_model dlagp_model; /* the learned GP model (rest-frame grid), in HBM   */
 
 /* ABI version of this header; bumped on any signature change. */
 int dlagp_abi_version(void);
@@ -96,6 +97,39 @@ int dlagp_ctx_device(const dlagp_ctx *ctx);
  */
 int dlagp_eval(dlagp_ctx *ctx, int64_t S, int kd, const double *z, const double *nhi,
                double *out);
+
+/*
+ * The learned GP model on its rest-frame grid -- the arguments of NullGP.__init__
+ * (reference null_gp.py:35-71) -- uploaded once per device and shared by every spectrum.
+ *   rest_wavelengths, mu, log_omega : [n_grid]; M : [n_grid][k] with element strides as in dlagp_create
+ *   log_c_0, log_tau_0, log_beta    : Lyman-series noise model (null_gp.py:216-236)
+ *   prev_tau_0, prev_beta           : mean-flux suppression (null_gp.py:197-214)
+ *   num_forest_lines                : series members in the effective optical depth (set_parameters.py)
+ */
+int dlagp_model_create(dlagp_model **out, int n_grid, int k, const double *rest_wavelengths,
+                       const double *mu, const double *M, ptrdiff_t m_row_stride,
+                       ptrdiff_t m_col_stride, const double *log_omega, double log_c_0,
+                       double log_tau_0, double log_beta, double prev_tau_0, double prev_beta,
+                       int num_forest_lines, int device);
+void dlagp_model_destroy(dlagp_model *model);
+
+/*
+ * dlagp_create with NullGP.get_interp (reference null_gp.py:179-242, effective_optical_depth.py:10-80)
+ * done on the device: this_mu, this_M, this_omega2 are interpolated from `model` at the rest
+ * wavelengths x[n] of the kept pixels, suppressed by the Lyman-series mean flux at the observed
+ * wavelengths this_wavelengths[n] and z_qso, and never visit the host.  y, v: [n] flux and noise
+ * variance of the kept pixels (after NullGP.set_data's normalisation); wavelengths / keep /
+ * num_lines / broadening as in dlagp_create.  A rest wavelength outside the model grid returns
+ * DLAGP_EINVAL (scipy's interp1d raises ValueError there).  The context lives on the model's device.
+ */
+int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, int n_u,
+                            const double *x, const double *y, const double *v,
+                            const double *this_wavelengths, double z_qso,
+                            const double *wavelengths, const uint8_t *keep, int num_lines,
+                            int broadening);
+
+/* Copy a context's this_mu[n], this_M[n][k] (C order), this_omega2[n] back; any pointer may be NULL. */
+int dlagp_ctx_read_model(dlagp_ctx *ctx, double *this_mu, double *this_M, double *this_omega2);
 
 /* Null-model evidence: the same density with a = 1. */
 int dlagp_null(dlagp_ctx *ctx, double *out);

@@ -550,3 +550,32 @@ def test_device_sweep_stops_a_sightline_on_nan_evidence():
         batch.sweep(zs, nhi[0], 9, min_sep, np.zeros((2, 8, S)))     # max_dlas > DLAGP_MAX_ABSORBERS
     with pytest.raises(ValueError):
         batch.sweep(zs, nhi[0], 2, min_sep)                          # uniforms missing
+
+
+# ------------------------------------------------------------------------------------------------
+# f1: NullGP.get_interp on the device (dlagp_model_create / dlagp_create_from_model)
+# ------------------------------------------------------------------------------------------------
+def test_device_interpolation_matches_reference_golden():
+    """model interpolation, mean-flux suppression and noise scaling on the device vs reference set_data output"""
+    from gpy_dla_detection_amd.null_gp import NullGP
+    from gpy_dla_detection_amd.set_parameters import Parameters
+    from gpy_dla_detection_amd.sightline import DeviceModel, DeviceSightline
+    from tests.golden_inputs import raw_spectrum_and_model
+
+    g = load_golden("set_data.npz")
+    z_qso, rest, flux, nv, mask, rest_grid, mu, M, log_omega, lc0, lt0, lb = raw_spectrum_and_model()
+    params = Parameters()
+    host = NullGP(params, FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb)
+    host.set_data(rest, flux, nv, mask, z_qso, normalize=True, build_model=False)   # index logic only
+    model = DeviceModel(rest_grid, mu, np.asfortranarray(M), log_omega, lc0, lt0, lb,
+                        num_forest_lines=params.num_forest_lines)
+    dev = DeviceSightline.from_model(model, host.x, host.y, host.v, host.this_wavelengths, z_qso,
+                                     host.padded_wavelengths, ~host.pixel_mask[host.ind_unmasked])
+    this_mu, this_M, this_omega2 = dev.read_model()
+    np.testing.assert_allclose(this_mu, g["this_mu"], rtol=1e-14)
+    np.testing.assert_allclose(this_M, g["this_M"], rtol=1e-14, atol=1e-16)  # atol: interpolants crossing zero
+    np.testing.assert_allclose(this_omega2, g["this_omega2"], rtol=1e-14)
+    assert abs(dev.null() - g["null_evidence"]) <= RTOL_LL * abs(g["null_evidence"])
+    with pytest.raises(ValueError):   # scipy's interp1d refuses to extrapolate
+        DeviceSightline.from_model(model, host.x + 400.0, host.y, host.v, host.this_wavelengths, z_qso,
+                                   host.padded_wavelengths, ~host.pixel_mask[host.ind_unmasked])
