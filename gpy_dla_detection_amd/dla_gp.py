@@ -146,6 +146,24 @@ def occupation_sweep(level_log_likelihoods, sample_z: np.ndarray, sample_nhi: np
     return evidences, sample_log_likelihoods, base_sample_inds
 
 
+def map_traceback(sample_log_likelihoods: np.ndarray, base_sample_inds: np.ndarray, sample_z: np.ndarray,
+                  log_nhi: np.ndarray):
+    """
+    MAP (z_dla, log N_HI) of every occupation level: the best sample of the level and, through the
+    resampled base indices, the absorbers it was stacked on (reference dla_gp.py:428-472).
+    Shapes (max_dlas, max_dlas), NaN where unused.
+    """
+    best = np.nanargmax(sample_log_likelihoods, axis=0)
+    max_dlas = sample_log_likelihoods.shape[1]
+    MAP_z_dla = np.full((max_dlas, max_dlas), np.nan)
+    MAP_log_nhi = np.full((max_dlas, max_dlas), np.nan)
+    for level, top in enumerate(best):
+        members = np.concatenate([[top], base_sample_inds[:level, top]]).astype(int)
+        MAP_z_dla[level, : level + 1] = sample_z[members]
+        MAP_log_nhi[level, : level + 1] = log_nhi[members]
+    return MAP_z_dla, MAP_log_nhi
+
+
 class DLAGP(_AbsorberGP):
     """
     p(y | lambda, sigma^2, M, omega, c_0, tau_0, beta, tau_kim, beta_kim, {z_dla, log N_HI})
@@ -202,17 +220,8 @@ class DLAGP(_AbsorberGP):
         MAP (z_dla, log N_HI) of every occupation level, traced back through the resampled
         base indices (reference :428-472).  Shapes (max_dlas, max_dlas), NaN where unused.
         """
-        best = np.nanargmax(self.sample_log_likelihoods, axis=0)
-        max_dlas = self.sample_log_likelihoods.shape[1]
-        MAP_z_dla = np.full((max_dlas, max_dlas), np.nan)
-        MAP_log_nhi = np.full((max_dlas, max_dlas), np.nan)
-        sample_z = self._sample_redshifts()
-        log_nhi = self.dla_samples.log_nhi_samples
-        for level, top in enumerate(best):
-            members = np.concatenate([[top], self.base_sample_inds[:level, top]]).astype(int)
-            MAP_z_dla[level, : level + 1] = sample_z[members]
-            MAP_log_nhi[level, : level + 1] = log_nhi[members]
-        return MAP_z_dla, MAP_log_nhi
+        return map_traceback(self.sample_log_likelihoods, self.base_sample_inds, self._sample_redshifts(),
+                             self.dla_samples.log_nhi_samples)
 
     def run_mcmc(self, *args, **kwargs):
         raise NotImplementedError(

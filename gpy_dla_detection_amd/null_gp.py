@@ -18,6 +18,45 @@ from .set_parameters import Parameters
 from . import sightline as _sl
 
 
+def prepare_data(params: Parameters, X: np.ndarray, Y: np.ndarray, noise_variance: np.ndarray,
+                 pixel_mask: np.ndarray, z_qso: float, normalize: bool = True) -> dict:
+    """
+    The data half of `NullGP.set_data` (reference null_gp.py:117-177), model-free: normalisation,
+    wavelength cuts, masks and the padded grid of the instrument convolution.  Returns the
+    attributes `set_data` leaves on the instance, by name.
+    """
+    p = params
+    x, y, v = X, Y, noise_variance
+    out = {"pixel_mask": pixel_mask}
+    if normalize:
+        window = (x >= p.normalization_min_lambda) & (x <= p.normalization_max_lambda) & (~pixel_mask)
+        median = np.nanmedian(y[window])
+        y = y / median
+        v = v / median ** 2
+        out["normalization_median"] = median
+
+    in_range = (x >= p.min_lambda) & (x <= p.max_lambda)
+    observed = Parameters.observed_wavelengths(x, z_qso)
+    # complete, equally spaced grid for the absorption profile
+    unmasked_wavelengths = observed[in_range]
+    kept = in_range & (~pixel_mask)
+    out.update(
+        ind_unmasked=in_range, unmasked_wavelengths=unmasked_wavelengths, this_wavelengths=observed[kept],
+        x=x[kept], y=y[kept], v=v[kept], ind=kept,
+    )
+    # `width` extra log-spaced pixels on either side for the instrument convolution
+    lo = np.log10(unmasked_wavelengths.min())
+    hi = np.log10(np.max(unmasked_wavelengths))
+    out["padded_wavelengths"] = np.concatenate(
+        [
+            np.logspace(lo - p.width * p.pixel_spacing, lo - p.pixel_spacing, p.width),
+            unmasked_wavelengths,
+            np.logspace(hi + p.pixel_spacing, hi + p.width * p.pixel_spacing, p.width),
+        ]
+    )
+    return out
+
+
 class NullGP:
     """
     p(y | lambda, z_qso, v, omega, M) = N(y; mu a_lya, A_lya (M M' + Omega) A_lya + V)
@@ -102,44 +141,12 @@ class NullGP:
         :param z_qso: quasar redshift
         """
         self._invalidate_device()
-        p = self.params
-        self.x, self.y, self.v = X, Y, noise_variance
-        self.pixel_mask = pixel_mask
         self.z_qso = z_qso
-
-        if normalize:
-            window = (self.x >= p.normalization_min_lambda) & (self.x <= p.normalization_max_lambda) & (~pixel_mask)
-            median = np.nanmedian(self.y[window])
-            self.y = self.y / median
-            self.v = self.v / median ** 2
-            self.normalization_median = median
-
-        in_range = (self.x >= p.min_lambda) & (self.x <= p.max_lambda)
-        self.ind_unmasked = in_range
-        observed = Parameters.observed_wavelengths(self.x, z_qso)
-        # complete, equally spaced grid for the absorption profile
-        self.unmasked_wavelengths = observed[in_range]
-
-        kept = in_range & (~self.pixel_mask)
-        self.this_wavelengths = observed[kept]
-        self.x = self.x[kept]
-        self.y = self.y[kept]
-        self.v = self.v[kept]
-        self.ind = kept
-
+        state = prepare_data(self.params, X, Y, noise_variance, pixel_mask, z_qso, normalize)
+        for name, value in state.items():
+            setattr(self, name, value)
         if build_model:
             self.get_interp(self.x, self.y, self.this_wavelengths, self.z_qso)
-
-        # `width` extra log-spaced pixels on either side for the instrument convolution
-        lo = np.log10(self.unmasked_wavelengths.min())
-        hi = np.log10(np.max(self.unmasked_wavelengths))
-        self.padded_wavelengths = np.concatenate(
-            [
-                np.logspace(lo - p.width * p.pixel_spacing, lo - p.pixel_spacing, p.width),
-                self.unmasked_wavelengths,
-                np.logspace(hi + p.pixel_spacing, hi + p.width * p.pixel_spacing, p.width),
-            ]
-        )
 
     def get_interp(self, x: np.ndarray, y: np.ndarray, wavelengths: np.ndarray, z_qso: float) -> None:
         """

@@ -1,0 +1,244 @@
+"""
+Catalogue driver: Bayesian model selection [null, sub-DLA, DLA(1..max_dlas)] for a list of spectra.
+
+Same job and same outputs as the reference driver `run_bayes_select.process_qso`
+(run_bayes_select.py:30-295): every array it writes to `processed_qsos_multi_meanflux.h5`
+comes back under the same dataset name and shape.  What differs is the execution:
+
+  * the reference loops over spectra and, per spectrum, builds three GP objects, calls `set_data` on
+    each and sweeps 1 + S + max_dlas * S samples in Python (:141-245);
+  * here the data half of `set_data` runs once per spectrum on the host (`null_gp.prepare_data`),
+    the model half (`get_interp`) on the device (`dlagp_create_from_model`), and a batch of
+    spectra is swept level by level with everything resident in HBM (`dlagp_batch_sweep`).
+    The resampling consumes the global RNG exactly as the reference does after `np.random.seed(0)`
+    per spectrum (:144), so `base_sample_inds` are the reference's.
+
+Spectra arrive as arrays -- reading SDSS FITS files (`read_spec`, :147) is outside this package.
+Multi-GPU: `rank` / `world_size` shard the catalogue in contiguous blocks (one process per GPU);
+every rank returns the full arrays after one all-gather per output (`parallel.gather_rows`).
+"""
+from collections import namedtuple
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+from scipy.special import logsumexp
+
+from . import parallel
+from .dla_gp import map_traceback
+from .null_gp import prepare_data
+from .set_parameters import Parameters
+
+LearnedModel = namedtuple(
+    "LearnedModel",
+    "rest_wavelengths mu M log_omega log_c_0 log_tau_0 log_beta prev_tau_0 prev_beta",
+    defaults=(0.0023, 3.65),
+)
+
+# datasets of processed_qsos_multi_meanflux.h5 that hold one row per quasar (run_bayes_select.py:270-291)
+PER_QUASAR = (
+    "min_z_dlas", "max_z_dlas", "sample_log_likelihoods_dla", "base_sample_inds",
+    "log_priors_no_dla", "log_priors_lls", "log_priors_dla",
+    "log_likelihoods_no_dla", "log_likelihoods_lls", "log_likelihoods_dla",
+    "log_posteriors_no_dla", "log_posteriors_lls", "log_posteriors_dla",
+    "sample_log_likelihoods_lls", "MAP_z_dlas", "MAP_log_nhis", "p_dlas", "p_no_dlas", "model_posteriors",
+)
+
+
+def occupation_log_priors(prior, z_qso: float, max_dlas: int, dla_samples, subdla_samples) -> np.ndarray:
+    """
+    log priors [null, sub-DLA, DLA(1..max_dlas)] exactly as `BayesModelSelect.model_selection` assembles
+    them (bayesian_model_selection.py:68-80 with dla_gp.py:398-426 and subdla_gp.py:311-346).
+    """
+    num_dlas, num_quasars = prior.less_ind(z_qso)
+    ratio = num_dlas / num_quasars
+    at_least = ratio ** np.arange(1, max_dlas + 1)
+    at_least[:-1] = at_least[:-1] - at_least[1:]
+    z_lls = getattr(subdla_samples, "_Z_lls", None)
+    z_dla = getattr(subdla_samples, "_Z_dla", None)
+    if z_lls is None:
+        z_lls, z_dla = subdla_samples.Z_lls, subdla_samples.Z_dla
+    sub = z_lls / z_dla * ratio ** np.arange(1, 2)
+    log_priors = np.concatenate([[np.nan], np.log(sub), np.log(at_least)])
+    log_priors[0] = np.log(1 - np.exp(logsumexp(log_priors[1:])))
+    return log_priors
+
+
+def _empty_results(num: int, S: int, max_dlas: int) -> Dict[str, np.ndarray]:
+    nan = lambda *shape: np.full(shape, np.nan)  # noqa: E731
+    return dict(
+        min_z_dlas=nan(num), max_z_dlas=nan(num),
+        log_priors_no_dla=nan(num), log_priors_dla=nan(num, max_dlas), log_priors_lls=nan(num),
+        log_likelihoods_no_dla=nan(num), log_likelihoods_dla=nan(num, max_dlas), log_likelihoods_lls=nan(num),
+        log_posteriors_no_dla=nan(num), log_posteriors_dla=nan(num, max_dlas), log_posteriors_lls=nan(num),
+        sample_log_likelihoods_dla=nan(num, S, max_dlas),
+        base_sample_inds=np.zeros((num, S, max_dlas - 1), dtype=np.int32),
+        sample_log_likelihoods_lls=nan(num, S),
+        MAP_z_dlas=nan(num, max_dlas, max_dlas), MAP_log_nhis=nan(num, max_dlas, max_dlas),
+        model_posteriors=nan(num, 2 + max_dlas), p_dlas=nan(num), p_no_dlas=nan(num),
+    )
+
+
+class DeviceEngine:
+    """
+    The GPU back end of `process_qso`: learned model in HBM (`DeviceModel`), one context per spectrum
+    built by `dlagp_create_from_model`, batches swept by `dlagp_batch_sweep`.  Any object with the same
+    four methods can stand in (the CPU tests drive the oracle through this seam).
+    """
+
+    def __init__(self, learned: LearnedModel, params: Parameters, device: int = 0):
+        from .sightline import DeviceModel
+
+        self.params = params
+        self.model = DeviceModel(*learned[:7], prev_tau_0=learned.prev_tau_0, prev_beta=learned.prev_beta,
+                                 num_forest_lines=params.num_forest_lines, device=device)
+
+    def sightline(self, state: dict, z_qso: float, broadening: bool):
+        """post-`prepare_data` state of one spectrum -> resident sightline (get_interp happens here)"""
+        from .sightline import DeviceSightline
+
+        keep = ~state["pixel_mask"][state["ind_unmasked"]]  # dla_gp.py:360
+        grid = state["padded_wavelengths"] if broadening else state["unmasked_wavelengths"]
+        return DeviceSightline.from_model(
+            self.model, state["x"], state["y"], state["v"], state["this_wavelengths"], z_qso, grid, keep,
+            num_lines=self.params.num_lines, broadening=broadening)
+
+    def batch(self, sightlines):
+        from .sightline import DeviceBatch
+
+        return DeviceBatch(sightlines)
+
+    def nulls(self, sightlines) -> np.ndarray:
+        return np.array([s.null() for s in sightlines])
+
+    def sweep(self, batch, sample_z, sample_nhi, max_dlas, min_z_separation, seed):
+        return parallel.sweep_batch_device(batch, sample_z, sample_nhi, max_dlas, min_z_separation, seed)
+
+    def release(self, batch, sightlines) -> None:
+        batch.close()
+        for s in sightlines:
+            s.close()
+
+    def close(self) -> None:
+        self.model.close()
+
+
+def process_qso(
+    spectra: Sequence[Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]],
+    z_qso_list: Sequence[float],
+    params: Parameters,
+    prior,
+    dla_samples,
+    subdla_samples,
+    learned: LearnedModel,
+    max_dlas: int = 4,
+    broadening: bool = True,
+    min_z_separation: float = 3000.0,
+    device: int = 0,
+    batch_size: int = 32,
+    seed: Optional[int] = 0,
+    rank: int = 0,
+    world_size: int = 1,
+    group=None,
+    qso_list: Optional[Sequence[str]] = None,
+    engine=None,
+) -> Dict[str, np.ndarray]:
+    """
+    :param spectra: per quasar (observed wavelengths, flux, noise_variance, pixel_mask) -- what the
+        reference's `read_spec(filename)` returns (run_bayes_select.py:147)
+    :param learned: the learned GP model (`LearnedModel`; the reference loads it from a .mat file per spectrum)
+    :param dla_samples, subdla_samples: QMC sample holders (`samples.DLASamples` / `SubDLASamples` or the *MAT loaders)
+    :param engine: back end (default `DeviceEngine(learned, params, device)`)
+    :param seed: the reference re-seeds the global RNG with 0 before every spectrum (:144)
+    :return: dict keyed by the dataset names of processed_qsos_multi_meanflux.h5 (:248-295)
+    """
+    learned = LearnedModel(*learned)
+    num = len(spectra)
+    assert len(z_qso_list) == num
+    S = params.num_dla_samples
+    lo, hi = parallel.shard_range(num, world_size, rank)
+    local = _empty_results(hi - lo, S, max_dlas)
+    min_sep = params.kms_to_z(min_z_separation)
+
+    own_engine = engine is None and hi > lo
+    if own_engine:
+        engine = DeviceEngine(learned, params, device)
+    nhi_dla = np.asarray(dla_samples.nhi_samples, dtype=np.float64)
+    nhi_sub = np.asarray(subdla_samples.nhi_samples, dtype=np.float64)
+
+    for start in range(lo, hi, batch_size):
+        stop = min(start + batch_size, hi)
+        sightlines, z_dla, z_lls = [], [], []
+        for q in range(start, stop):
+            wavelengths, flux, noise_variance, pixel_mask = spectra[q]
+            z_qso = z_qso_list[q]
+            rest_wavelengths = params.emitted_wavelengths(wavelengths, z_qso)
+            st = prepare_data(params, rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, normalize=True)
+            sightlines.append(engine.sightline(st, z_qso, broadening))
+            z_dla.append(dla_samples.sample_z_dlas(st["this_wavelengths"], z_qso))
+            z_lls.append(subdla_samples.sample_z_lls(st["this_wavelengths"], z_qso))
+            local["min_z_dlas"][q - lo] = params.min_z_dla(wavelengths, z_qso)
+            local["max_z_dlas"][q - lo] = params.max_z_dla(wavelengths, z_qso)
+        batch = engine.batch(sightlines)
+        z_dla, z_lls = np.stack(z_dla), np.stack(z_lls)
+        nulls = engine.nulls(sightlines)
+        # the sub-DLA model is swept before the DLA model (model list order, run_bayes_select.py:189);
+        # with max_dlas = 1 it draws nothing from the RNG, so the DLA sweep sees the freshly seeded stream
+        ev_sub, ll_sub, _ = engine.sweep(batch, z_lls, nhi_sub, 1, min_sep, seed)
+        ev_dla, ll_dla, base = engine.sweep(batch, z_dla, nhi_dla, max_dlas, min_sep, seed)
+
+        for b, q in enumerate(range(start, stop)):
+            i = q - lo
+            log_priors = occupation_log_priors(prior, z_qso_list[q], max_dlas, dla_samples, subdla_samples)
+            log_likelihoods = np.concatenate([[nulls[b]], ev_sub[b], ev_dla[b]])
+            log_posteriors = log_likelihoods + log_priors
+            for name, values in (("log_priors", log_priors), ("log_likelihoods", log_likelihoods),
+                                 ("log_posteriors", log_posteriors)):
+                local[name + "_no_dla"][i] = values[0]
+                local[name + "_lls"][i] = values[1]
+                local[name + "_dla"][i] = values[-max_dlas:]
+            local["sample_log_likelihoods_dla"][i] = ll_dla[b]
+            local["base_sample_inds"][i] = base[b].T
+            local["sample_log_likelihoods_lls"][i] = ll_sub[b][:, 0]
+            local["MAP_z_dlas"][i], local["MAP_log_nhis"][i] = map_traceback(
+                ll_dla[b], base[b], z_dla[b], dla_samples.log_nhi_samples)
+            posteriors = np.exp(log_posteriors - logsumexp(log_posteriors))
+            local["model_posteriors"][i] = posteriors
+            local["p_dlas"][i] = np.sum(posteriors[-max_dlas:])
+            local["p_no_dlas"][i] = 1 - local["p_dlas"][i]
+        engine.release(batch, sightlines)
+    if own_engine:
+        engine.close()
+
+    results = {}
+    for name in PER_QUASAR:
+        rows = local[name].reshape(hi - lo, int(np.prod(local[name].shape[1:])))
+        full = parallel.gather_rows(rows, num, group=group) if world_size > 1 else rows.astype(np.float64)
+        results[name] = full.reshape((num,) + local[name].shape[1:]).astype(local[name].dtype)
+    # model settings and bookkeeping the reference stores next to the results (:250-268, :293-295)
+    for name in ("prior_z_qso_increase", "k", "normalization_min_lambda", "normalization_max_lambda",
+                 "min_z_cut", "max_z_cut", "num_dla_samples", "num_lines", "num_forest_lines"):
+        results[name] = np.asarray(getattr(params, name))
+    results["z_qsos"] = np.array(z_qso_list)
+    if qso_list is not None:
+        results["qso_list"] = np.array(list(qso_list))
+    return results
+
+
+def write_results(results: Dict[str, np.ndarray], filename: str = "processed_qsos_multi_meanflux.h5") -> str:
+    """
+    Write `process_qso`'s output under the reference's dataset names (run_bayes_select.py:248-295):
+    HDF5 when h5py is installed, otherwise the same names in a NumPy .npz next to it.
+    """
+    try:
+        import h5py
+    except ImportError:
+        target = filename[:-3] + ".npz" if filename.endswith(".h5") else filename + ".npz"
+        np.savez_compressed(target, **results)
+        return target
+    with h5py.File(filename, "w") as f:
+        for name, value in results.items():
+            if name == "qso_list":
+                f.create_dataset(name, data=np.array(value, h5py.string_dtype(encoding="utf-8")))
+            else:
+                f.create_dataset(name, data=value)
+    return filename

@@ -42,3 +42,28 @@ def raw_spectrum_and_model(seed=5, k=20):
     M = 0.1 * rng.standard_normal((rest_grid.shape[0], k)) * (0.9 ** np.arange(k))[None, :]
     log_omega = -2.0 + 0.3 * np.sin(rest_grid / 55.0)
     return z_qso, rest, flux, noise_variance, pixel_mask, rest_grid, mu, M, log_omega, -2.3, -5.9, 1.2
+
+
+def raw_catalogue(num=3, k=20):
+    """
+    A small synthetic catalogue for golden set G8: the learned model of `raw_spectrum_and_model`
+    and `num` raw spectra (observed wavelengths, flux, noise variance, pixel mask) at different
+    quasar redshifts, the later ones with one or two damped troughs pressed into the forest.
+    """
+    _, _, _, _, _, rest_grid, mu, M, log_omega, lc0, lt0, lb = raw_spectrum_and_model(seed=5, k=k)
+    spectra, z_qsos = [], []
+    obs = 10.0 ** (3.5600 + 1e-4 * np.arange(4400))
+    for i in range(num):
+        rng = np.random.default_rng(100 + i)
+        z_qso = 2.6 + 0.25 * i
+        rest = obs / (1 + z_qso)
+        flux = 3.0 + 0.5 * np.sin(rest / 40.0)
+        for j in range(i):  # i troughs: Lorentzian optical depth around an absorber redshift
+            centre = 1215.6701 * (1 + z_qso - 0.35 - 0.3 * j)
+            flux = flux * np.exp(-40.0 * (1 + j) / (1.0 + ((obs - centre) / 3.0) ** 2))
+        flux = flux + 0.2 * rng.standard_normal(obs.shape[0])
+        noise_variance = 0.04 * (1 + rng.random(obs.shape[0]))
+        pixel_mask = rng.random(obs.shape[0]) < 0.03
+        spectra.append((obs.copy(), flux, noise_variance, pixel_mask))
+        z_qsos.append(z_qso)
+    return (rest_grid, mu, M, log_omega, lc0, lt0, lb), spectra, z_qsos

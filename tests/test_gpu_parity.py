@@ -579,3 +579,17 @@ def test_device_interpolation_matches_reference_golden():
     with pytest.raises(ValueError):   # scipy's interp1d refuses to extrapolate
         DeviceSightline.from_model(model, host.x + 400.0, host.y, host.v, host.this_wavelengths, z_qso,
                                    host.padded_wavelengths, ~host.pixel_mask[host.ind_unmasked])
+
+
+# ------------------------------------------------------------------------------------------------
+# f3: the catalogue driver end to end on the device vs the reference's own loop body (G8)
+# ------------------------------------------------------------------------------------------------
+def test_process_qso_on_device_matches_reference_driver_golden():
+    from gpy_dla_detection_amd.run_bayes_select import process_qso
+    from tests.test_host_logic import FixedPrior as Prior, assert_catalogue_matches_golden, catalogue_inputs
+
+    g = load_golden("catalogue.npz")
+    learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(int(g["S"]))
+    results = process_qso(spectra, z_qsos, params, Prior(), dla_samples, sub_samples, learned,
+                          max_dlas=int(g["max_dlas"]), batch_size=2)
+    assert_catalogue_matches_golden(results, g, rtol=RTOL_LL)

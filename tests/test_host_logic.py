@@ -130,6 +130,14 @@ sights = [make_sightline(i, n_unmasked=120 + 4 * i, n_masked=2) for i in range(5
 out = parallel.model_evidences_sharded(sights, num_samples=24, max_dlas=2, rank=rank, world_size=world,
                                        make_batch=lambda s, device: OracleBatch(s))
 np.save(os.path.join(os.environ["DLAGP_OUT"], "rank%d.npy" % rank), out)
+
+# the catalogue driver, 3 spectra over 2 ranks (2 + 1), every output all-gathered
+from gpy_dla_detection_amd.run_bayes_select import process_qso
+from tests.test_host_logic import FixedPrior, OracleEngine, catalogue_inputs
+learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(96)
+res = process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=3,
+                  rank=rank, world_size=world, engine=OracleEngine(learned, params))
+np.savez(os.path.join(os.environ["DLAGP_OUT"], "catalogue_rank%d.npz" % rank), **res)
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -173,3 +181,110 @@ def test_sharded_evidences_gloo_world_size_2(tmp_path):
                                             make_batch=lambda s, device: OracleBatch(s))
     assert want.shape == (5, 4) and np.all(np.isfinite(want))
     np.testing.assert_array_equal(got0, want)
+    # catalogue driver: both ranks hold the complete result arrays, equal to the reference's
+    g = load_golden("catalogue.npz")
+    cat0, cat1 = (np.load(tmp_path / ("catalogue_rank%d.npz" % r)) for r in (0, 1))
+    for name in cat0.files:
+        np.testing.assert_array_equal(cat0[name], cat1[name], err_msg=name)
+    assert_catalogue_matches_golden(cat0, g, rtol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------
+# catalogue driver (f3): run_bayes_select.process_qso against the reference's own loop body (G8)
+# ------------------------------------------------------------------------------------------------
+class OracleEngine:
+    """
+    `process_qso` back end for the CPU tests: host `get_interp` of this package + the oracle as
+    the evaluator + the host half of every level (`parallel.sweep_batch`).  Checks the driver's
+    bookkeeping -- priors, posteriors, MAP, array layout, sharding -- without a GPU.
+    """
+
+    def __init__(self, learned, params):
+        from gpy_dla_detection_amd.null_gp import NullGP
+
+        self.gp = NullGP(params, None, *learned[:7])
+        self.params = params
+
+    def sightline(self, state, z_qso, broadening):
+        from oracle import ref_like
+
+        self.gp.get_interp(state["x"], state["y"], state["this_wavelengths"], z_qso)
+        return ref_like.SpectrumState(
+            y=state["y"], v=state["v"], this_mu=self.gp.this_mu, this_M=self.gp.this_M,
+            this_omega2=self.gp.this_omega2, padded_wavelengths=state["padded_wavelengths"],
+            unmasked_wavelengths=state["unmasked_wavelengths"],
+            keep=~state["pixel_mask"][state["ind_unmasked"]], num_lines=self.params.num_lines, broadening=broadening)
+
+    def batch(self, sightlines):
+        batch = OracleBatch([])
+        batch.states = list(sightlines)
+        return batch
+
+    def nulls(self, sightlines):
+        from oracle import ref_like
+
+        return np.array([ref_like.null_log_model_evidence(st) for st in sightlines])
+
+    def sweep(self, batch, sample_z, sample_nhi, max_dlas, min_z_separation, seed):
+        return parallel.sweep_batch(batch.eval, sample_z, sample_nhi, max_dlas, min_z_separation, seed)
+
+    def release(self, batch, sightlines):
+        pass
+
+    def close(self):
+        pass
+
+
+def catalogue_inputs(S):
+    from gpy_dla_detection_amd.run_bayes_select import LearnedModel
+    from gpy_dla_detection_amd.samples import DLASamples, SubDLASamples
+    from tests.golden_inputs import raw_catalogue
+
+    learned, spectra, z_qsos = raw_catalogue()
+    params = Parameters(num_dla_samples=S)
+    u = halton(S, 3)
+    dla_samples = DLASamples(params, None, halton(S, 2), 20.0 + 3.0 * u)
+    sub_samples = SubDLASamples(params, None, halton(S, 2), 19.5 + 0.5 * u, Z_dla=1.0, Z_lls=0.25)
+    return LearnedModel(*learned), spectra, z_qsos, params, dla_samples, sub_samples
+
+
+def assert_catalogue_matches_golden(results, g, rtol):
+    S, max_dlas = int(g["S"]), int(g["max_dlas"])
+    assert results["sample_log_likelihoods_dla"].shape == (3, S, max_dlas)
+    assert results["base_sample_inds"].shape == (3, S, max_dlas - 1) and results["base_sample_inds"].dtype == np.int32
+    np.testing.assert_array_equal(results["base_sample_inds"], g["base_sample_inds"])
+    for name in ("min_z_dlas", "max_z_dlas", "log_priors_no_dla", "log_priors_lls", "log_priors_dla", "z_qsos"):
+        np.testing.assert_allclose(results[name], g[name], rtol=1e-13, err_msg=name)
+    for name in ("log_likelihoods_no_dla", "log_likelihoods_lls", "log_likelihoods_dla", "log_posteriors_no_dla",
+                 "log_posteriors_lls", "log_posteriors_dla", "sample_log_likelihoods_dla",
+                 "sample_log_likelihoods_lls"):
+        assert np.array_equal(np.isnan(results[name]), np.isnan(g[name])), name
+        np.testing.assert_allclose(results[name], g[name], rtol=rtol, equal_nan=True, err_msg=name)
+    np.testing.assert_allclose(results["MAP_z_dlas"], g["MAP_z_dlas"], rtol=1e-13, equal_nan=True)
+    np.testing.assert_allclose(results["MAP_log_nhis"], g["MAP_log_nhis"], rtol=1e-13, equal_nan=True)
+    np.testing.assert_allclose(results["model_posteriors"], g["model_posteriors"], rtol=1e-6, atol=1e-280)
+    np.testing.assert_allclose(results["p_dlas"], g["p_dlas"], rtol=1e-6, atol=1e-280)
+    np.testing.assert_allclose(results["p_no_dlas"], g["p_no_dlas"], rtol=1e-6, atol=1e-12)
+    assert np.array_equal(np.argmax(results["model_posteriors"], axis=1), np.argmax(g["model_posteriors"], axis=1))
+    assert int(results["num_dla_samples"]) == S and int(results["k"]) == 20
+
+
+def test_process_qso_matches_reference_driver_golden(tmp_path):
+    from gpy_dla_detection_amd.run_bayes_select import process_qso, write_results
+    from tests.golden_inputs import checksum as crc
+
+    g = load_golden("catalogue.npz")
+    learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(int(g["S"]))
+    assert crc(*[a for spec in spectra for a in spec[:3]]) == int(g["input_crc"])
+    np.random.seed(123)
+    before = np.random.get_state()[1].copy()
+    results = process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned,
+                          max_dlas=int(g["max_dlas"]), batch_size=2, engine=OracleEngine(learned, params),
+                          qso_list=["spec-%d" % i for i in range(3)])
+    assert np.array_equal(np.random.get_state()[1], before)
+    assert_catalogue_matches_golden(results, g, rtol=1e-10)
+    path = write_results(results, str(tmp_path / "processed_qsos_multi_meanflux.h5"))
+    if path.endswith(".npz"):
+        back = np.load(path)
+        np.testing.assert_array_equal(back["base_sample_inds"], results["base_sample_inds"])
+        assert list(back["qso_list"]) == ["spec-0", "spec-1", "spec-2"]

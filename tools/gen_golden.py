@@ -19,6 +19,8 @@ Fixtures (all float64):
   G5 evidences_*.npz       DLAGP.log_model_evidences(4) / SubDLAGP.log_model_evidences(1), seed 0
   G6 model_selection.npz   BayesModelSelect([0,1,4],2).model_selection with a fixed prior
   G7 set_data.npz          NullGP.set_data/get_interp on a synthetic raw spectrum + learned model
+  G8 catalogue.npz         the per-spectrum body of run_bayes_select.process_qso on three raw spectra:
+                           every array the reference writes to processed_qsos_multi_meanflux.h5
 """
 import os
 import sys
@@ -43,7 +45,7 @@ from gpy_dla_detection import voigt as ref_voigt  # noqa: E402
 
 from gpy_dla_detection_amd.synthetic import make_sightline, make_qmc_samples  # noqa: E402
 from gpy_dla_detection_amd.samples import halton  # noqa: E402
-from tests.golden_inputs import checksum, mvnpdf_inputs, raw_spectrum_and_model, MVNPDF_SHAPES  # noqa: E402
+from tests.golden_inputs import checksum, mvnpdf_inputs, raw_catalogue, raw_spectrum_and_model, MVNPDF_SHAPES  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 
@@ -295,11 +297,71 @@ def g7_set_data():
     )
 
 
+def g8_catalogue():
+    """
+    The loop body of the reference driver (run_bayes_select.py:141-245) with the reference's classes,
+    on raw_catalogue(): read_spec is replaced by the synthetic spectra, the *.mat loaders by arrays.
+    """
+    S, max_dlas = 96, 3
+    learned, spectra, z_qsos = raw_catalogue()
+    params = RefParameters(num_dla_samples=S)
+    prior = FixedPrior()
+    off, u = halton(S, 2), halton(S, 3)
+    dla_samples = ArraySamples(params, off, 20.0 + 3.0 * u)
+    sub_samples = ArraySamples(params, off, 19.5 + 0.5 * u)
+    bayes = RefBayes([0, 1, max_dlas], 2)
+    N = len(spectra)
+    out = dict(
+        min_z_dlas=np.full(N, np.nan), max_z_dlas=np.full(N, np.nan),
+        log_priors_no_dla=np.full(N, np.nan), log_priors_dla=np.full((N, max_dlas), np.nan),
+        log_likelihoods_no_dla=np.full(N, np.nan), log_likelihoods_dla=np.full((N, max_dlas), np.nan),
+        log_posteriors_no_dla=np.full(N, np.nan), log_posteriors_dla=np.full((N, max_dlas), np.nan),
+        sample_log_likelihoods_dla=np.full((N, S, max_dlas), np.nan),
+        base_sample_inds=np.zeros((N, S, max_dlas - 1), dtype=np.int32),
+        log_likelihoods_lls=np.full(N, np.nan), log_posteriors_lls=np.full(N, np.nan),
+        log_priors_lls=np.full(N, np.nan), sample_log_likelihoods_lls=np.full((N, S), np.nan),
+        MAP_z_dlas=np.full((N, max_dlas, max_dlas), np.nan), MAP_log_nhis=np.full((N, max_dlas, max_dlas), np.nan),
+        model_posteriors=np.full((N, 2 + max_dlas), np.nan), p_dlas=np.full(N, np.nan), p_no_dlas=np.full(N, np.nan),
+    )
+    for q, ((wavelengths, flux, noise_variance, pixel_mask), z_qso) in enumerate(zip(spectra, z_qsos)):
+        np.random.seed(0)
+        rest_wavelengths = params.emitted_wavelengths(wavelengths, z_qso)
+        gp = RefNullGP(params, prior, *learned)
+        gp.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
+        dla_gp = RefDLAGP(params, prior, dla_samples, *learned, min_z_separation=3000.0, broadening=True)
+        dla_gp.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
+        sub_gp = RefSubDLAGP(params, prior, sub_samples, *learned, min_z_separation=3000.0, broadening=True)
+        sub_gp.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
+        bayes.model_selection([gp, sub_gp, dla_gp], z_qso)
+        out["min_z_dlas"][q] = params.min_z_dla(wavelengths, z_qso)
+        out["max_z_dlas"][q] = params.max_z_dla(wavelengths, z_qso)
+        out["log_priors_no_dla"][q] = bayes.log_priors[0]
+        out["log_priors_dla"][q] = bayes.log_priors[-max_dlas:]
+        out["log_priors_lls"][q] = bayes.log_priors[1]
+        out["log_likelihoods_no_dla"][q] = bayes.log_likelihoods[0]
+        out["log_likelihoods_dla"][q] = bayes.log_likelihoods[-max_dlas:]
+        out["log_likelihoods_lls"][q] = bayes.log_likelihoods[1]
+        out["log_posteriors_no_dla"][q] = bayes.log_posteriors[0]
+        out["log_posteriors_dla"][q] = bayes.log_posteriors[-max_dlas:]
+        out["log_posteriors_lls"][q] = bayes.log_posteriors[1]
+        out["sample_log_likelihoods_dla"][q] = dla_gp.sample_log_likelihoods
+        out["base_sample_inds"][q] = dla_gp.base_sample_inds.T
+        out["sample_log_likelihoods_lls"][q] = sub_gp.sample_log_likelihoods[:, 0]
+        out["MAP_z_dlas"][q], out["MAP_log_nhis"][q] = dla_gp.maximum_a_posteriori()
+        out["model_posteriors"][q] = bayes.model_posteriors
+        out["p_dlas"][q] = bayes.p_dla
+        out["p_no_dlas"][q] = bayes.p_no_dla
+    out["z_qsos"] = np.array(z_qsos)
+    out["S"], out["max_dlas"] = S, max_dlas
+    out["input_crc"] = checksum(*[a for spec in spectra for a in spec[:3]])
+    np.savez_compressed(os.path.join(OUT, "catalogue.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     table = dict(g1=g1_voigt_profile, g2=g2_voigt_absorption, g3=g3_mvnpdf, g4=g4_sample_ll,
-                 g5=g5_evidences, g6=g6_model_selection, g7=g7_set_data)
+                 g5=g5_evidences, g6=g6_model_selection, g7=g7_set_data, g8=g8_catalogue)
     for name in which:
         print("generating", name, flush=True)
         table[name]()

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""
+End-to-end catalogue throughput on one GPU: raw spectra -> run_bayes_select.process_qso ->
+the reference's output arrays.  Synthetic SDSS-like spectra (4600 pixels at 1e-4 dex, z_qso in
+[2.2, 3.4], n ~ 1000-1250 pixels in the modelled range -- the size of real DR12Q sightlines),
+S = 10 000 QMC samples, max_dlas = 4.  Prints one JSON object with spectra/s and a phase split.
+"""
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np
+import torch
+
+torch.cuda.init()
+from gpy_dla_detection_amd.run_bayes_select import LearnedModel, process_qso  # noqa: E402
+from gpy_dla_detection_amd.samples import DLASamples, SubDLASamples, halton  # noqa: E402
+from gpy_dla_detection_amd.set_parameters import Parameters  # noqa: E402
+
+
+class FixedPrior:
+    def less_ind(self, z_qso):
+        return 731.0, 9265.0
+
+
+def make_inputs(num, k=20, seed=7):
+    rng = np.random.default_rng(seed)
+    rest_grid = np.arange(911.75, 1215.75 + 1e-9, 0.25)
+    mu = 1 + 0.2 * np.cos(rest_grid / 30.0)
+    M = 0.1 * rng.standard_normal((rest_grid.shape[0], k)) * (0.9 ** np.arange(k))[None, :]
+    log_omega = -2.0 + 0.3 * np.sin(rest_grid / 55.0)
+    learned = LearnedModel(rest_grid, mu, M, log_omega, -2.3, -5.9, 1.2)
+    obs = 10.0 ** (3.5600 + 1e-4 * np.arange(4600))
+    spectra, z_qsos = [], []
+    for i in range(num):
+        z_qso = 2.2 + 1.2 * rng.random()
+        rest = obs / (1 + z_qso)
+        flux = 3.0 + 0.5 * np.sin(rest / 40.0)
+        if i % 3:
+            centre = 1215.6701 * (1 + z_qso - 0.3)
+            flux = flux * np.exp(-50.0 / (1.0 + ((obs - centre) / 3.0) ** 2))
+        flux = flux + 0.2 * rng.standard_normal(obs.shape[0])
+        spectra.append((obs, flux, 0.04 * (1 + rng.random(obs.shape[0])), rng.random(obs.shape[0]) < 0.03))
+        z_qsos.append(z_qso)
+    return learned, spectra, z_qsos
+
+
+def main():
+    num = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+    batch_size = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    params = Parameters(num_dla_samples=S)
+    u = halton(S, 3)
+    dla = DLASamples(params, None, halton(S, 2), 20.0 + 3.0 * u)
+    sub = SubDLASamples(params, None, halton(S, 2), 19.5 + 0.5 * u, Z_dla=1.0, Z_lls=0.25)
+    learned, spectra, z_qsos = make_inputs(num)
+    process_qso(spectra[:batch_size], z_qsos[:batch_size], params, FixedPrior(), dla, sub, learned, batch_size=batch_size)
+    t0 = time.perf_counter()
+    res = process_qso(spectra, z_qsos, params, FixedPrior(), dla, sub, learned, batch_size=batch_size)
+    t = time.perf_counter() - t0
+    out = {
+        "spectra": num, "S": S, "max_dlas": 4, "batch_size": batch_size, "seconds": t,
+        "spectra_per_s": num / t, "evals_per_s": num * (1 + 5 * S) / t,
+        "argmax_counts": np.bincount(np.argmax(res["model_posteriors"], axis=1), minlength=6).tolist(),
+    }
+    if os.environ.get("DLAGP_PROFILE"):
+        import cProfile
+        import pstats
+
+        pr = cProfile.Profile()
+        pr.enable()
+        process_qso(spectra, z_qsos, params, FixedPrior(), dla, sub, learned, batch_size=batch_size)
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumtime").print_stats(25)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
