@@ -54,6 +54,18 @@ struct SampleSource {
     int indexed;       // 0 = direct
     long nhi_stride;   // 0 when all sightlines share one column-density table, else S
     int base_levels;   // rows of `base` per sightline (max_dlas - 1)
+    // Profile cache of a multi-level sweep (indexed mode, MFMA path).  Every absorber of every level is
+    // one of the sightline's S QMC points, and sample s of level l stacks point base[l-1][s] on the
+    // absorbers sample s had at level l-1 (reference dla_gp.py:135-150).  So level 1 keeps the convolved
+    // absorption of every point on the kept pixels, cache[(b S + p) cache_stride + pixel] (cache_mode 1),
+    // and level l > 1 forms  running[s] = running[s] * cache[base[l-1][s]]  (cache_mode 2; at level 2 the
+    // running product is read from the cache itself) instead of evaluating Voigt profiles, writing the
+    // product back for the next level (cache_write).  2 x 240 MB per sightline at S = 10 000, n = 3000.
+    double *cache;
+    double *running;
+    long cache_stride;
+    int cache_mode;    // 0 off, 1 store level-1 profiles, 2 multiply cached rows
+    int cache_write;   // mode 2: write the running product back (not needed at the last level)
 };
 
 #if defined(__HIPCC__)

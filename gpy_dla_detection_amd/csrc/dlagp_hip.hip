@@ -54,7 +54,9 @@ static int fail(int code, const char *fmt, ...) {
 static int64_t g_opt_pixel_splits = 0;
 static int64_t g_opt_path = 0;
 static int64_t g_opt_timing = 0;
-static int64_t g_opt_debug = 0;  // bit 1: stamped instantiation of the MFMA kernel (diagnostics)
+static int64_t g_opt_debug = 0;
+static int64_t g_opt_profile_cache = 1;  // multi-level sweeps keep level-1 profiles in HBM (0 = recompute)
+static int64_t g_opt_profile_cache_max_mb = 98304;  // never take more than this for the cache  // bit 1: stamped instantiation of the MFMA kernel (diagnostics)
 
 struct EventPair {
     hipEvent_t start, stop;
@@ -138,7 +140,10 @@ struct Workspace {
     // device-resident occupation sweep: raw level log-likelihoods, cdf scratch, per-sightline alive flag,
     // and staging of its host-pointer variant
     DeviceBuffer level_ll, cdf, alive, uniforms, evidences, sample_ll, base;
+    DeviceBuffer cache, running;  // profile cache / running products of the multi-level sweep, [nb][S][max n_pad]
     void release() {
+        cache.release();
+        running.release();
         level_ll.release();
         cdf.release();
         alive.release();
@@ -312,7 +317,11 @@ template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, GroupPlan *gp, int nsplit,
                         long S, int kd, int num_lines, const SampleSource &src, double *part, int *status) {
     const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * kd * ((LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
-    if (g_opt_debug & 2) {  // diagnostic instantiation with per-phase cycle stamps
+    if (src.cache_mode == 1) {  // level 1 of a cached multi-level sweep: also stores the profiles
+        hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, false, 1>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
+                           table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
+                           kd, src, part, status, (int)g_opt_debug);
+    } else if (g_opt_debug & 2) {  // diagnostic instantiation with per-phase cycle stamps
         hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, true>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
                            table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
                            kd, src, part, status, (int)g_opt_debug);
@@ -323,6 +332,13 @@ static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table
     }
 }
 
+// whether a launch with kd absorbers per sample runs the MFMA kernel (else the generic one)
+static bool mfma_path_serves(const LaunchGroup &g, int kd) {
+    // the MFMA kernel keeps its 16 samples' per-absorber constants in dynamic LDS
+    const size_t mfma_prep_lds = (size_t)DLAGP_MFMA_GROUP * std::max(kd, 1) * (g.num_lines + 1) * sizeof(double);
+    return g.mfma_ok && kd >= 1 && mfma_prep_lds <= 40 * 1024 && g_opt_path != 1;
+}
+
 static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &src, double *d_out,
                         hipStream_t stream) {
     if (S <= 0) return DLAGP_OK;
@@ -331,15 +347,9 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
     const long rows = (long)nb * S;
     const SightlineDev *table = g.d_table.as<SightlineDev>();
 
-    // the MFMA kernel keeps its 16 samples' per-absorber constants in dynamic LDS
-    const size_t mfma_prep_lds = (size_t)DLAGP_MFMA_GROUP * std::max(kd, 1) * (g.num_lines + 1) * sizeof(double);
-    bool use_mfma = g.mfma_ok && kd >= 1 && mfma_prep_lds <= 40 * 1024;
-    if (g_opt_path == 1) use_mfma = false;
-    if (g_opt_path == 2 && kd >= 1) {
-        if (!g.mfma_ok || mfma_prep_lds > 40 * 1024)
-            return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (rank > 20, ragged mask, or kd x lines too large)");
-        use_mfma = true;
-    }
+    bool use_mfma = mfma_path_serves(g, kd);
+    if (g_opt_path == 2 && kd >= 1 && !use_mfma)
+        return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (rank > 20, ragged mask, or kd x lines too large)");
     const int nsplit = use_mfma ? choose_splits(g, S) : 1;
 
     // partial sums: [split][sightline x ceil(S/16) blocks][row_width columns][16 samples]
@@ -361,12 +371,19 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
         HIP_TRY(hipEventRecord(ev.start, stream));
     }
 
+    if (!use_mfma && src.cache_mode)
+        return fail(DLAGP_EINVAL, "internal: the profile cache is only served by the MFMA path");
     if (use_mfma) {
         const long groups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
         dim3 grid((unsigned)(groups * nsplit), (unsigned)nb);
         const bool lines3 = g.num_lines == 3;
         double *part = ws.part.as<double>();
-        if (g.broadening) {
+        if (src.cache_mode == 2) {
+            hipLaunchKernelGGL((accumulate_mfma<3, true, false, 2>), grid, dim3(DLAGP_MFMA_THREADS),
+                               (size_t)DLAGP_MFMA_GROUP * sizeof(double), stream, table,
+                               gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, (long)S,
+                               kd, src, part, ws.status.as<int>(), 0);
+        } else if (g.broadening) {
             if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>());
             else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>());
         } else {
@@ -423,7 +440,7 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
         HIP_TRY(hipMemcpy(ws.z.ptr, z, nsamp * sizeof(double), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ws.nhi.ptr, nhi, nsamp * sizeof(double), hipMemcpyHostToDevice));
     }
-    rc = launch_sweep(g, S, kd, SampleSource{ws.z.as<double>(), ws.nhi.as<double>(), nullptr, 0, 0, 0},
+    rc = launch_sweep(g, S, kd, SampleSource{ws.z.as<double>(), ws.nhi.as<double>(), nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0},
                       ws.out.as<double>(), nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, ws.out.ptr, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost));
@@ -457,8 +474,32 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
         hipLaunchKernelGGL(fill_i32, dim3((unsigned)std::min<long>((n_base + 255) / 256, 2048)), dim3(256), 0, stream,
                            d_base, n_base, 0);
     HIP_TRY(hipGetLastError());
-    const SampleSource src{d_sample_z, d_sample_nhi, d_base, 1, (int)nhi_stride, max_dlas - 1};
+    SampleSource src{d_sample_z, d_sample_nhi, d_base, 1, (long)nhi_stride, max_dlas - 1, nullptr, nullptr, 0, 0, 0};
+    // Profile cache: every absorber of every level is one of the sightline's S QMC points, whose convolved
+    // profile level 1 computes anyway.  Keeping them (8 S n_pad bytes per sightline) turns the Voigt work of
+    // levels 2..max_dlas into HBM reads -- capacity traded for time on the shared FP64 pipe.
+    bool use_cache = g_opt_profile_cache != 0 && max_dlas > 1;
+    for (int level = 0; level < max_dlas; ++level) use_cache = use_cache && mfma_path_serves(g, level + 1);
+    const size_t cache_bytes = rows * (size_t)g.max_npad * sizeof(double);
+    const size_t want_bytes = cache_bytes * (max_dlas > 2 ? 2 : 1);  // profiles + running products
+    if (use_cache) {
+        const size_t have = ws.cache.bytes + ws.running.bytes;
+        if (have < want_bytes) {
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            use_cache = want_bytes <= (size_t)g_opt_profile_cache_max_mb << 20 && want_bytes <= (free_b + have) / 2;
+        }
+        if (use_cache && (rc = ws.cache.reserve(cache_bytes))) return rc;
+        if (use_cache && max_dlas > 2 && (rc = ws.running.reserve(cache_bytes))) return rc;
+    }
+    if (use_cache) {
+        src.cache = ws.cache.as<double>();
+        src.running = ws.running.as<double>();
+        src.cache_stride = g.max_npad;
+    }
     for (int level = 0; level < max_dlas; ++level) {
+        src.cache_mode = use_cache ? (level == 0 ? 1 : 2) : 0;
+        src.cache_write = use_cache && level >= 1 && level + 1 < max_dlas;
         if ((rc = launch_sweep(g, S, level + 1, src, ws.level_ll.as<double>(), stream))) return rc;
         hipLaunchKernelGGL(level_finish, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS), 0, stream,
                            ws.level_ll.as<const double>(), (long)S, level, max_dlas, src, min_z_separation, d_uniforms,
@@ -860,7 +901,7 @@ int dlagp_eval_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, cons
     int rc = check_eval_args(ctx, S, kd, d_z, d_nhi, d_out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    return launch_sweep(ctx->self, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0}, d_out,
+    return launch_sweep(ctx->self, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0}, d_out,
                         static_cast<hipStream_t>(stream));
 }
 
@@ -900,7 +941,7 @@ int dlagp_batch_eval_device(dlagp_batch *batch, int64_t S, int kd, const double 
     int rc = check_eval_args(batch, S, kd, d_z, d_nhi, d_out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(batch->group.device));
-    return launch_sweep(batch->group, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0}, d_out,
+    return launch_sweep(batch->group, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0}, d_out,
                         static_cast<hipStream_t>(stream));
 }
 
@@ -1001,6 +1042,8 @@ int dlagp_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "path")) g_opt_path = value;
     else if (!strcmp(name, "timing")) g_opt_timing = value;
     else if (!strcmp(name, "debug")) g_opt_debug = value;
+    else if (!strcmp(name, "profile_cache")) g_opt_profile_cache = value;
+    else if (!strcmp(name, "profile_cache_max_mb")) g_opt_profile_cache_max_mb = value;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 }

@@ -208,11 +208,15 @@ __device__ __forceinline__ void lds_wave_sync() {
 // Any number of absorbers kd >= 1: each absorber's profile is convolved and multiplied into the LDS
 // buffer a[sample][pixel of the pass] before the MFMA loop (dla_gp.py:370-388).
 // Dynamic LDS: the wave's per-sample constants, 16 samples x kd x (L + 1) doubles.
-template <int LINES, bool BROADEN, bool STAMPS>
+// MODE (profile cache of the multi-level sweep, SampleSource::cache): 0 = none; 1 = level 1, also stores the
+// convolved profiles; 2 = deeper levels, phase 1 multiplies cached rows instead of evaluating Voigt profiles
+// (LINES / BROADEN are then irrelevant: instantiated once, as <3, true, false, 2>).
+template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
     const int2 *const *__restrict__ split_tables, int nsplit, long S, int kd,
     SampleSource src, double *__restrict__ part, int *__restrict__ status, int debug_flags) {
+    constexpr bool CACHED = MODE == 2;
     constexpr int A_STRIDE = 4 * DLAGP_MAX_PASS_STEPS + 2;  // 58: stride/2 odd -> conflict-free b64 reads
     __shared__ double raw[16 * DLAGP_RAW_STRIDE];
     __shared__ double a_lds[16 * A_STRIDE];
@@ -248,7 +252,17 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const int prep_stride = L + 1;
 
     // per-sample constants of this wave -> LDS (rows beyond S repeat the last sample; never stored)
-    const int wave_prep = 16 * kd * prep_stride;
+    const int wave_prep = CACHED ? 0 : 16 * kd * prep_stride;
+    if (CACHED) {
+        // the cached row each of the wave's samples stacks on its running product at this level
+        int *row_lds = reinterpret_cast<int *>(prep_lds);
+        if (lane < 16) {
+            long smp = sample0 + lane;
+            smp = smp < S ? smp : S - 1;
+            row_lds[lane] = (int)sample_point(src, b, smp, kd - 1, S, kd);
+        }
+        lds_wave_sync();
+    }
     for (int i = lane; i < wave_prep; i += 64) {
         const int which = i % prep_stride;           // 0..L-1: line multiplier, L: column density
         const int sample_abs = i / prep_stride;      // sample * kd + absorber
@@ -297,83 +311,128 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
             double, __builtin_amdgcn_raw_buffer_load_b64(aux_rsrc, my_rel * (DLAGP_AUX_FIELDS * 8) + 32,
                                                          step0 * REC_STEP_BYTES, 0));
 
-        // ---------------- phase 1: raw profile and convolution, absorber by absorber ----------------
-        int e = entry_start + lane;
-        e = e < num_entries ? e : num_entries - 1;
-        const double lam = lam_ptr[e];
-        for (int jd = 0; jd < kd; ++jd) {
+        if constexpr (CACHED) {
+            // ---------------- phase 1 (cached): running product x the new absorber's cached profile ----------------
+            // all 32 row reads of the pass are issued before the first use: one memory round trip per pass,
+            // hidden behind the other resident wave's MFMAs
             if (stamps) t_mark = stamp_now();
-            if (LINES == 3) {
-                // the sample's four constants {m'_0, m'_1, m'_2, N log2e} are one 32-byte LDS broadcast
-                // read, fetched one sample ahead so that the loop never waits on it
-                const v4d *sp4 = reinterpret_cast<const v4d *>(prep_lds) + jd;
-                v4d cur = sp4[0];
-#pragma unroll 1
-                for (int ss = 0; ss < 16; ++ss) {
-                    const v4d nxt = sp4[(ss < 15 ? ss + 1 : ss) * kd];
-                    const double m[3] = {cur.x, cur.y, cur.z};
-                    const double tau = optical_depth<LINES>(lam, m, 3);
-                    raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp2(-cur.w * tau);  // voigt.py:309
-                    cur = nxt;
-                }
-            } else {
-#pragma unroll 2
-                for (int ss = 0; ss < 16; ++ss) {
-                    const double *sp = prep_lds + (ss * kd + jd) * prep_stride;
-                    const double tau = optical_depth<LINES>(lam, sp, L);
-                    raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp2(-sp[L] * tau);
-                }
+            typedef const __attribute__((address_space(1))) double *gcd;
+            const int *row_lds = reinterpret_cast<const int *>(prep_lds);
+            const int npx = pass_steps * DLAGP_STEP_PIXELS;
+            const int px = lane < npx ? lane : npx - 1;
+            const long col = (long)step0 * DLAGP_STEP_PIXELS + px;
+            const long row0 = (long)b * S;
+            const long last = S - 1 - sample0;  // rows beyond S repeat the last sample (never stored)
+            gcd cache_col = (gcd)src.cache + col;
+            gcd run_col = (gcd)(kd == 2 ? src.cache : src.running) + (row0 + sample0) * src.cache_stride + col;
+            double own[16], other[16];
+#pragma unroll
+            for (int ss = 0; ss < 16; ++ss) {
+                const long rel = ss < last ? ss : last;
+                own[ss] = run_col[rel * src.cache_stride];
+                other[ss] = cache_col[(row0 + row_lds[ss]) * src.cache_stride];
             }
-            if (stamps) {
-                const unsigned long long now = stamp_now();
-                t_voigt += now - t_mark;
-                t_mark = now;
-            }
-            if (jd == 0) pos_lds[lane] = (int)my_pos_f - entry_start;
-            lds_wave_sync();
-            // convolution (voigt.py:319) on the kept pixels (dla_gp.py:388), product over absorbers.
-            // Always all 14 steps, branch-free, so that the LDS reads of different steps overlap:
-            // lanes beyond the pass's pixels re-read a valid window and write unused slots.
-            // The reads of four steps are issued together (scheduling barriers keep hipcc from
-            // serialising them one ds_read + wait at a time), then the arithmetic runs on them.
-            const double *raw_row = raw + s_loc * DLAGP_RAW_STRIDE;
-            double *a_dst = &a_lds[s_loc * A_STRIDE + slot];
-            constexpr int CONV_GROUP = 4;
-            constexpr int NW = BROADEN ? DLAGP_NUM_TAPS : 1;
+            __attribute__((address_space(1))) double *out_col =
+                (__attribute__((address_space(1))) double *)src.running + (row0 + sample0) * src.cache_stride + col;
 #pragma unroll
-            for (int g0 = 0; g0 < DLAGP_MAX_PASS_STEPS; g0 += CONV_GROUP) {
-                double wv[CONV_GROUP][NW];
-                double prev[CONV_GROUP];
-#pragma unroll
-                for (int u = 0; u < CONV_GROUP; ++u) {
-                    const int st = g0 + u;
-                    if (st < DLAGP_MAX_PASS_STEPS) {
-                        const double *win = raw_row + pos_lds[st * DLAGP_STEP_PIXELS + slot];
-#pragma unroll
-                        for (int t = 0; t < NW; ++t) wv[u][t] = win[t];
-                        prev[u] = a_dst[st * DLAGP_STEP_PIXELS];
-                    }
+            for (int ss = 0; ss < 16; ++ss) {
+                const double prod = own[ss] * other[ss];
+                if (lane < npx) {
+                    a_lds[ss * A_STRIDE + lane] = prod;
+                    if (src.cache_write && ss <= last) out_col[ss * src.cache_stride] = prod;
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < CONV_GROUP; ++u) {
-                    const int st = g0 + u;
-                    if (st < DLAGP_MAX_PASS_STEPS) {
-                        // the instrument profile is symmetric (voigt.py:214-224): 4 coefficients, not 7
-                        double conv = wv[u][0];
-                        if constexpr (BROADEN) {
-                            conv = (wv[u][0] + wv[u][6]) * tap[0];
-                            conv = fma(wv[u][1] + wv[u][5], tap[1], conv);
-                            conv = fma(wv[u][2] + wv[u][4], tap[2], conv);
-                            conv = fma(wv[u][3], tap[3], conv);
-                        }
-                        a_dst[st * DLAGP_STEP_PIXELS] = jd == 0 ? conv : prev[u] * conv;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
             lds_wave_sync();
             if (stamps) t_conv += stamp_now() - t_mark;
+        } else {
+        // ---------------- phase 1: raw profile and convolution, absorber by absorber ----------------
+            int e = entry_start + lane;
+            e = e < num_entries ? e : num_entries - 1;
+            const double lam = lam_ptr[e];
+            for (int jd = 0; jd < kd; ++jd) {
+                if (stamps) t_mark = stamp_now();
+                if (LINES == 3) {
+                    // the sample's four constants {m'_0, m'_1, m'_2, N log2e} are one 32-byte LDS broadcast
+                    // read, fetched one sample ahead so that the loop never waits on it
+                    const v4d *sp4 = reinterpret_cast<const v4d *>(prep_lds) + jd;
+                    v4d cur = sp4[0];
+#pragma unroll 1
+                    for (int ss = 0; ss < 16; ++ss) {
+                        const v4d nxt = sp4[(ss < 15 ? ss + 1 : ss) * kd];
+                        const double m[3] = {cur.x, cur.y, cur.z};
+                        const double tau = optical_depth<LINES>(lam, m, 3);
+                        raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp2(-cur.w * tau);  // voigt.py:309
+                        cur = nxt;
+                    }
+                } else {
+#pragma unroll 2
+                    for (int ss = 0; ss < 16; ++ss) {
+                        const double *sp = prep_lds + (ss * kd + jd) * prep_stride;
+                        const double tau = optical_depth<LINES>(lam, sp, L);
+                        raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp2(-sp[L] * tau);
+                    }
+                }
+                if (stamps) {
+                    const unsigned long long now = stamp_now();
+                    t_voigt += now - t_mark;
+                    t_mark = now;
+                }
+                if (jd == 0) pos_lds[lane] = (int)my_pos_f - entry_start;
+                lds_wave_sync();
+                // convolution (voigt.py:319) on the kept pixels (dla_gp.py:388), product over absorbers.
+                // Always all 14 steps, branch-free, so that the LDS reads of different steps overlap:
+                // lanes beyond the pass's pixels re-read a valid window and write unused slots.
+                // The reads of four steps are issued together (scheduling barriers keep hipcc from
+                // serialising them one ds_read + wait at a time), then the arithmetic runs on them.
+                const double *raw_row = raw + s_loc * DLAGP_RAW_STRIDE;
+                double *a_dst = &a_lds[s_loc * A_STRIDE + slot];
+                constexpr int CONV_GROUP = 4;
+                constexpr int NW = BROADEN ? DLAGP_NUM_TAPS : 1;
+#pragma unroll
+                for (int g0 = 0; g0 < DLAGP_MAX_PASS_STEPS; g0 += CONV_GROUP) {
+                    double wv[CONV_GROUP][NW];
+                    double prev[CONV_GROUP];
+#pragma unroll
+                    for (int u = 0; u < CONV_GROUP; ++u) {
+                        const int st = g0 + u;
+                        if (st < DLAGP_MAX_PASS_STEPS) {
+                            const double *win = raw_row + pos_lds[st * DLAGP_STEP_PIXELS + slot];
+#pragma unroll
+                            for (int t = 0; t < NW; ++t) wv[u][t] = win[t];
+                            prev[u] = a_dst[st * DLAGP_STEP_PIXELS];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < CONV_GROUP; ++u) {
+                        const int st = g0 + u;
+                        if (st < DLAGP_MAX_PASS_STEPS) {
+                            // the instrument profile is symmetric (voigt.py:214-224): 4 coefficients, not 7
+                            double conv = wv[u][0];
+                            if constexpr (BROADEN) {
+                                conv = (wv[u][0] + wv[u][6]) * tap[0];
+                                conv = fma(wv[u][1] + wv[u][5], tap[1], conv);
+                                conv = fma(wv[u][2] + wv[u][4], tap[2], conv);
+                                conv = fma(wv[u][3], tap[3], conv);
+                            }
+                            a_dst[st * DLAGP_STEP_PIXELS] = jd == 0 ? conv : prev[u] * conv;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                lds_wave_sync();
+                if (stamps) t_conv += stamp_now() - t_mark;
+            }
+            // level 1 of a multi-level sweep: keep the convolved profiles for the deeper levels
+            if constexpr (MODE == 1) {
+                const int npx = pass_steps * DLAGP_STEP_PIXELS;
+                __attribute__((address_space(1))) double *dst =
+                    (__attribute__((address_space(1))) double *)src.cache +
+                    ((long)b * S + sample0) * src.cache_stride + (long)step0 * DLAGP_STEP_PIXELS + lane;
+                const long valid = S - sample0 < 16 ? S - sample0 : 16;
+                if (lane < npx)
+                    for (int ss = 0; ss < valid; ++ss) dst[ss * src.cache_stride] = a_lds[ss * A_STRIDE + lane];
+            }
         }
         if (stamps) t_mark = stamp_now();
 

@@ -205,7 +205,11 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
  *   dlagp_set_option: "pixel_splits" (0 = automatic), "path" (0 = automatic, 1 = generic
  *                     kernel, 2 = MFMA kernel), "timing" (1 = bracket the accumulate kernel
  *                     of every launch with HIP events on its stream), "debug" (bit 1: launch the
- *                     stamped instantiation of the MFMA kernel, see dlagp_debug_read)
+ *                     stamped instantiation of the MFMA kernel, see dlagp_debug_read),
+ *                     "profile_cache" (1 = dlagp_batch_sweep keeps the level-1 absorption profiles
+ *                     of all QMC points in HBM, 8 S n_pad bytes per sightline, and multiplies cached
+ *                     rows at the deeper levels instead of re-evaluating Voigt profiles; 0 = recompute),
+ *                     "profile_cache_max_mb" (upper bound of that allocation, default 98304)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.
  */

@@ -330,6 +330,7 @@ def restore_options():
     yield set_option
     set_option("path", 0)
     set_option("pixel_splits", 0)
+    set_option("profile_cache", 1)
 
 
 @pytest.mark.parametrize("shape", [dict(index=4, n_unmasked=1250, n_masked=28, k=20),
@@ -502,13 +503,17 @@ def test_device_sweep_matches_reference_golden(tag):
     np.testing.assert_allclose(ll_sub[0], g["sub_sample_ll"], rtol=RTOL_LL)
 
 
-@pytest.mark.parametrize("path", [0, 1])
-def test_device_sweep_equals_host_level_logic(path, restore_options):
-    """several ragged sightlines, automatic and generic accumulate kernels: device levels == host levels"""
+@pytest.mark.parametrize("path,cache", [(0, 1), (0, 0), (1, 1)])
+def test_device_sweep_equals_host_level_logic(path, cache, restore_options):
+    """
+    several ragged sightlines; MFMA kernel with and without the profile cache, and the generic kernel
+    (which never caches): device levels == host levels
+    """
     from gpy_dla_detection_amd import parallel
     from gpy_dla_detection_amd.sightline import DeviceBatch
 
     restore_options("path", path)
+    restore_options("profile_cache", cache)
     sights = [make_sightline(i, n_unmasked=n_u, n_masked=m) for i, (n_u, m) in enumerate([(300, 5), (411, 0), (257, 30)])]
     devs = [device_sightline(s) for s in sights]
     batch = DeviceBatch(devs)
