@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests -q -m gpu -x > gpurun_out/pytest_gpu.log 2>&1
 tail -3 gpurun_out/pytest_gpu.log
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/prof_${tag}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_${tag}_bench.log 2>&1
 grep "^{" gpurun_out/prof_${tag}_bench.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('evals/s %.3e  ms/step %.3f  kernel_ms %.3f  frac %.3f' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac']))"
 python3 - "$tag" <<'PY'
 import csv, glob, sys
