@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "dlagp_device.h"
 #include "fastmath_device.h"
 
@@ -309,13 +311,43 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     // ---- stage: lds[c][sample], c < NC: vech(B - I); NC..NC+K-1: u; NC+K: sum r^2/d; NC+K+1: sum log d;
     // NC+K+2: n log 2pi.  One contiguous 33 KB block per split: fully coalesced reads, which are what
     // this kernel costs (a CU sustains only tens of GB/s from HBM/MALL, hence also the small workgroups).
-    for (int idx = tid; idx < DLAGP_FIN_STAGED * NS; idx += DLAGP_FIN_THREADS) {
-        const int c = idx / NS, smp = idx % NS;
-        const int src = c < NC ? c : (c < NC + K ? qbase + (c - NC) : sbase + (c - NC - K));
-        double acc = 0.0;
-        for (int h = 0; h < nsplit; ++h) acc += part[partial_index(h, nblocks, block, rw, src, smp)];
-        fin_lds[idx] = acc;
-    }
+    // All loads of a thread are issued before the first use (the loop is fully unrolled for the usual
+    // split counts): issued one iteration at a time, the ~15 dependent round trips to L2/HBM were 70 % of
+    // this kernel.
+    constexpr int ITER = (DLAGP_FIN_STAGED * NS + DLAGP_FIN_THREADS - 1) / DLAGP_FIN_THREADS;
+    auto stage = [&](auto nsplit_c) {
+        constexpr int H = decltype(nsplit_c)::value;
+        double v[ITER][H];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * DLAGP_FIN_THREADS;
+            const int cl = idx < DLAGP_FIN_STAGED * NS ? idx : tid;  // clamp: a valid address, value unused
+            const int c = cl / NS, smp = cl % NS;
+            const int src = c < NC ? c : (c < NC + K ? qbase + (c - NC) : sbase + (c - NC - K));
+#pragma unroll
+            for (int h = 0; h < H; ++h) v[it][h] = part[partial_index(h, nblocks, block, rw, src, smp)];
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * DLAGP_FIN_THREADS;
+            double acc = 0.0;
+#pragma unroll
+            for (int h = 0; h < H; ++h) acc += v[it][h];
+            if (idx < DLAGP_FIN_STAGED * NS) fin_lds[idx] = acc;
+        }
+    };
+    if (nsplit == 1) stage(std::integral_constant<int, 1>{});
+    else if (nsplit == 2) stage(std::integral_constant<int, 2>{});
+    else if (nsplit == 3) stage(std::integral_constant<int, 3>{});
+    else if (nsplit == 4) stage(std::integral_constant<int, 4>{});
+    else
+        for (int idx = tid; idx < DLAGP_FIN_STAGED * NS; idx += DLAGP_FIN_THREADS) {
+            const int c = idx / NS, smp = idx % NS;
+            const int src = c < NC ? c : (c < NC + K ? qbase + (c - NC) : sbase + (c - NC - K));
+            double acc = 0.0;
+            for (int h = 0; h < nsplit; ++h) acc += part[partial_index(h, nblocks, block, rw, src, smp)];
+            fin_lds[idx] = acc;
+        }
     __syncthreads();
     if (tid >= valid) return;  // lanes beyond the sightline's last sample hold unwritten partials
     const long row = row0 + tid;
