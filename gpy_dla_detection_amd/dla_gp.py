@@ -223,11 +223,50 @@ class DLAGP(_AbsorberGP):
         return map_traceback(self.sample_log_likelihoods, self.base_sample_inds, self._sample_redshifts(),
                              self.dla_samples.log_nhi_samples)
 
-    def run_mcmc(self, *args, **kwargs):
-        raise NotImplementedError(
-            "the emcee posterior sampler (reference dla_gp.py:227-309) is outside the GPU hot path; "
-            "call sample_log_likelihood_k_dlas from your own sampler"
-        )
+    def mcmc_arguments(self) -> tuple:
+        """the `args` tuple the reference passes to emcee for `log_posterior` (dla_gp.py:265-287)"""
+        from scipy import stats
+        from scipy.integrate import quad
+
+        samples = self.dla_samples
+        min_z_dla = self.params.min_z_dla(self.this_wavelengths, self.z_qso)
+        max_z_dla = self.params.max_z_dla(self.this_wavelengths, self.z_qso)
+        uniform = stats.uniform(loc=samples.uniform_min_log_nhi,
+                                scale=samples.uniform_max_log_nhi - samples.uniform_min_log_nhi)
+
+        def unnormalized_pdf(nhi):  # polynomial fit of Garnett et al. (2017), reference :249-251
+            return np.exp(-1.2695 * nhi ** 2 + 50.863 * nhi - 509.33)
+
+        Z = quad(unnormalized_pdf, samples.fit_min_log_nhi, 25.0)[0]
+
+        def normalized_pdf(nhi):
+            return samples.alpha * (unnormalized_pdf(nhi) / Z) + (1 - samples.alpha) * uniform.pdf(nhi)
+
+        return (self.this_wavelengths, self.y, self.v, self.z_qso, min_z_dla, max_z_dla,
+                samples.uniform_min_log_nhi, samples.uniform_max_log_nhi, normalized_pdf, self.padded_wavelengths,
+                self.this_mu, self.this_M, self.this_omega2, self.pixel_mask, self.ind_unmasked,
+                self.params.num_lines)
+
+    def run_mcmc(self, nwalkers: int, kth_dla: int = 1, nsamples: int = 5000, pos=None,
+                 skip_initial_state_check: bool = True):
+        """
+        emcee refinement of the k-th occupation level (reference dla_gp.py:227-309).  The ensemble is
+        evaluated through `log_posterior_vectorized`: all walkers of a step in one device launch.
+        Needs the optional dependency emcee.
+        """
+        import emcee  # optional dependency
+
+        from .log_posterior_mcmc import log_posterior_vectorized
+
+        sampler = emcee.EnsembleSampler(nwalkers, kth_dla * 2, log_posterior_vectorized, args=self.mcmc_arguments(),
+                                        vectorize=True)
+        if pos is None:
+            sample_z = self._sample_redshifts()
+            pos = np.concatenate(
+                [np.random.choice(sample_z, size=(nwalkers, kth_dla)),
+                 np.random.choice(self.dla_samples.log_nhi_samples, size=(nwalkers, kth_dla))], axis=1)
+        sampler.run_mcmc(pos, nsamples, progress=False, skip_initial_state_check=skip_initial_state_check)
+        return sampler
 
     @classmethod
     def from_mat(cls, params: Parameters, prior, dla_samples, min_z_separation: float = 3000.0,

@@ -67,3 +67,17 @@ def raw_catalogue(num=3, k=20):
         spectra.append((obs.copy(), flux, noise_variance, pixel_mask))
         z_qsos.append(z_qso)
     return (rest_grid, mu, M, log_omega, lc0, lt0, lb), spectra, z_qsos
+
+
+def mcmc_pdf(log_nhi):
+    """column-density prior density used for golden set G9 (a smooth positive function; our own choice)"""
+    return 0.3 * np.exp(-0.5 * ((log_nhi - 20.6) / 0.5) ** 2) + 0.1
+
+
+def mcmc_thetas(z_lo, z_hi):
+    """(z_dla, log N_HI) pairs for G9: inside the prior box, on its edges and outside"""
+    rng = np.random.default_rng(99)
+    inside = np.stack([z_lo + (z_hi - z_lo) * rng.random(10), 20.0 + 3.0 * rng.random(10)], axis=1)
+    outside = np.array([[z_lo - 0.01, 21.0], [z_hi + 0.01, 21.0], [0.5 * (z_lo + z_hi), 19.9],
+                        [0.5 * (z_lo + z_hi), 23.1], [z_hi, 21.0]])
+    return np.concatenate([inside, outside])

@@ -598,3 +598,33 @@ def test_process_qso_on_device_matches_reference_driver_golden():
     results = process_qso(spectra, z_qsos, params, Prior(), dla_samples, sub_samples, learned,
                           max_dlas=int(g["max_dlas"]), batch_size=2)
     assert_catalogue_matches_golden(results, g, rtol=RTOL_LL)
+
+
+# ------------------------------------------------------------------------------------------------
+# f4: MCMC target density (log_posterior_mcmc) on the device
+# ------------------------------------------------------------------------------------------------
+def test_log_posterior_mcmc_matches_reference_golden():
+    from gpy_dla_detection_amd import log_posterior_mcmc as mc
+    from tests.golden_inputs import mcmc_pdf, mcmc_thetas
+
+    g = load_golden("log_posterior.npz")
+    sight = make_sightline(1, n_unmasked=400, n_masked=9)
+    assert checksum(sight.y, sight.this_M) == int(g["sight_crc"])
+    z_lo, z_hi = sight.z_range()
+    thetas = mcmc_thetas(z_lo, z_hi)
+    np.testing.assert_array_equal(thetas, g["thetas"])
+    pixel_mask = ~sight.keep
+    ind_unmasked = np.ones(sight.keep.shape[0], dtype=bool)
+    args = (sight.this_wavelengths, sight.y, sight.v, sight.z_qso, z_lo, z_hi, 20.0, 23.0, mcmc_pdf,
+            sight.padded_wavelengths, sight.this_mu, sight.this_M, sight.this_omega2, pixel_mask, ind_unmasked, 3)
+    batched = mc.log_posterior_vectorized(thetas, *args)          # emcee vectorize=True form: one launch
+    assert np.array_equal(np.isneginf(batched), np.isneginf(g["log_posterior"]))
+    live = np.isfinite(g["log_posterior"])
+    np.testing.assert_allclose(batched[live], g["log_posterior"][live], rtol=RTOL_LL)
+    single = np.array([mc.log_posterior(tuple(t), *args) for t in thetas[:3]])   # the reference's call form
+    np.testing.assert_allclose(single, batched[:3], rtol=1e-13)
+    # two absorbers per walker: (z_1, z_2, logN_1, logN_2) -- against the sightline API
+    pair = np.concatenate([thetas[:2, :1].T, thetas[:2, 1:].T], axis=1)
+    want = device_sightline(sight).eval(pair[:, :2], 10.0 ** pair[:, 2:])[0] + np.log(mcmc_pdf(pair[0, 2])) + \
+        np.log(mcmc_pdf(pair[0, 3]))
+    assert abs(mc.log_posterior_vectorized(pair, *args)[0] - want) <= 1e-12 * abs(want)

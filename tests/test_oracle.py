@@ -119,3 +119,22 @@ def test_log_model_evidences_small_seeded():
     ev, sll, _ = R.log_model_evidences(st, g["dla_sample_z"], nhi_sub, 1, float(g["dla_min_z_separation"]), verbose=False)
     np.testing.assert_allclose(ev, g["sub_evidences"], rtol=RTOL)
     np.testing.assert_allclose(sll, g["sub_sample_ll"], rtol=RTOL)
+
+
+def test_oracle_reproduces_reference_log_posterior():
+    """G9: the MCMC target density = log prior + the same likelihood (reference log_posterior_mcmc.py:46-95)"""
+    from tests.golden_inputs import mcmc_pdf, mcmc_thetas
+
+    g = load_golden("log_posterior.npz")
+    sight = make_sightline(1, n_unmasked=400, n_masked=9)
+    st = oracle_state(sight)
+    z_lo, z_hi = sight.z_range()
+    thetas = mcmc_thetas(z_lo, z_hi)
+    for theta, want in zip(thetas, g["log_posterior"]):
+        z, log_nhi = theta
+        inside = z_lo < z < z_hi and 20.0 < log_nhi < 23.0
+        if not inside:
+            assert np.isneginf(want)
+            continue
+        got = np.log(mcmc_pdf(log_nhi)) + R.sample_log_likelihood_k_dlas(st, [z], [10.0 ** log_nhi])
+        assert abs(got - want) <= 1e-11 * abs(want)
