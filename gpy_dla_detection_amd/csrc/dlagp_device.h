@@ -27,6 +27,7 @@ struct SightlineDev {
     int num_entries;  // E
     int num_lines;  // Lyman-series members
     int ntaps;      // 7 with instrumental broadening, 1 without
+    int lls_break;  // 1: add the Lyman-limit continuum opacity of every absorber (reference voigt_lls.py:258-284)
     int ntw;        // w-tiles: ceil(k (k + 1) / 2 / 16)
     int ntq;        // q-tiles: ceil(k / 16)
     int row_width;  // (ntw + ntq) * 16 + DLAGP_ROW_EXTRA doubles per partial row

@@ -537,7 +537,9 @@ static int finish_group(LaunchGroup &g) {
 // `fill(ctx)` then has to leave y, mu, omega2, v (n_pad, padded 0/0/0/1) and dense_M ([n][sl.k]) on the device.
 template <typename Fill>
 static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *wavelengths, const uint8_t *keep,
-                          int num_lines, int broadening, int device, Fill fill) {
+                          int num_lines, int flags, int device, Fill fill) {
+    const int broadening = flags & DLAGP_FLAG_BROADENING;
+    const int lls_break = (flags & DLAGP_FLAG_LLS_BREAK) != 0;
     if (!out) return fail(DLAGP_EINVAL, "out is NULL");
     *out = nullptr;
     if (!wavelengths || !keep) return fail(DLAGP_EINVAL, "NULL input array");
@@ -545,6 +547,7 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     if (k < 1 || k > DLAGP_MAX_RANK) return fail(DLAGP_EINVAL, "rank k=%d outside [1, %d]", k, DLAGP_MAX_RANK);
     if (num_lines < 1 || num_lines > DLAGP_MAX_LINES)
         return fail(DLAGP_EINVAL, "num_lines=%d outside [1, %d]", num_lines, DLAGP_MAX_LINES);
+    if (flags & ~(DLAGP_FLAG_BROADENING | DLAGP_FLAG_LLS_BREAK)) return fail(DLAGP_EINVAL, "unknown flag bits 0x%x", flags);
     int kept = 0;
     for (int j = 0; j < n_u; ++j) kept += keep[j] != 0;
     if (kept != n)
@@ -563,6 +566,7 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     sl.n_pad = (n + DLAGP_CHUNK_PIXELS - 1) / DLAGP_CHUNK_PIXELS * DLAGP_CHUNK_PIXELS;
     sl.nsteps = sl.n_pad / DLAGP_STEP_PIXELS;
     sl.k = k_eff;
+    sl.lls_break = lls_break;
     sl.ntaps = broadening ? DLAGP_NUM_TAPS : 1;
     sl.num_entries = broadening ? n_u + DLAGP_NUM_TAPS - 1 : n_u;
     sl.num_lines = num_lines;
@@ -588,7 +592,8 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     {
         std::vector<PassDesc> passes;
         std::vector<int2> splits;
-        ctx->mfma_ok = k_eff == DLAGP_MFMA_RANK && plan_passes(hpos, sl.n_pad, sl.ntaps, 1, passes, splits);
+        // the Lyman-limit term is implemented in the generic kernel only
+        ctx->mfma_ok = k_eff == DLAGP_MFMA_RANK && !lls_break && plan_passes(hpos, sl.n_pad, sl.ntaps, 1, passes, splits);
     }
 
     const size_t px = (size_t)sl.n_pad * sizeof(double);

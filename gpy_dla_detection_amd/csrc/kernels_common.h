@@ -12,6 +12,8 @@ namespace dlagp {
 
 #define DLAGP_LOG_2PI 1.83787706640934534  // reference null_gp.py:325
 #define DLAGP_MAX_ABSORBERS_DEV 8           // = DLAGP_MAX_ABSORBERS of include/dlagp.h
+#define DLAGP_LYMAN_LIMIT_ANGSTROM 911.7641             // reference voigt_lls.py:227
+#define DLAGP_LLS_COLUMN_SCALE 1.5848931924611142e17    // 10**17.2, reference voigt_lls.py:277
 
 // Partial sums live in blocks of 16 consecutive samples of one sightline:
 //   part[split][block][column][16],  block = sightline * ngroups + sample / 16,  ngroups = ceil(S / 16)

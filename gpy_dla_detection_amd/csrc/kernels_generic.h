@@ -37,8 +37,14 @@ __device__ __forceinline__ void sample_absorption(const SightlineDev &sl, int kd
         if (tid < sl.num_lines) mult[tid] = line_multiplier(tid, zj);
         __syncthreads();
         for (int e = tid; e < sl.num_entries; e += DLAGP_GENERIC_THREADS) {
-            const double tau = line_optical_depth(sl.lam[e], mult, sl.num_lines);
-            raw[e] = exp(-nj * tau);  // voigt.py:309
+            const double lam = sl.lam[e];
+            double exponent = -nj * line_optical_depth(lam, mult, sl.num_lines);  // voigt.py:309
+            if (sl.lls_break) {
+                // Lyman-limit break, voigt_lls.py:271-284,348: N / 10^17.2 (lambda_rest / 911.7641)^3 bluewards of the limit
+                const double ratio = lam / (1.0 + zj) / DLAGP_LYMAN_LIMIT_ANGSTROM;
+                if (!(ratio > 1.0)) exponent -= nj / DLAGP_LLS_COLUMN_SCALE * (ratio * ratio * ratio);
+            }
+            raw[e] = exp(exponent);
         }
         __syncthreads();
         for (int i = tid; i < sl.n_pad; i += DLAGP_GENERIC_THREADS) {

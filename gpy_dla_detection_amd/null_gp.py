@@ -238,7 +238,7 @@ class NullGP:
             self.y, self.v, self.this_mu, self.this_M, self.this_omega2, self.padded_wavelengths,
             self.unmasked_wavelengths, self.pixel_mask, self.ind_unmasked,
         )
-        settings = (int(self.params.num_lines), broadening, int(self.device))
+        settings = (int(self.params.num_lines), broadening, int(self.device), bool(getattr(self, "lls_break", False)))
         stale = (
             self._device_sightline is None
             or self._device_key[1] != settings
@@ -249,7 +249,7 @@ class NullGP:
             grid = self.padded_wavelengths if broadening else self.unmasked_wavelengths
             self._device_sightline = _sl.DeviceSightline(
                 self.y, self.this_mu, self.this_M, self.this_omega2, self.v, grid, self._keep_flags(),
-                num_lines=settings[0], broadening=broadening, device=settings[2],
+                num_lines=settings[0], broadening=broadening, device=settings[2], lls_break=settings[3],
             )
             self._device_key = (arrays, settings)
         return self._device_sightline

@@ -55,7 +55,7 @@ class DeviceSightline:
     """
 
     def __init__(self, y, mu, M, omega2, v, wavelengths, keep, num_lines: int = 3,
-                 broadening: bool = True, device: int = 0):
+                 broadening: bool = True, device: int = 0, lls_break: bool = False):
         lib = _lib.load()
         y, mu, omega2, v = (_lib.as_f64(a) for a in (y, mu, omega2, v))
         wavelengths = _lib.as_f64(wavelengths)
@@ -75,16 +75,17 @@ class DeviceSightline:
         rc = lib.dlagp_create(
             ctypes.byref(handle), n, n_u, k, _lib.ptr(y), _lib.ptr(mu), _lib.ptr(M),
             M.strides[0] // 8, M.strides[1] // 8, _lib.ptr(omega2), _lib.ptr(v), _lib.ptr(wavelengths),
-            keep.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), int(num_lines), int(bool(broadening)), int(device),
+            keep.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), int(num_lines),
+            int(bool(broadening)) | (2 if lls_break else 0), int(device),
         )
         _lib.check(rc)
         self._handle = handle
         self.n, self.k, self.device = n, k, int(device)
-        self.num_lines, self.broadening = int(num_lines), bool(broadening)
+        self.num_lines, self.broadening, self.lls_break = int(num_lines), bool(broadening), bool(lls_break)
 
     @classmethod
     def from_model(cls, model: DeviceModel, x, y, v, this_wavelengths, z_qso: float, wavelengths, keep,
-                   num_lines: int = 3, broadening: bool = True):
+                   num_lines: int = 3, broadening: bool = True, lls_break: bool = False):
         """
         NullGP.get_interp on the device (dlagp_create_from_model): the GP mean, factor and absorption
         noise are interpolated from `model` at the kept pixels' rest wavelengths `x` and suppressed by
@@ -105,11 +106,12 @@ class DeviceSightline:
         _lib.check(lib.dlagp_create_from_model(
             ctypes.byref(handle), model._handle, n, n_u, _lib.ptr(x), _lib.ptr(y), _lib.ptr(v),
             _lib.ptr(this_wavelengths), float(z_qso), _lib.ptr(wavelengths),
-            keep.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), int(num_lines), int(bool(broadening))))
+            keep.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), int(num_lines),
+            int(bool(broadening)) | (2 if lls_break else 0)))
         self = cls.__new__(cls)
         self._handle = handle
         self.n, self.k, self.device = n, model.k, model.device
-        self.num_lines, self.broadening = int(num_lines), bool(broadening)
+        self.num_lines, self.broadening, self.lls_break = int(num_lines), bool(broadening), bool(lls_break)
         return self
 
     def read_model(self):
@@ -121,14 +123,14 @@ class DeviceSightline:
         return mu, M, omega2
 
     @classmethod
-    def from_state(cls, st, num_lines: int = 3, broadening: bool = True, device: int = 0):
+    def from_state(cls, st, num_lines: int = 3, broadening: bool = True, device: int = 0, lls_break: bool = False):
         """from any object with the reference's post-set_data attribute names"""
         keep = getattr(st, "keep", None)
         if keep is None:
             keep = ~st.pixel_mask[st.ind_unmasked]
         grid = st.padded_wavelengths if broadening else st.unmasked_wavelengths
         return cls(st.y, st.this_mu, st.this_M, st.this_omega2, st.v, grid, keep,
-                   num_lines=num_lines, broadening=broadening, device=device)
+                   num_lines=num_lines, broadening=broadening, device=device, lls_break=lls_break)
 
     # -- lifetime -----------------------------------------------------------------------------
     def close(self) -> None:

@@ -49,6 +49,13 @@ extern "C" {
 #define DLAGP_MAX_ABSORBERS 8 /* absorbers per sample (the reference sweeps 1..4)            */
 #define DLAGP_MAX_RANK 64     /* largest k of the low-rank factor                            */
 
+/* bits of the `broadening` argument of dlagp_create / dlagp_create_from_model */
+#define DLAGP_FLAG_BROADENING 1 /* 7-tap instrument convolution (voigt.py:311-319)          */
+#define DLAGP_FLAG_LLS_BREAK 2  /* absorbers also carry the Lyman-limit continuum opacity
+                                   N / 10^17.2 (lambda_rest / 911.7641 A)^3 bluewards of the
+                                   limit (reference voigt_lls.py:258-284, :348; the profile of
+                                   examples/gp_find_lls.py:159-224); evaluated by the generic kernel */
+
 typedef struct dlagp_ctx dlagp_ctx;     /* one sightline's model + data, resident in HBM    */
 typedef struct dlagp_batch dlagp_batch; /* a launch group of sightlines on one device       */
 typedef struct dlagp_model dlagp_model; /* the learned GP model (rest-frame grid), in HBM   */
@@ -75,6 +82,7 @@ const char *dlagp_last_error(void);
  *   keep         n_u flags, keep[j] != 0 iff unmasked pixel j is a kept pixel
  *                (= ~pixel_mask[ind_unmasked], dla_gp.py:360); exactly n flags set
  *   num_lines    Lyman-series members in the Voigt profile, 1..31       (set_parameters.py:60)
+ *   broadening   DLAGP_FLAG_* bits; 0 / 1 keep their meaning (no / with instrumental broadening)
  *   device       HIP device ordinal
  */
 int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const double *mu,

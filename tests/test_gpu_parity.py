@@ -628,3 +628,63 @@ def test_log_posterior_mcmc_matches_reference_golden():
     want = device_sightline(sight).eval(pair[:, :2], 10.0 ** pair[:, 2:])[0] + np.log(mcmc_pdf(pair[0, 2])) + \
         np.log(mcmc_pdf(pair[0, 3]))
     assert abs(mc.log_posterior_vectorized(pair, *args)[0] - want) <= 1e-12 * abs(want)
+
+
+# ------------------------------------------------------------------------------------------------
+# f4: Lyman-limit-system profile (reference voigt_lls.py) behind DLAGP_FLAG_LLS_BREAK
+# ------------------------------------------------------------------------------------------------
+def test_lls_profile_matches_reference_golden_and_oracle():
+    from oracle import ref_like as R
+
+    g = load_golden("voigt_lls.npz")
+    grid = g["grid"]
+    n_u = grid.shape[0] - 6
+    rng = np.random.default_rng(3)
+    keep = np.ones(n_u, dtype=bool)
+    keep[rng.choice(n_u, 20, replace=False)] = False
+    n = int(keep.sum())
+    from gpy_dla_detection_amd.sightline import DeviceSightline
+
+    y, mu = 1 + 0.1 * rng.standard_normal(n), np.ones(n)
+    M = 0.1 * rng.standard_normal((n, 20))
+    omega2, v = 0.01 * (1 + rng.random(n)), 0.02 * (1 + rng.random(n))
+    for broadening in (True, False):
+        wl = grid if broadening else grid[3:-3]
+        dev = DeviceSightline(y, mu, M, omega2, v, wl, keep, broadening=broadening, lls_break=True)
+        want = g["absorption_b%d" % broadening]
+        want = want if broadening else want[:, 3:-3]
+        for i, (z, ln) in enumerate(zip(g["z"], g["log_nhi"])):
+            np.testing.assert_allclose(dev.absorption([z], [10.0 ** ln]), want[i][keep], rtol=0, atol=RTOL_ABS)
+        # log-likelihoods with the break, two absorbers: device vs oracle
+        st = R.SpectrumState(y=y, v=v, this_mu=mu, this_M=M, this_omega2=omega2, padded_wavelengths=grid,
+                             unmasked_wavelengths=grid[3:-3], keep=keep, broadening=broadening, lls_break=True)
+        z2 = np.stack([g["z"][:6], g["z"][6:]], axis=1)
+        n2 = 10.0 ** np.stack([g["log_nhi"][:6], g["log_nhi"][6:]], axis=1)
+        got = dev.eval(z2, n2)
+        ref = np.array([R.sample_log_likelihood_k_dlas(st, z2[i], n2[i]) for i in range(6)])
+        np.testing.assert_allclose(got, ref, rtol=RTOL_LL)
+        plain = DeviceSightline(y, mu, M, omega2, v, wl, keep, broadening=broadening).eval(z2, n2)
+        assert np.max(np.abs(plain - got)) > 1.0  # the break matters on this grid
+    with pytest.raises(ValueError):
+        from gpy_dla_detection_amd import _lib
+        import ctypes
+
+        h = ctypes.c_void_p()
+        k8 = np.ascontiguousarray(keep, dtype=np.uint8)
+        _lib.check(_lib.load().dlagp_create(ctypes.byref(h), n, n_u, 20, _lib.ptr(y), _lib.ptr(mu), _lib.ptr(M), 20, 1,
+                                            _lib.ptr(omega2), _lib.ptr(v), _lib.ptr(grid),
+                                            k8.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), 3, 4, 0))  # unknown flag bit
+
+
+def test_lls_gp_class_runs_the_sweep_with_the_break():
+    from gpy_dla_detection_amd.lls_gp import LLSGP
+
+    sight = make_sightline(1, n_unmasked=400, n_masked=9)
+    _, _, dla = build_models(sight, 64)
+    lls = LLSGP.__new__(LLSGP)
+    lls.__dict__.update(dla.__dict__)
+    lls._device_sightline, lls._device_key = None, None
+    assert lls.device_sightline().lls_break and not dla.device_sightline().lls_break
+    z, _, nhi = make_qmc_samples(sight, 4)
+    # this synthetic grid lies redwards of every absorber's limit: the break adds nothing there
+    np.testing.assert_allclose(lls.device_sightline().eval(z, nhi), dla.device_sightline().eval(z, nhi), rtol=1e-11)

@@ -138,3 +138,15 @@ def test_oracle_reproduces_reference_log_posterior():
             continue
         got = np.log(mcmc_pdf(log_nhi)) + R.sample_log_likelihood_k_dlas(st, [z], [10.0 ** log_nhi])
         assert abs(got - want) <= 1e-11 * abs(want)
+
+
+def test_oracle_reproduces_reference_voigt_lls():
+    """G10: Lyman-series lines + Lyman-limit break (reference voigt_lls.py:258-360)"""
+    g = load_golden("voigt_lls.npz")
+    for broadening in (True, False):
+        want = g["absorption_b%d" % broadening]
+        for i, (z, ln) in enumerate(zip(g["z"], g["log_nhi"])):
+            got = R.voigt_absorption(g["grid"], nhi=10.0 ** ln, z_dla=z, num_lines=3, broadening=broadening,
+                                     lls_break=True)
+            np.testing.assert_allclose(got, want[i], rtol=1e-13, atol=1e-300)
+    assert (g["absorption_b0"] < 1e-3).any() and (g["absorption_b0"] > 0.5).any()  # the break is on the grid

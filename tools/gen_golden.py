@@ -19,6 +19,7 @@ Fixtures (all float64):
   G5 evidences_*.npz       DLAGP.log_model_evidences(4) / SubDLAGP.log_model_evidences(1), seed 0
   G6 model_selection.npz   BayesModelSelect([0,1,4],2).model_selection with a fixed prior
   G7 set_data.npz          NullGP.set_data/get_interp on a synthetic raw spectrum + learned model
+  G10 voigt_lls.npz        voigt_lls.voigt_absorption: Lyman series + Lyman-limit break
   G9 log_posterior.npz     log_posterior_mcmc.log_posterior (MCMC target density) for a set of thetas
   G8 catalogue.npz         the per-spectrum body of run_bayes_select.process_qso on three raw spectra:
                            every array the reference writes to processed_qsos_multi_meanflux.h5
@@ -44,6 +45,7 @@ from gpy_dla_detection.subdla_gp import SubDLAGP as RefSubDLAGP  # noqa: E402
 from gpy_dla_detection.bayesian_model_selection import BayesModelSelect as RefBayes  # noqa: E402
 from gpy_dla_detection import voigt as ref_voigt  # noqa: E402
 from gpy_dla_detection import log_posterior_mcmc as ref_mcmc  # noqa: E402
+from gpy_dla_detection import voigt_lls as ref_voigt_lls  # noqa: E402
 
 from gpy_dla_detection_amd.synthetic import make_sightline, make_qmc_samples  # noqa: E402
 from gpy_dla_detection_amd.samples import halton  # noqa: E402
@@ -374,11 +376,26 @@ def g9_log_posterior():
                         sight_crc=checksum(sight.y, sight.this_M))
 
 
+def g10_voigt_lls():
+    """reference voigt_lls.voigt_absorption (Lyman series + Lyman-limit break) on a padded grid"""
+    grid = 10.0 ** (3.5600 + 1e-4 * (np.arange(1256) - 3))  # 3629-4845 A: the limit of z = 3.1..4.2 absorbers is inside
+    rng = np.random.default_rng(17)
+    z = 3.05 + 1.2 * rng.random(12)
+    log_nhi = 17.0 + 5.5 * rng.random(12)
+    store = {"grid": grid, "z": z, "log_nhi": log_nhi}
+    for broadening in (True, False):
+        store["absorption_b%d" % broadening] = np.stack([
+            ref_voigt_lls.voigt_absorption(grid, nhi=10.0 ** ln, z_lls=zz, num_lines=3, broadening=broadening)
+            for zz, ln in zip(z, log_nhi)
+        ])
+    np.savez_compressed(os.path.join(OUT, "voigt_lls.npz"), **store)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     table = dict(g1=g1_voigt_profile, g2=g2_voigt_absorption, g3=g3_mvnpdf, g4=g4_sample_ll,
-                 g5=g5_evidences, g6=g6_model_selection, g7=g7_set_data, g8=g8_catalogue, g9=g9_log_posterior)
+                 g5=g5_evidences, g6=g6_model_selection, g7=g7_set_data, g8=g8_catalogue, g9=g9_log_posterior, g10=g10_voigt_lls)
     for name in which:
         print("generating", name, flush=True)
         table[name]()
