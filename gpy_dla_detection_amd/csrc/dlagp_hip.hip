@@ -316,7 +316,8 @@ static int choose_splits(const LaunchGroup &g, int64_t S) {
 template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, GroupPlan *gp, int nsplit,
                         long S, int kd, int num_lines, const SampleSource &src, double *part, int *status) {
-    const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * kd * ((LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
+    // 16 samples + one spare row that the look-ahead of the sample loop may read
+    const size_t prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * kd * ((LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
     if (src.cache_mode == 1) {  // level 1 of a cached multi-level sweep: also stores the profiles
         hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, false, 1>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
                            table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
@@ -335,7 +336,7 @@ static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table
 // whether a launch with kd absorbers per sample runs the MFMA kernel (else the generic one)
 static bool mfma_path_serves(const LaunchGroup &g, int kd) {
     // the MFMA kernel keeps its 16 samples' per-absorber constants in dynamic LDS
-    const size_t mfma_prep_lds = (size_t)DLAGP_MFMA_GROUP * std::max(kd, 1) * (g.num_lines + 1) * sizeof(double);
+    const size_t mfma_prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * std::max(kd, 1) * (g.num_lines + 1) * sizeof(double);
     return g.mfma_ok && kd >= 1 && mfma_prep_lds <= 40 * 1024 && g_opt_path != 1;
 }
 

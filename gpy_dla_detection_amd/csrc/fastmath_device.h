@@ -65,6 +65,28 @@ __device__ __forceinline__ double fast_exp2(double t) {
     return __builtin_amdgcn_ldexp(p, ki);
 }
 
+// The same with the second-highest coefficient handed in in a vector register (see vgpr_constant): the
+// first Horner step is then one three-operand v_fma_f64 (scalar, vector, vector) instead of the
+// v_mov_b64 + v_fmac_f64 pair hipcc emits for two literal coefficients.
+__device__ __forceinline__ double fast_exp2(double t, double c8_vgpr) {
+    constexpr double c[DLAGP_EXP_DEGREE + 1] = DLAGP_EXP2_COEF_INIT;
+    const double k = __builtin_rint(t);
+    const double f = t - k;
+    double p;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "s"(c[DLAGP_EXP_DEGREE]), "v"(f), "v"(c8_vgpr));
+#pragma unroll
+    for (int m = DLAGP_EXP_DEGREE - 2; m >= 0; --m) p = horner_sgpr(p, f, c[m]);
+    int ki;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(ki) : "v"(k));
+    return __builtin_amdgcn_ldexp(p, ki);
+}
+
+// a constant pinned in a vector register (opaque to the optimiser, so it is not folded back into a literal)
+__device__ __forceinline__ double vgpr_constant(double c) {
+    asm volatile("" : "+v"(c));
+    return c;
+}
+
 // Running product with explicit exponent: value = mant * 2^expo.  sum(log d_i) = log(mant) + expo ln2.
 // 750 multiplications lose < 1e-13 absolutely in the logarithm (against |log p| ~ 1e3).
 struct LogProduct {

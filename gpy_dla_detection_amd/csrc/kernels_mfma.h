@@ -80,8 +80,11 @@ __device__ __forceinline__ double wing_term(double x2, const double *__restrict_
 // unconditionally; if any lane of the wave sits within 16 Doppler widths of a line centre
 // (~6 entries per line and absorber) a wave-uniform branch swaps that lane's term for the
 // Taylor/table evaluation.
+// `w3v`: the wing polynomials' degree-3 coefficients of the first three lines in vector registers (LINES == 3
+// only): with one operand of the first Horner step in a VGPR that step is a single v_fma_f64.
 template <int LINES>
-__device__ __forceinline__ double optical_depth(double lam, const double *__restrict__ mult, int num_lines) {
+__device__ __forceinline__ double optical_depth(double lam, const double *__restrict__ mult, int num_lines,
+                                                const double *w3v = nullptr, const double *xs_in = nullptr) {
     const int L = LINES > 0 ? LINES : num_lines;
     const double x_offset = -DLAGP_LINES.c * DLAGP_LINES.inv_sqrt2_sigma;
     constexpr double split2 = DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT;
@@ -94,7 +97,7 @@ __device__ __forceinline__ double optical_depth(double lam, const double *__rest
         bool any_core = false;
 #pragma unroll
         for (int l = 0; l < 3; ++l) {
-            xs[l] = fma(lam, mult[l], x_offset);
+            xs[l] = xs_in ? xs_in[l] : fma(lam, mult[l], x_offset);
             const double x2 = xs[l] * xs[l];
             any_core |= !(x2 >= split2);  // also catches NaN
             xc[l] = fmax(x2, split2);
@@ -108,9 +111,11 @@ __device__ __forceinline__ double optical_depth(double lam, const double *__rest
 #pragma unroll
         for (int l = 0; l < 3; ++l) {
             const double *w = DLAGP_LINES.wing[l];
-            double poly = w[DLAGP_WING_DEGREE];
+            static_assert(DLAGP_WING_DEGREE == 4, "first Horner step below pairs the coefficients 4 and 3");
+            double poly;
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(poly) : "s"(w[4]), "v"(us[l]), "v"(w3v[l]));
 #pragma unroll
-            for (int m = DLAGP_WING_DEGREE - 1; m >= 0; --m) poly = fma(poly, us[l], w[m]);
+            for (int m = DLAGP_WING_DEGREE - 2; m >= 0; --m) poly = fma(poly, us[l], w[m]);
             tau = fma(us[l], poly, tau);
         }
         if (__builtin_amdgcn_ballot_w64(any_core)) {
@@ -355,14 +360,32 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                     // the sample's four constants {m'_0, m'_1, m'_2, N log2e} are one 32-byte LDS broadcast
                     // read, fetched one sample ahead so that the loop never waits on it
                     const v4d *sp4 = reinterpret_cast<const v4d *>(prep_lds) + jd;
-                    v4d cur = sp4[0];
+                    // The three line multipliers of the next sample are read right after their last use in this
+                    // one, into the same registers (no copies); the column density, needed until the end of the
+                    // body, rotates through one extra register pair.
+                    const v4d first = sp4[0];
+                    double m0 = first.x, m1 = first.y, m2 = first.z, ncol = first.w;
+                    const double x_offset = -DLAGP_LINES.c * DLAGP_LINES.inv_sqrt2_sigma;
+                    constexpr double exp2_coef[DLAGP_EXP_DEGREE + 1] = DLAGP_EXP2_COEF_INIT;
+                    const double c8v = vgpr_constant(exp2_coef[DLAGP_EXP_DEGREE - 1]);
+                    const double w3v[3] = {vgpr_constant(DLAGP_LINES.wing[0][3]), vgpr_constant(DLAGP_LINES.wing[1][3]),
+                                           vgpr_constant(DLAGP_LINES.wing[2][3])};
+                    // one running LDS address (hipcc otherwise rebuilds lane * 8 + offset for every sample)
+                    __attribute__((address_space(3))) double *raw_w = (__attribute__((address_space(3))) double *)raw + lane;
+                    asm volatile("" : "+v"(raw_w));
 #pragma unroll 1
                     for (int ss = 0; ss < 16; ++ss) {
-                        const v4d nxt = sp4[(ss < 15 ? ss + 1 : ss) * kd];
-                        const double m[3] = {cur.x, cur.y, cur.z};
-                        const double tau = optical_depth<LINES>(lam, m, 3);
-                        raw[ss * DLAGP_RAW_STRIDE + lane] = fast_exp2(-cur.w * tau);  // voigt.py:309
-                        cur = nxt;
+                        const double xs[3] = {fma(lam, m0, x_offset), fma(lam, m1, x_offset), fma(lam, m2, x_offset)};
+                        __builtin_amdgcn_sched_barrier(0);
+                        const v4d nxt = sp4[(ss + 1) * kd];  // the last read lands in the spare 17th row
+                        m0 = nxt.x;
+                        m1 = nxt.y;
+                        m2 = nxt.z;
+                        __builtin_amdgcn_sched_barrier(0);
+                        const double tau = optical_depth<LINES>(lam, nullptr, 3, w3v, xs);
+                        *raw_w = fast_exp2(-ncol * tau, c8v);  // voigt.py:309
+                        raw_w += DLAGP_RAW_STRIDE;
+                        ncol = nxt.w;
                     }
                 } else {
 #pragma unroll 2
