@@ -27,6 +27,11 @@ struct SightlineDev {
     int num_entries;  // E
     int num_lines;  // Lyman-series members
     int ntaps;      // 7 with instrumental broadening, 1 without
+    // The wavelength grid is finite, increasing and uniform in log10 to within 0.4 pixel (true for the
+    // reference's grids, null_gp.py:159-177): entry e sits at log10(lambda) = grid_log0 + e / grid_inv_dlog.
+    // Lets the MFMA kernel locate the few entries in a line core from the absorber redshift alone.
+    int grid_uniform;
+    double grid_log0, grid_inv_dlog;
     int lls_break;  // 1: add the Lyman-limit continuum opacity of every absorber (reference voigt_lls.py:258-284)
     int ntw;        // w-tiles: ceil(k (k + 1) / 2 / 16)
     int ntq;        // q-tiles: ceil(k / 16)
@@ -96,6 +101,11 @@ struct LineConstants {
     // far wing, everything folded: tau_l = u W_l(u), u = 1/x^2,
     // W_l(u) = k_wing [A(u) - y^2 u (1 + 5u + 26.25u^2)], A = near-minimax fit (faddeeva_table.h)
     double wing[DLAGP_MAX_LINES][6];
+    // 2^f on [-1/2, 1/2], degree-9 fit (faddeeva_table.h).  Kept here, in constant memory, rather than as
+    // literals: values that arrive through scalar loads stay in SGPRs and feed v_fma_f64 directly, whereas
+    // hipcc parks literal coefficients in VGPRs (a copy per Horner step) unless forced by inline asm, and
+    // every inline-asm statement costs an s_nop.
+    double exp2c[10];
     double inv_sqrt2_sigma;              // 1 / (sqrt2 sigma)
     double c;                            // speed of light, cm/s
 };

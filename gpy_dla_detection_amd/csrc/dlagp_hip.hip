@@ -55,6 +55,7 @@ static int64_t g_opt_pixel_splits = 0;
 static int64_t g_opt_path = 0;
 static int64_t g_opt_timing = 0;
 static int64_t g_opt_debug = 0;
+static int64_t g_opt_core_patch = 1;     // MFMA kernel: line cores repaired outside the sample loop when eligible
 static int64_t g_opt_profile_cache = 1;  // multi-level sweeps keep level-1 profiles in HBM (0 = recompute)
 static int64_t g_opt_profile_cache_max_mb = 98304;  // never take more than this for the cache  // bit 1: stamped instantiation of the MFMA kernel (diagnostics)
 
@@ -94,6 +95,11 @@ static int ensure_device(int device) {
         const double corr[6] = {0.0, 1.0, 5.0, 26.25, 0.0, 0.0};  // y^2 u (1 + 5u + 26.25u^2)
         for (int m = 0; m < 6; ++m)
             lc.wing[l][m] = m <= DLAGP_WING_DEGREE ? lc.k_wing[l] * (a[m] - y2 * corr[m]) : 0.0;
+    }
+    {
+        static_assert(DLAGP_EXP_DEGREE == 9, "LineConstants::exp2c holds ten coefficients");
+        const double e2[DLAGP_EXP_DEGREE + 1] = DLAGP_EXP2_COEF_INIT;
+        for (int m = 0; m <= DLAGP_EXP_DEGREE; ++m) lc.exp2c[m] = e2[m];
     }
     lc.inv_sqrt2_sigma = 1.0 / sqrt2_sigma;
     lc.c = DLAGP_SPEED_OF_LIGHT_CGS;
@@ -182,6 +188,7 @@ struct LaunchGroup {
     bool broadening = true;
     int max_entries = 0, max_npad = 0, max_chunks = 0;
     bool mfma_ok = false;
+    bool grid_uniform = false;  // every member's wavelength grid is log-uniform (core patch eligible)
     Workspace ws;
     std::map<int, std::unique_ptr<GroupPlan>> plans;
     void release() {
@@ -315,9 +322,23 @@ static int choose_splits(const LaunchGroup &g, int64_t S) {
 // ------------------------------------------------------------------------------------------------
 template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, GroupPlan *gp, int nsplit,
-                        long S, int kd, int num_lines, const SampleSource &src, double *part, int *status) {
+                        long S, int kd, int num_lines, const SampleSource &src, double *part, int *status,
+                        bool patch) {
     // 16 samples + one spare row that the look-ahead of the sample loop may read
     const size_t prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * kd * ((LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
+    if constexpr (LINES == 3) {
+        if (patch && !(g_opt_debug & 2)) {  // line cores repaired outside the sample loop (kd == 1, uniform grid)
+            if (src.cache_mode == 1)
+                hipLaunchKernelGGL((accumulate_mfma<3, BROADEN, false, 1, true>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds,
+                                   stream, table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(),
+                                   nsplit, S, kd, src, part, status, (int)g_opt_debug);
+            else
+                hipLaunchKernelGGL((accumulate_mfma<3, BROADEN, false, 0, true>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds,
+                                   stream, table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(),
+                                   nsplit, S, kd, src, part, status, (int)g_opt_debug);
+            return;
+        }
+    }
     if (src.cache_mode == 1) {  // level 1 of a cached multi-level sweep: also stores the profiles
         hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, false, 1>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
                            table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
@@ -378,6 +399,7 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
         const long groups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
         dim3 grid((unsigned)(groups * nsplit), (unsigned)nb);
         const bool lines3 = g.num_lines == 3;
+        const bool patch = lines3 && kd == 1 && g.grid_uniform && g_opt_core_patch != 0;
         double *part = ws.part.as<double>();
         if (src.cache_mode == 2) {
             hipLaunchKernelGGL((accumulate_mfma<3, true, false, 2>), grid, dim3(DLAGP_MFMA_THREADS),
@@ -385,11 +407,11 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
                                gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, (long)S,
                                kd, src, part, ws.status.as<int>(), 0);
         } else if (g.broadening) {
-            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>());
-            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>());
+            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), patch);
+            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), false);
         } else {
-            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>());
-            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>());
+            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), patch);
+            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), false);
         }
         HIP_TRY(hipGetLastError());
     } else {
@@ -519,7 +541,9 @@ static int finish_group(LaunchGroup &g) {
     g.num_lines = g.ctxs[0]->sl.num_lines;
     g.broadening = g.ctxs[0]->sl.ntaps > 1;
     g.mfma_ok = true;
+    g.grid_uniform = true;
     for (dlagp_ctx *ctx : g.ctxs) {
+        g.grid_uniform = g.grid_uniform && ctx->sl.grid_uniform;
         table.push_back(ctx->sl);
         g.max_entries = std::max(g.max_entries, ctx->sl.num_entries);
         g.max_npad = std::max(g.max_npad, ctx->sl.n_pad);
@@ -590,6 +614,23 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     for (int j = 0, i = 0; j < n_u; ++j)
         if (keep[j]) hpos[i++] = j;
     for (int i = n; i < sl.n_pad; ++i) hpos[i] = hpos[n - 1];
+    {
+        // finite, increasing, uniform in log10 to 0.4 entry?  (core patch of the MFMA kernel, kernels_mfma.h)
+        const int ne = sl.num_entries;
+        bool uniform = ne >= 2 && wavelengths[0] > 0.0 && std::isfinite(wavelengths[0]) && std::isfinite(wavelengths[ne - 1]);
+        const double log0 = uniform ? std::log10(wavelengths[0]) : 0.0;
+        const double dlog = uniform ? (std::log10(wavelengths[ne - 1]) - log0) / (ne - 1) : 0.0;
+        uniform = uniform && dlog > 0.0;
+        for (int e = 1; uniform && e < ne; ++e)
+            uniform = wavelengths[e] > wavelengths[e - 1] &&
+                      std::fabs((std::log10(wavelengths[e]) - log0) / dlog - e) <= 0.4;
+        sl.grid_uniform = uniform ? 1 : 0;
+        sl.grid_log0 = log0;
+        sl.grid_inv_dlog = uniform ? 1.0 / dlog : 0.0;
+        // the core half-width must stay below 3.1 entries for the 7-candidate window: 16 Doppler widths are
+        // 16 sqrt2 sigma / c ln10 = 2.98e-4 dex
+        if (uniform && 2.98e-4 / dlog > 3.1) sl.grid_uniform = 0;
+    }
     {
         std::vector<PassDesc> passes;
         std::vector<int2> splits;
@@ -1048,6 +1089,7 @@ int dlagp_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "path")) g_opt_path = value;
     else if (!strcmp(name, "timing")) g_opt_timing = value;
     else if (!strcmp(name, "debug")) g_opt_debug = value;
+    else if (!strcmp(name, "core_patch")) g_opt_core_patch = value;
     else if (!strcmp(name, "profile_cache")) g_opt_profile_cache = value;
     else if (!strcmp(name, "profile_cache_max_mb")) g_opt_profile_cache_max_mb = value;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);

@@ -81,6 +81,18 @@ __device__ __forceinline__ double fast_exp2(double t, double c8_vgpr) {
     return __builtin_amdgcn_ldexp(p, ki);
 }
 
+// 2^t with the coefficients read from `c` (constant memory -> SGPRs), `c8_vgpr` = c[8] in a vector register
+__device__ __forceinline__ double fast_exp2_table(double t, const double *__restrict__ c, double c8_vgpr) {
+    const double k = __builtin_rint(t);
+    const double f = t - k;
+    double p = fma(c[9], f, c8_vgpr);
+#pragma unroll
+    for (int m = 7; m >= 0; --m) p = fma(p, f, c[m]);
+    int ki;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(ki) : "v"(k));  // saturating: -inf / huge arguments give 2^INT_MIN = 0
+    return __builtin_amdgcn_ldexp(p, ki);
+}
+
 // a constant pinned in a vector register (opaque to the optimiser, so it is not folded back into a literal)
 __device__ __forceinline__ double vgpr_constant(double c) {
     asm volatile("" : "+v"(c));

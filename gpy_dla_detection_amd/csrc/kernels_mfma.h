@@ -82,7 +82,8 @@ __device__ __forceinline__ double wing_term(double x2, const double *__restrict_
 // Taylor/table evaluation.
 // `w3v`: the wing polynomials' degree-3 coefficients of the first three lines in vector registers (LINES == 3
 // only): with one operand of the first Horner step in a VGPR that step is a single v_fma_f64.
-template <int LINES>
+// CORE = false (3 lines only): no core test at all -- the caller repairs the core entries afterwards.
+template <int LINES, bool CORE = true>
 __device__ __forceinline__ double optical_depth(double lam, const double *__restrict__ mult, int num_lines,
                                                 const double *w3v = nullptr, const double *xs_in = nullptr) {
     const int L = LINES > 0 ? LINES : num_lines;
@@ -99,7 +100,7 @@ __device__ __forceinline__ double optical_depth(double lam, const double *__rest
         for (int l = 0; l < 3; ++l) {
             xs[l] = xs_in ? xs_in[l] : fma(lam, mult[l], x_offset);
             const double x2 = xs[l] * xs[l];
-            any_core |= !(x2 >= split2);  // also catches NaN
+            if (CORE) any_core |= !(x2 >= split2);  // also catches NaN
             xc[l] = fmax(x2, split2);
         }
         const double p01 = xc[0] * xc[1];
@@ -118,7 +119,7 @@ __device__ __forceinline__ double optical_depth(double lam, const double *__rest
             for (int m = DLAGP_WING_DEGREE - 2; m >= 0; --m) poly = fma(poly, us[l], w[m]);
             tau = fma(us[l], poly, tau);
         }
-        if (__builtin_amdgcn_ballot_w64(any_core)) {
+        if (CORE && __builtin_amdgcn_ballot_w64(any_core)) {
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 const double x = xs[l];
@@ -216,7 +217,18 @@ __device__ __forceinline__ void lds_wave_sync() {
 // MODE (profile cache of the multi-level sweep, SampleSource::cache): 0 = none; 1 = level 1, also stores the
 // convolved profiles; 2 = deeper levels, phase 1 multiplies cached rows instead of evaluating Voigt profiles
 // (LINES / BROADEN are then irrelevant: instantiated once, as <3, true, false, 2>).
-template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0>
+//
+// PATCH (LINES == 3, kd == 1, SightlineDev::grid_uniform): the line cores are taken out of the sample loop.
+// Within 16 Doppler widths of a line centre -- at most 6 consecutive entries per (sample, line) -- the far-
+// wing form does not hold and the Taylor/table evaluation (core_taylor) is needed.  Testing for that in
+// the loop costs three compares per sample and entry plus a wave-wide branch that is taken for ~7 % of the
+// (sample, pass) pairs with 1-6 active lanes -- 6 % of the kernel (ab/nocore experiment).
+// Instead the loop runs the wing form with clamped arguments everywhere, and the wave repairs the few
+// core entries afterwards: once per wave, for every (sample, line) whose centre lies in the wave's pixel
+// range, 7 candidate entries around the centre (located through the log-uniform grid) get a factor
+//   2^(-N log2e (tau_core - tau_clamped wing))   (1 outside the core)
+// computed 64 candidates at a time; every pass multiplies the factors that fall into its window into raw[].
+template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, bool PATCH = false>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
     const int2 *const *__restrict__ split_tables, int nsplit, long S, int kd,
@@ -226,7 +238,14 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     __shared__ double raw[16 * DLAGP_RAW_STRIDE];
     __shared__ double a_lds[16 * A_STRIDE];
     __shared__ int pos_lds[64];
+    constexpr int NPAIR_MAX = PATCH ? 48 : 1;  // (sample, line) pairs of a wave
+    constexpr int NCAND = 7;                   // candidate entries per pair, see below
+    __shared__ double patch_factor[NPAIR_MAX * NCAND];
+    __shared__ int patch_first[NPAIR_MAX];     // first candidate entry of an active pair
+    __shared__ int patch_sample[NPAIR_MAX];    // its sample (0..15)
+    __shared__ int patch_hit[NPAIR_MAX];       // per pass: active pairs touching the pass
     extern __shared__ double prep_lds[];
+    static_assert(!PATCH || (LINES == 3 && MODE != 2), "the core patch is written for the 3-line Voigt loop");
 
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = 0;  // finalize raises it
     const int b = blockIdx.y;
@@ -274,14 +293,77 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         long smp = sample0 + sample_abs / kd;
         smp = smp < S ? smp : S - 1;
         const int j = sample_abs % kd;
-        prep_lds[i] = which == L ? sample_nhi(src, b, smp, j, S, kd) * 1.44269504088896338700e+00
-                                 : line_multiplier(which, sample_z(src, b, smp, j, S, kd)) * DLAGP_LINES.inv_sqrt2_sigma;
+        const double zj = sample_z(src, b, smp, j, S, kd);
+        double value = which == L ? sample_nhi(src, b, smp, j, S, kd) * 1.44269504088896338700e+00
+                                  : line_multiplier(which, zj) * DLAGP_LINES.inv_sqrt2_sigma;
+        // a NaN redshift makes every line NaN, np.nansum drops them all and the profile is 1 (voigt.py:309):
+        // without the in-loop NaN test that is a zero column density
+        if (PATCH && which == L && !(zj == zj)) value = 0.0;
+        prep_lds[i] = value;
     }
 
     const PassDesc *passes = pass_tables[b];
     const int2 span_v = split_tables[b][split];  // passes [x, y)
     const int pass_begin = __builtin_amdgcn_readfirstlane(span_v.x);
     const int pass_end = __builtin_amdgcn_readfirstlane(span_v.y);
+
+    // ---------------- core patch factors of this wave (PATCH) ----------------
+    int npatch = 0;  // active (sample, line) pairs, wave-uniform
+    if constexpr (PATCH) {
+        lds_wave_sync();  // per-sample constants visible
+        const double x_offset = -DLAGP_LINES.c * DLAGP_LINES.inv_sqrt2_sigma;
+        const int first_entry = passes[pass_begin].entry_start;
+        const int last_entry = passes[pass_end - 1].entry_start + DLAGP_PASS_ENTRIES - 1;
+        // lane p < 48 owns pair (sample p / 3, line p % 3): centre of the line in entry units.
+        // x = lambda m' + x_offset vanishes at lambda_c = -x_offset / m'; candidates are the 7 entries inside
+        // (e_c - 3.5, e_c + 3.5): the core half-width is 16 / 5.37 = 2.98 entries at 1e-4 dex, and the grid
+        // may deviate from uniformity by 0.4 entry (checked in dlagp_create).
+        bool active = false;
+        int cand0 = 0;
+        if (lane < 48) {
+            const double m = prep_lds[(lane / 3) * prep_stride + lane % 3];
+            const double e_c = (log10(-x_offset / m) - sl.grid_log0) * sl.grid_inv_dlog;
+            if (e_c > -16.0 && e_c < 1.0e9) {  // finite, and not absurdly far bluewards of the grid
+                cand0 = (int)floor(e_c - 3.5) + 1;
+                active = cand0 + NCAND - 1 >= first_entry && cand0 <= last_entry;
+            }
+        }
+        const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
+        npatch = __builtin_popcountll(amask);
+        if (active) {
+            const int rank = __builtin_popcountll(amask & ((1ull << lane) - 1));
+            patch_first[rank] = cand0;
+            patch_sample[rank] = lane / 3 | (lane % 3) << 8;
+        }
+        lds_wave_sync();
+        for (int base = 0; base < npatch * NCAND; base += 64) {
+            const int item = base + lane;
+            if (item < npatch * NCAND) {
+                const int rank = item / NCAND, j = item % NCAND;
+                const int packed = patch_sample[rank];
+                const int ss = packed & 255, l = packed >> 8;
+                const int e = patch_first[rank] + j;
+                const int e_load = e < 0 ? 0 : (e < num_entries ? e : num_entries - 1);
+                const double m = prep_lds[ss * prep_stride + l];
+                const double x = fma(lam_ptr[e_load], m, x_offset);  // the loop's expression, bit for bit
+                double factor = 1.0;
+                if (e == e_load && !(x * x >= DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT)) {
+                    // what the loop put there: the wing form at the clamped argument u = 1 / 256
+                    constexpr double u_c = 1.0 / (DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT);
+                    const double *w = DLAGP_LINES.wing[l];
+                    double poly = w[DLAGP_WING_DEGREE];
+#pragma unroll
+                    for (int q = DLAGP_WING_DEGREE - 1; q >= 0; --q) poly = fma(poly, u_c, w[q]);
+                    const double core = DLAGP_LINES.k_core[l] * core_taylor(x, DLAGP_LINES.y[l]);
+                    // a NaN core term is dropped (np.nansum): only the clamped wing term is taken back out
+                    const double delta = (core == core ? core : 0.0) - u_c * poly;
+                    factor = fast_exp2(-prep_lds[ss * prep_stride + 3] * delta);
+                }
+                patch_factor[item] = factor;
+            }
+        }
+        lds_wave_sync();
+    }
 
     d4 acc[DLAGP_MFMA_NT];
 #pragma unroll
@@ -366,8 +448,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                     const v4d first = sp4[0];
                     double m0 = first.x, m1 = first.y, m2 = first.z, ncol = first.w;
                     const double x_offset = -DLAGP_LINES.c * DLAGP_LINES.inv_sqrt2_sigma;
-                    constexpr double exp2_coef[DLAGP_EXP_DEGREE + 1] = DLAGP_EXP2_COEF_INIT;
-                    const double c8v = vgpr_constant(exp2_coef[DLAGP_EXP_DEGREE - 1]);
+                    const double c8v = vgpr_constant(DLAGP_LINES.exp2c[8]);
                     const double w3v[3] = {vgpr_constant(DLAGP_LINES.wing[0][3]), vgpr_constant(DLAGP_LINES.wing[1][3]),
                                            vgpr_constant(DLAGP_LINES.wing[2][3])};
                     // one running LDS address (hipcc otherwise rebuilds lane * 8 + offset for every sample)
@@ -382,8 +463,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                         m1 = nxt.y;
                         m2 = nxt.z;
                         __builtin_amdgcn_sched_barrier(0);
-                        const double tau = optical_depth<LINES>(lam, nullptr, 3, w3v, xs);
-                        *raw_w = fast_exp2(-ncol * tau, c8v);  // voigt.py:309
+                        const double tau = optical_depth<LINES, !PATCH>(lam, nullptr, 3, w3v, xs);
+                        *raw_w = fast_exp2_table(-ncol * tau, DLAGP_LINES.exp2c, c8v);  // voigt.py:309
                         raw_w += DLAGP_RAW_STRIDE;
                         ncol = nxt.w;
                     }
@@ -402,6 +483,28 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 }
                 if (jd == 0) pos_lds[lane] = (int)my_pos_f - entry_start;
                 lds_wave_sync();
+                if constexpr (PATCH) {
+                    // multiply the core factors that fall into this pass's 64 entries into raw[] (see the kernel header)
+                    const int mine = patch_first[lane < npatch ? lane : 0];
+                    const bool hit = lane < npatch && mine + NCAND - 1 >= entry_start && mine < entry_start + DLAGP_PASS_ENTRIES;
+                    const unsigned long long hmask = __builtin_amdgcn_ballot_w64(hit);
+                    if (hmask) {
+                        if (hit) patch_hit[__builtin_popcountll(hmask & ((1ull << lane) - 1))] = lane;
+                        lds_wave_sync();
+                        const int nitems = __builtin_popcountll(hmask) * NCAND;
+                        for (int base = 0; base < nitems; base += 64) {
+                            const int item = base + lane;
+                            if (item < nitems) {
+                                const int rank = patch_hit[item / NCAND], j = item % NCAND;
+                                const int rel = patch_first[rank] + j - entry_start;
+                                const double factor = patch_factor[rank * NCAND + j];
+                                if (rel >= 0 && rel < DLAGP_PASS_ENTRIES && factor != 1.0)
+                                    raw[(patch_sample[rank] & 255) * DLAGP_RAW_STRIDE + rel] *= factor;
+                            }
+                        }
+                        lds_wave_sync();
+                    }
+                }
                 // convolution (voigt.py:319) on the kept pixels (dla_gp.py:388), product over absorbers.
                 // Always all 14 steps, branch-free, so that the LDS reads of different steps overlap:
                 // lanes beyond the pass's pixels re-read a valid window and write unused slots.

@@ -214,6 +214,9 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
  *                     kernel, 2 = MFMA kernel), "timing" (1 = bracket the accumulate kernel
  *                     of every launch with HIP events on its stream), "debug" (bit 1: launch the
  *                     stamped instantiation of the MFMA kernel, see dlagp_debug_read),
+ *                     "core_patch" (1 = the MFMA kernel evaluates the line cores outside its sample
+ *                     loop when it can: 3 lines, 1 absorber per sample, log-uniform wavelength grid;
+ *                     0 = always test for them inside the loop),
  *                     "profile_cache" (1 = dlagp_batch_sweep keeps the level-1 absorption profiles
  *                     of all QMC points in HBM, 8 S n_pad bytes per sightline, and multiplies cached
  *                     rows at the deeper levels instead of re-evaluating Voigt profiles; 0 = recompute),

@@ -331,6 +331,7 @@ def restore_options():
     set_option("path", 0)
     set_option("pixel_splits", 0)
     set_option("profile_cache", 1)
+    set_option("core_patch", 1)
 
 
 @pytest.mark.parametrize("shape", [dict(index=4, n_unmasked=1250, n_masked=28, k=20),
@@ -688,3 +689,49 @@ def test_lls_gp_class_runs_the_sweep_with_the_break():
     z, _, nhi = make_qmc_samples(sight, 4)
     # this synthetic grid lies redwards of every absorber's limit: the break adds nothing there
     np.testing.assert_allclose(lls.device_sightline().eval(z, nhi), dla.device_sightline().eval(z, nhi), rtol=1e-11)
+
+
+def test_core_patch_equals_in_loop_core_test(restore_options):
+    """
+    kd = 1 on a log-uniform grid runs the MFMA kernel that repairs the line cores outside its sample loop;
+    option core_patch = 0 keeps the test inside the loop.  Same numbers, including samples whose line
+    centres sit on the first / last entries, outside the grid, and NaN / infinite redshifts.
+    """
+    from oracle import ref_like as R
+
+    set_option = restore_options
+    sight = make_sightline(2)
+    dev = device_sightline(sight)
+    z, _, nhi = make_qmc_samples(sight, 4096)
+    lam = sight.padded_wavelengths
+    lines = np.array([1215.6701, 1025.7223, 972.5368])
+    special = []
+    for e in (0, 1, 2, 3, 4, 5, 6, lam.shape[0] - 1, lam.shape[0] - 2, lam.shape[0] - 4, 1500):
+        for line in lines:                       # line centre exactly on / between chosen entries
+            special += [lam[e] / line - 1.0, np.sqrt(lam[e] * lam[min(e + 1, lam.shape[0] - 1)]) / line - 1.0]
+    special += [lam[0] / lines[0] - 1.0 - 0.002, lam[-1] / lines[0] - 1.0 + 0.002, 0.0, 9.0, -0.5, np.nan, np.inf]
+    z = np.concatenate([z, special])
+    nhi = np.concatenate([nhi, np.resize([1e20, 3e21, 1e23], len(special))])
+    set_option("path", 2)
+    got = dev.eval(z, nhi)
+    set_option("core_patch", 0)
+    want = dev.eval(z, nhi)
+    finite = np.isfinite(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    # the repaired entries carry two roundings of 2^t (|t| up to ~1e3) instead of one: ~1e-12 in the total
+    np.testing.assert_allclose(got[finite], want[finite], rtol=2e-11)
+    assert abs(got[-2] - dev.null()) <= 1e-12 * abs(dev.null())   # NaN redshift: no absorber at all
+    st = oracle_state(sight)
+    pick = np.r_[0:8, len(z) - len(special):len(z) - 2]
+    ref = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in pick])
+    np.testing.assert_allclose(got[pick], ref, rtol=RTOL_LL)
+    # a grid that is not log-uniform silently takes the in-loop kernel
+    set_option("core_patch", 1)
+    warped = lam * (1 + 3e-4 * np.sin(np.arange(lam.shape[0]) / 90.0))
+    from gpy_dla_detection_amd.sightline import DeviceSightline
+
+    dev_w = DeviceSightline(sight.y, sight.this_mu, sight.this_M, sight.this_omega2, sight.v, warped, sight.keep)
+    got_w = dev_w.eval(z[:64], nhi[:64])
+    st.padded_wavelengths = warped
+    ref_w = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in range(8)])
+    np.testing.assert_allclose(got_w[:8], ref_w, rtol=RTOL_LL)
