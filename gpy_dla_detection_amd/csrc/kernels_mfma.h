@@ -82,7 +82,8 @@ __device__ __forceinline__ double wing_term(double x2, const double *__restrict_
 // Taylor/table evaluation.
 // `w3v`: the wing polynomials' degree-3 coefficients of the first three lines in vector registers (LINES == 3
 // only): with one operand of the first Horner step in a VGPR that step is a single v_fma_f64.
-// CORE = false (3 lines only): no core test at all -- the caller repairs the core entries afterwards.
+// CORE = false (3 lines only): no core test and no clamping at all -- a lane inside a line core produces
+// garbage (its shared reciprocal overflows) and the caller overwrites that entry afterwards.
 template <int LINES, bool CORE = true>
 __device__ __forceinline__ double optical_depth(double lam, const double *__restrict__ mult, int num_lines,
                                                 const double *w3v = nullptr, const double *xs_in = nullptr) {
@@ -101,7 +102,7 @@ __device__ __forceinline__ double optical_depth(double lam, const double *__rest
             xs[l] = xs_in ? xs_in[l] : fma(lam, mult[l], x_offset);
             const double x2 = xs[l] * xs[l];
             if (CORE) any_core |= !(x2 >= split2);  // also catches NaN
-            xc[l] = fmax(x2, split2);
+            xc[l] = CORE ? fmax(x2, split2) : x2;
         }
         const double p01 = xc[0] * xc[1];
         const double r = fast_rcp1(p01 * xc[2]);
@@ -223,11 +224,12 @@ __device__ __forceinline__ void lds_wave_sync() {
 // wing form does not hold and the Taylor/table evaluation (core_taylor) is needed.  Testing for that in
 // the loop costs three compares per sample and entry plus a wave-wide branch that is taken for ~7 % of the
 // (sample, pass) pairs with 1-6 active lanes -- 6 % of the kernel (ab/nocore experiment).
-// Instead the loop runs the wing form with clamped arguments everywhere, and the wave repairs the few
-// core entries afterwards: once per wave, for every (sample, line) whose centre lies in the wave's pixel
-// range, 7 candidate entries around the centre (located through the log-uniform grid) get a factor
-//   2^(-N log2e (tau_core - tau_clamped wing))   (1 outside the core)
-// computed 64 candidates at a time; every pass multiplies the factors that fall into its window into raw[].
+// Instead the loop runs the bare wing form everywhere (no test, no clamp: core entries come out as garbage),
+// and the wave replaces the few core entries afterwards: once per wave, for every (sample, line) whose
+// centre lies in the wave's pixel range, the 7 candidate entries around the centre (located through the
+// log-uniform grid) are examined 64 at a time and those inside the core get their exact profile value
+// 2^(-N log2e tau) (core form for that line, wing form for the other two); every pass copies the values
+// that fall into its window over raw[].
 template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, bool PATCH = false>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     __shared__ int pos_lds[64];
     constexpr int NPAIR_MAX = PATCH ? 48 : 1;  // (sample, line) pairs of a wave
     constexpr int NCAND = 7;                   // candidate entries per pair, see below
-    __shared__ double patch_factor[NPAIR_MAX * NCAND];
+    __shared__ double patch_factor[NPAIR_MAX * NCAND];  // exact profile value of a core entry, -1 elsewhere
     __shared__ int patch_first[NPAIR_MAX];     // first candidate entry of an active pair
     __shared__ int patch_sample[NPAIR_MAX];    // its sample (0..15)
     __shared__ int patch_hit[NPAIR_MAX];       // per pass: active pairs touching the pass
@@ -298,7 +300,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                                   : line_multiplier(which, zj) * DLAGP_LINES.inv_sqrt2_sigma;
         // a NaN redshift makes every line NaN, np.nansum drops them all and the profile is 1 (voigt.py:309):
         // without the in-loop NaN test that is a zero column density
-        if (PATCH && which == L && !(zj == zj)) value = 0.0;
+        // (and a finite multiplier, so that the optical depth the zero multiplies is finite)
+        if (PATCH && !(zj == zj)) value = 0.0;
         prep_lds[i] = value;
     }
 
@@ -344,20 +347,20 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 const int ss = packed & 255, l = packed >> 8;
                 const int e = patch_first[rank] + j;
                 const int e_load = e < 0 ? 0 : (e < num_entries ? e : num_entries - 1);
-                const double m = prep_lds[ss * prep_stride + l];
-                const double x = fma(lam_ptr[e_load], m, x_offset);  // the loop's expression, bit for bit
-                double factor = 1.0;
+                const double lam_e = lam_ptr[e_load];
+                const double *mrow = prep_lds + ss * prep_stride;
+                const double x = fma(lam_e, mrow[l], x_offset);  // the loop's expression, bit for bit
+                double factor = -1.0;  // marks "not a core entry" (profile values are >= 0)
                 if (e == e_load && !(x * x >= DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT)) {
-                    // what the loop put there: the wing form at the clamped argument u = 1 / 256
-                    constexpr double u_c = 1.0 / (DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT);
-                    const double *w = DLAGP_LINES.wing[l];
-                    double poly = w[DLAGP_WING_DEGREE];
-#pragma unroll
-                    for (int q = DLAGP_WING_DEGREE - 1; q >= 0; --q) poly = fma(poly, u_c, w[q]);
                     const double core = DLAGP_LINES.k_core[l] * core_taylor(x, DLAGP_LINES.y[l]);
-                    // a NaN core term is dropped (np.nansum): only the clamped wing term is taken back out
-                    const double delta = (core == core ? core : 0.0) - u_c * poly;
-                    factor = fast_exp2(-prep_lds[ss * prep_stride + 3] * delta);
+                    double tau = core == core ? core : 0.0;  // a NaN term is dropped (np.nansum, voigt.py:309)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double xk = fma(lam_e, mrow[k], x_offset);
+                        const double wing = wing_term(xk * xk, DLAGP_LINES.wing[k]);
+                        if (k != l) tau += wing;  // Lyman lines are > 40 A apart: never two cores at one entry
+                    }
+                    factor = fast_exp2(-mrow[3] * tau);
                 }
                 patch_factor[item] = factor;
             }
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 if (jd == 0) pos_lds[lane] = (int)my_pos_f - entry_start;
                 lds_wave_sync();
                 if constexpr (PATCH) {
-                    // multiply the core factors that fall into this pass's 64 entries into raw[] (see the kernel header)
+                    // copy the core values that fall into this pass's 64 entries over raw[] (see the kernel header)
                     const int mine = patch_first[lane < npatch ? lane : 0];
                     const bool hit = lane < npatch && mine + NCAND - 1 >= entry_start && mine < entry_start + DLAGP_PASS_ENTRIES;
                     const unsigned long long hmask = __builtin_amdgcn_ballot_w64(hit);
@@ -497,9 +500,9 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                             if (item < nitems) {
                                 const int rank = patch_hit[item / NCAND], j = item % NCAND;
                                 const int rel = patch_first[rank] + j - entry_start;
-                                const double factor = patch_factor[rank * NCAND + j];
-                                if (rel >= 0 && rel < DLAGP_PASS_ENTRIES && factor != 1.0)
-                                    raw[(patch_sample[rank] & 255) * DLAGP_RAW_STRIDE + rel] *= factor;
+                                const double value = patch_factor[rank * NCAND + j];
+                                if (rel >= 0 && rel < DLAGP_PASS_ENTRIES && !(value < 0.0))
+                                    raw[(patch_sample[rank] & 255) * DLAGP_RAW_STRIDE + rel] = value;
                             }
                         }
                         lds_wave_sync();
