@@ -528,7 +528,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                             const double *win = raw_row + pos_lds[st * DLAGP_STEP_PIXELS + slot];
 #pragma unroll
                             for (int t = 0; t < NW; ++t) wv[u][t] = win[t];
-                            prev[u] = a_dst[st * DLAGP_STEP_PIXELS];
+                            if (!PATCH) prev[u] = a_dst[st * DLAGP_STEP_PIXELS];  // PATCH implies one absorber
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -544,7 +544,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                                 conv = fma(wv[u][2] + wv[u][4], tap[2], conv);
                                 conv = fma(wv[u][3], tap[3], conv);
                             }
-                            a_dst[st * DLAGP_STEP_PIXELS] = jd == 0 ? conv : prev[u] * conv;
+                            if constexpr (PATCH) a_dst[st * DLAGP_STEP_PIXELS] = conv;
+                            else a_dst[st * DLAGP_STEP_PIXELS] = jd == 0 ? conv : prev[u] * conv;
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
