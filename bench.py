@@ -127,11 +127,13 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--splits", type=int, default=0, help=argparse.SUPPRESS)  # tuning: force the pixel-split count
     ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)  # 2: per-phase cycle stamps (diagnostic)
+    # rehearsal of the N > 1 code path on a one-GPU box: every rank on device 0, gloo instead of RCCL
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
 
     from gpy_dla_detection_amd import sightline as sl
     from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline
@@ -158,7 +160,10 @@ def main() -> None:
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     dev = sl.DeviceSightline.from_state(sight, device=local_rank)
     if args.splits:
@@ -168,16 +173,27 @@ def main() -> None:
     z = torch.from_numpy(z_host).to(device)
     nhi = torch.from_numpy(nhi_host).to(device)
     out = torch.empty(S, dtype=torch.float64, device=device)
-    evidence = torch.zeros(1, dtype=torch.float64, device=device)
-    gathered = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+    # a small ring of result slots: the all-gather of step i may still be reading its slot while step i + 1 runs
+    RING = 4
+    evidences = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(RING)]
+    gathered = [[torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)] for _ in range(RING)]
+    in_flight = [None] * RING
+    counter = [0]
+    evidence = evidences[0]
 
-    def step():
+    def step(collective=True):
+        slot = counter[0] % RING
+        counter[0] += 1
+        if in_flight[slot] is not None:
+            in_flight[slot].wait()
+            in_flight[slot] = None
         stream = torch.cuda.current_stream().cuda_stream
         dev.eval_device(S, 1, z.data_ptr(), nhi.data_ptr(), out.data_ptr(), stream)
         # "- log S" and the log-mean-exp model evidence of the level (reference dla_gp.py:155-190)
-        sl.level_evidence_device(out.data_ptr(), 1, S, 0, evidence.data_ptr(), device=local_rank, stream=stream)
-        if world > 1:
-            return dist.all_gather(gathered, evidence, async_op=True)
+        sl.level_evidence_device(out.data_ptr(), 1, S, 0, evidences[slot].data_ptr(), device=local_rank, stream=stream)
+        if world > 1 and collective:
+            in_flight[slot] = dist.all_gather(gathered[slot], evidences[slot], async_op=True)
+            return in_flight[slot]
         return None
 
     def fence():
@@ -189,12 +205,11 @@ def main() -> None:
     # The GPU leaves its idle power state only after tens of milliseconds of load: the first ~40 steps run
     # ~12 % slower than the sustained rate (profiles/r01_clock_ramp.txt).  Untimed steps until the device
     # has been busy for --ramp-ms, then the W warmup steps the contract asks for, then exactly K timed steps.
+    # (local work only: the loop is time-based, so ranks may run different numbers of iterations)
     ramp_start = time.perf_counter()
     while (time.perf_counter() - ramp_start) * 1e3 < args.ramp_ms:
         for _ in range(10):
-            work = step()
-            if work is not None:
-                work.wait()
+            step(collective=False)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         work = step()
@@ -203,14 +218,12 @@ def main() -> None:
     fence()
     sl.set_option("timing", 1)
     sl.timing_read(reset=True)
-    pending = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        work = step()
+        step()
+    for work in in_flight:
         if work is not None:
-            pending.append(work)
-    for work in pending:
-        work.wait()
+            work.wait()
     fence()
     elapsed = time.perf_counter() - t0
     sl.set_option("timing", 0)
