@@ -115,20 +115,67 @@ static int ensure_device(int device) {
 // ------------------------------------------------------------------------------------------------
 // device buffers
 // ------------------------------------------------------------------------------------------------
+// Released buffers are parked per (device, size) and handed out again: a catalogue run creates and
+// destroys thousands of contexts of a few distinct sizes, and hipMalloc / hipFree (which synchronises the
+// device) were a quarter of its wall time.  At most g_opt_pool_mb are parked (option "pool_mb", 0 = off);
+// only buffers up to 64 MB take part (the big sweep workspaces stay with their launch group anyway).
+static std::mutex g_pool_mutex;
+static std::map<std::pair<int, size_t>, std::vector<void *>> g_pool;
+static size_t g_pool_bytes = 0;
+static int64_t g_opt_pool_mb = 2048;
+
+static void pool_flush() {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    int current = 0;
+    (void)hipGetDevice(&current);
+    for (auto &kv : g_pool) {
+        (void)hipSetDevice(kv.first.first);
+        for (void *p : kv.second) (void)hipFree(p);
+    }
+    g_pool.clear();
+    g_pool_bytes = 0;
+    (void)hipSetDevice(current);
+}
+
 struct DeviceBuffer {
     void *ptr = nullptr;
     size_t bytes = 0;
+    static constexpr size_t kPoolMaxBuffer = (size_t)64 << 20;
     int reserve(size_t want) {
         if (want <= bytes) return DLAGP_OK;
-        if (ptr) (void)hipFree(ptr);
-        ptr = nullptr;
-        bytes = 0;
+        release();
+        int device = 0;
+        HIP_TRY(hipGetDevice(&device));
+        if (want <= kPoolMaxBuffer) {
+            std::lock_guard<std::mutex> lock(g_pool_mutex);
+            auto it = g_pool.find({device, want});
+            if (it != g_pool.end() && !it->second.empty()) {
+                ptr = it->second.back();
+                it->second.pop_back();
+                g_pool_bytes -= want;
+                bytes = want;
+                return DLAGP_OK;
+            }
+        }
         HIP_TRY(hipMalloc(&ptr, want));
         bytes = want;
         return DLAGP_OK;
     }
     void release() {
-        if (ptr) (void)hipFree(ptr);
+        if (!ptr) return;
+        bool parked = false;
+        if (bytes <= kPoolMaxBuffer) {
+            int device = 0;
+            if (hipGetDevice(&device) == hipSuccess) {
+                std::lock_guard<std::mutex> lock(g_pool_mutex);
+                if (g_pool_bytes + bytes <= (size_t)std::max<int64_t>(g_opt_pool_mb, 0) << 20) {
+                    g_pool[{device, bytes}].push_back(ptr);
+                    g_pool_bytes += bytes;
+                    parked = true;
+                }
+            }
+        }
+        if (!parked) (void)hipFree(ptr);
         ptr = nullptr;
         bytes = 0;
     }
@@ -164,6 +211,9 @@ struct Workspace {
         out.release();
     }
 };
+
+static std::mutex g_spare_mutex;
+static std::map<int, Workspace> g_spare_workspace;  // per device: workspace of the last destroyed batch
 
 // pass / split tables of one sightline for one split count (MFMA path)
 struct SightlinePlan {
@@ -967,6 +1017,14 @@ int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
     dlagp_batch *batch = new dlagp_batch();
     batch->group.device = ctxs[0]->device;
     batch->group.ctxs.assign(ctxs, ctxs + nb);
+    {  // adopt the workspace the previous batch on this device left behind (see dlagp_batch_destroy)
+        std::lock_guard<std::mutex> lock(g_spare_mutex);
+        auto it = g_spare_workspace.find(batch->group.device);
+        if (it != g_spare_workspace.end()) {
+            batch->group.ws = it->second;
+            g_spare_workspace.erase(it);
+        }
+    }
     int rc = finish_group(batch->group);
     if (rc) {
         dlagp_batch_destroy(batch);
@@ -979,6 +1037,24 @@ int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
 void dlagp_batch_destroy(dlagp_batch *batch) {
     if (!batch) return;
     (void)hipSetDevice(batch->group.device);
+    // A catalogue run builds one batch after the other: the sweep workspace (partial sums, profile cache --
+    // gigabytes) is handed to the next batch of this device instead of being freed and allocated again.
+    // One workspace per device is kept; option "pool_mb" = 0 turns this off as well.
+    Workspace keep{};
+    bool parked = false;
+    if (g_opt_pool_mb > 0) {
+        std::lock_guard<std::mutex> lock(g_spare_mutex);
+        auto it = g_spare_workspace.find(batch->group.device);
+        if (it != g_spare_workspace.end()) {
+            keep = it->second;  // the older spare goes
+            it->second = batch->group.ws;
+        } else {
+            g_spare_workspace[batch->group.device] = batch->group.ws;
+        }
+        batch->group.ws = Workspace{};
+        parked = true;
+    }
+    if (parked) keep.release();
     batch->group.release();
     delete batch;
 }
@@ -1090,6 +1166,18 @@ int dlagp_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "timing")) g_opt_timing = value;
     else if (!strcmp(name, "debug")) g_opt_debug = value;
     else if (!strcmp(name, "core_patch")) g_opt_core_patch = value;
+    else if (!strcmp(name, "pool_mb")) {
+        g_opt_pool_mb = value;
+        if (value <= 0) {
+            pool_flush();
+            std::lock_guard<std::mutex> lock(g_spare_mutex);
+            for (auto &kv : g_spare_workspace) {
+                (void)hipSetDevice(kv.first);
+                kv.second.release();
+            }
+            g_spare_workspace.clear();
+        }
+    }
     else if (!strcmp(name, "profile_cache")) g_opt_profile_cache = value;
     else if (!strcmp(name, "profile_cache_max_mb")) g_opt_profile_cache_max_mb = value;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);

@@ -217,6 +217,9 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
  *                     "core_patch" (1 = the MFMA kernel evaluates the line cores outside its sample
  *                     loop when it can: 3 lines, 1 absorber per sample, log-uniform wavelength grid;
  *                     0 = always test for them inside the loop),
+ *                     "pool_mb" (device buffers of destroyed contexts are parked, up to this many MB,
+ *                     and reused by later contexts of the same size instead of hipFree / hipMalloc;
+ *                     default 2048, 0 frees everything parked and turns the pool off),
  *                     "profile_cache" (1 = dlagp_batch_sweep keeps the level-1 absorption profiles
  *                     of all QMC points in HBM, 8 S n_pad bytes per sightline, and multiplies cached
  *                     rows at the deeper levels instead of re-evaluating Voigt profiles; 0 = recompute),
