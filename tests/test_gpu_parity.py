@@ -735,3 +735,23 @@ def test_core_patch_equals_in_loop_core_test(restore_options):
     st.padded_wavelengths = warped
     ref_w = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in range(8)])
     np.testing.assert_allclose(got_w[:8], ref_w, rtol=RTOL_LL)
+
+
+@pytest.mark.parametrize("S,max_dlas,nb", [(1, 1, 1), (5, 2, 1), (17, 3, 2), (64, 8, 1), (1030, 2, 3)])
+def test_device_sweep_shapes(S, max_dlas, nb, restore_options):
+    """odd sample counts (below / across the 16-sample groups and the 1024-thread scan), deep and shallow sweeps"""
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    sights = [make_sightline(10 + i, n_unmasked=230 + 17 * i, n_masked=3 + i) for i in range(nb)]
+    batch = DeviceBatch([device_sightline(s) for s in sights])
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    min_sep = 3000.0 * 1000.0 / 299792458.0
+    want = parallel.sweep_batch(batch.eval, zs, nhi, max_dlas, min_sep, seed=11)
+    got = parallel.sweep_batch_device(batch, zs, nhi, max_dlas, min_sep, seed=11)
+    np.testing.assert_array_equal(got[2], want[2])
+    assert np.array_equal(np.isnan(got[1]), np.isnan(want[1]))
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-11, equal_nan=True)
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-11, equal_nan=True)
+    assert got[0].shape == (nb, max_dlas) and got[1].shape == (nb, S, max_dlas) and got[2].shape == (nb, max(max_dlas - 1, 0), S)
