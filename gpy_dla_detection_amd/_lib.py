@@ -44,6 +44,7 @@ SIGNATURES = {
     "dlagp_batch_destroy": (None, [c_void_p]),
     "dlagp_batch_eval_device": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dlagp_batch_eval": (c_int, [c_void_p, c_int64, c_int, _dp, _dp, _dp]),
+    "dlagp_batch_null": (c_int, [c_void_p, _dp]),
     "dlagp_batch_sweep": (c_int, [c_void_p, c_int64, c_int, _dp, _dp, c_int64, c_double, _dp, _dp, _dp,
                                   POINTER(ctypes.c_int32)]),
     "dlagp_batch_sweep_device": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_double, c_void_p,

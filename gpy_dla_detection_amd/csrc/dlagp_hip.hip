@@ -185,6 +185,27 @@ struct DeviceBuffer {
     }
 };
 
+// Page-locked host memory for the host-pointer entry points.  hipMemcpy to or from ordinary (pageable)
+// caller memory makes the runtime pin and later unpin the caller's pages; for freshly allocated arrays
+// of a few MB (NumPy results) that left ~20 ms of runtime work behind every sweep, paid by the next call.
+// Transfers of more than 64 KB therefore go through this buffer (one extra CPU copy, ~10 GB/s).
+struct PinnedBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t want) {
+        if (want <= bytes) return DLAGP_OK;
+        release();
+        HIP_TRY(hipHostMalloc(&ptr, want, hipHostMallocDefault));
+        bytes = want;
+        return DLAGP_OK;
+    }
+    void release() {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+};
+
 // scratch shared by the launches of one launch group
 struct Workspace {
     DeviceBuffer part;    // partial rows [nsplit][rows][row_width]
@@ -194,7 +215,9 @@ struct Workspace {
     // and staging of its host-pointer variant
     DeviceBuffer level_ll, cdf, alive, uniforms, evidences, sample_ll, base;
     DeviceBuffer cache, running;  // profile cache / running products of the multi-level sweep, [nb][S][max n_pad]
+    PinnedBuffer stage;           // host staging of the host-pointer entry points
     void release() {
+        stage.release();
         cache.release();
         running.release();
         level_ll.release();
@@ -500,6 +523,62 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
     return DLAGP_OK;
 }
 
+// One batch of host <-> device transfers through the workspace's pinned staging buffer.
+//   add(): registers a transfer and returns nothing; run_uploads() copies host -> stage -> device (async on
+//   the null stream, the stage is not reused before the final synchronisation); run_downloads() enqueues
+//   device -> stage, synchronises the device once and copies stage -> host.  Small transfers use hipMemcpy.
+struct Transfers {
+    struct Item {
+        void *device;
+        void *host;
+        size_t bytes;
+        size_t offset;
+    };
+    PinnedBuffer &stage;
+    std::vector<Item> up, down;
+    size_t total = 0;
+    static constexpr size_t kDirect = 64 * 1024;
+    explicit Transfers(PinnedBuffer &s) : stage(s) {}
+    void upload(void *device, const void *host, size_t bytes) {
+        if (bytes) up.push_back({device, const_cast<void *>(host), bytes, 0});
+    }
+    void download(void *host, const void *device, size_t bytes) {
+        if (bytes && host) down.push_back({const_cast<void *>(device), host, bytes, 0});
+    }
+    int reserve() {
+        total = 0;
+        for (auto *list : {&up, &down})
+            for (Item &it : *list)
+                if (it.bytes > kDirect) {
+                    it.offset = total;
+                    total += (it.bytes + 255) & ~(size_t)255;
+                }
+        return total ? stage.reserve(total) : DLAGP_OK;
+    }
+    int run_uploads() {
+        for (const Item &it : up) {
+            if (it.bytes > kDirect) {
+                std::memcpy(static_cast<char *>(stage.ptr) + it.offset, it.host, it.bytes);
+                HIP_TRY(hipMemcpyAsync(it.device, static_cast<char *>(stage.ptr) + it.offset, it.bytes, hipMemcpyHostToDevice, nullptr));
+            } else {
+                HIP_TRY(hipMemcpy(it.device, it.host, it.bytes, hipMemcpyHostToDevice));
+            }
+        }
+        return DLAGP_OK;
+    }
+    int run_downloads() {
+        for (const Item &it : down)
+            if (it.bytes > kDirect)
+                HIP_TRY(hipMemcpyAsync(static_cast<char *>(stage.ptr) + it.offset, it.device, it.bytes, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        for (const Item &it : down) {
+            if (it.bytes > kDirect) std::memcpy(it.host, static_cast<char *>(stage.ptr) + it.offset, it.bytes);
+            else HIP_TRY(hipMemcpy(it.host, it.device, it.bytes, hipMemcpyDeviceToHost));
+        }
+        return DLAGP_OK;
+    }
+};
+
 // host-pointer wrapper: stage, launch, copy back, report non-PD as DLAGP_ELINALG
 static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, const double *nhi, double *out) {
     Workspace &ws = g.ws;
@@ -509,14 +588,17 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
     if ((rc = ws.z.reserve(nsamp * sizeof(double)))) return rc;
     if ((rc = ws.nhi.reserve(nsamp * sizeof(double)))) return rc;
     if ((rc = ws.out.reserve((size_t)rows * sizeof(double)))) return rc;
+    Transfers tr(ws.stage);
     if (kd > 0) {
-        HIP_TRY(hipMemcpy(ws.z.ptr, z, nsamp * sizeof(double), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ws.nhi.ptr, nhi, nsamp * sizeof(double), hipMemcpyHostToDevice));
+        tr.upload(ws.z.ptr, z, nsamp * sizeof(double));
+        tr.upload(ws.nhi.ptr, nhi, nsamp * sizeof(double));
     }
+    tr.download(out, ws.out.ptr, (size_t)rows * sizeof(double));
+    if ((rc = tr.reserve()) || (rc = tr.run_uploads())) return rc;
     rc = launch_sweep(g, S, kd, SampleSource{ws.z.as<double>(), ws.nhi.as<double>(), nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0},
                       ws.out.as<double>(), nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(out, ws.out.ptr, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost));
+    if ((rc = tr.run_downloads())) return rc;
     int status = 0;
     HIP_TRY(hipMemcpy(&status, ws.status.ptr, sizeof(int), hipMemcpyDeviceToHost));
     if (status) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
@@ -1076,6 +1158,12 @@ int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, con
     return sweep_from_host(batch->group, S, kd, z, nhi, out);
 }
 
+int dlagp_batch_null(dlagp_batch *batch, double *out) {
+    if (!batch || !out) return fail(DLAGP_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(batch->group.device));
+    return sweep_from_host(batch->group, 1, 0, nullptr, nullptr, out);
+}
+
 static int check_sweep_args(const dlagp_batch *batch, int64_t S, int max_dlas, const void *sample_z,
                             const void *sample_nhi, int64_t nhi_stride, const void *uniforms, const void *evidences) {
     if (!batch) return fail(DLAGP_EINVAL, "NULL batch");
@@ -1120,16 +1208,19 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
     if ((rc = ws.evidences.reserve(nb * max_dlas * sizeof(double)))) return rc;
     if ((rc = ws.sample_ll.reserve(rows * max_dlas * sizeof(double)))) return rc;
     if ((rc = ws.base.reserve(std::max<size_t>(n_base, 1) * sizeof(int32_t)))) return rc;
-    HIP_TRY(hipMemcpy(ws.z.ptr, sample_z, rows * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ws.nhi.ptr, sample_nhi, n_nhi * sizeof(double), hipMemcpyHostToDevice));
-    if (n_base) HIP_TRY(hipMemcpy(ws.uniforms.ptr, uniforms, n_base * sizeof(double), hipMemcpyHostToDevice));
+    Transfers tr(ws.stage);
+    tr.upload(ws.z.ptr, sample_z, rows * sizeof(double));
+    tr.upload(ws.nhi.ptr, sample_nhi, n_nhi * sizeof(double));
+    tr.upload(ws.uniforms.ptr, uniforms, n_base * sizeof(double));
+    tr.download(evidences, ws.evidences.ptr, nb * max_dlas * sizeof(double));
+    tr.download(sample_ll, ws.sample_ll.ptr, rows * max_dlas * sizeof(double));
+    tr.download(base_inds, ws.base.ptr, n_base * sizeof(int32_t));
+    if ((rc = tr.reserve()) || (rc = tr.run_uploads())) return rc;
     rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), nhi_stride, min_z_separation,
                       ws.uniforms.as<double>(), ws.evidences.as<double>(), ws.sample_ll.as<double>(),
                       ws.base.as<int>(), nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(evidences, ws.evidences.ptr, nb * max_dlas * sizeof(double), hipMemcpyDeviceToHost));
-    if (sample_ll) HIP_TRY(hipMemcpy(sample_ll, ws.sample_ll.ptr, rows * max_dlas * sizeof(double), hipMemcpyDeviceToHost));
-    if (base_inds && n_base) HIP_TRY(hipMemcpy(base_inds, ws.base.ptr, n_base * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if ((rc = tr.run_downloads())) return rc;
     int status = 0;
     HIP_TRY(hipMemcpy(&status, ws.alive.as<int>() + nb, sizeof(int), hipMemcpyDeviceToHost));
     if (status) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");

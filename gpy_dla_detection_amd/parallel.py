@@ -214,7 +214,7 @@ class _DeviceBatchAdapter:
         return self.batch.sweep(*args)
 
     def nulls(self):
-        return np.array([d.null() for d in self.devs])
+        return self.batch.nulls()
 
 
 def _device_batch(sights, device):

@@ -107,8 +107,8 @@ class DeviceEngine:
 
         return DeviceBatch(sightlines)
 
-    def nulls(self, sightlines) -> np.ndarray:
-        return np.array([s.null() for s in sightlines])
+    def nulls(self, batch, sightlines) -> np.ndarray:
+        return batch.nulls()
 
     def sweep(self, batch, sample_z, sample_nhi, max_dlas, min_z_separation, seed):
         return parallel.sweep_batch_device(batch, sample_z, sample_nhi, max_dlas, min_z_separation, seed)
@@ -180,7 +180,7 @@ def process_qso(
             local["max_z_dlas"][q - lo] = params.max_z_dla(wavelengths, z_qso)
         batch = engine.batch(sightlines)
         z_dla, z_lls = np.stack(z_dla), np.stack(z_lls)
-        nulls = engine.nulls(sightlines)
+        nulls = engine.nulls(batch, sightlines)
         # the sub-DLA model is swept before the DLA model (model list order, run_bayes_select.py:189);
         # with max_dlas = 1 it draws nothing from the RNG, so the DLA sweep sees the freshly seeded stream
         ev_sub, ll_sub, _ = engine.sweep(batch, z_lls, nhi_sub, 1, min_sep, seed)

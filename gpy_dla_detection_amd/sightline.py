@@ -234,6 +234,12 @@ class DeviceBatch:
     def eval_device(self, S: int, kd: int, d_z: int, d_nhi: int, d_out: int, stream: int = 0) -> None:
         _lib.check(_lib.load().dlagp_batch_eval_device(self._handle, S, kd, d_z, d_nhi, d_out, stream))
 
+    def nulls(self) -> np.ndarray:
+        """null-model evidence of every member (NullGP.log_model_evidence, null_gp.py:294-305), one launch"""
+        out = np.empty(self.nb, dtype=np.float64)
+        _lib.check(_lib.load().dlagp_batch_null(self._handle, _lib.ptr(out)))
+        return out
+
 
     def sweep(self, sample_z, sample_nhi, max_dlas: int, min_z_separation: float, uniforms=None):
         """

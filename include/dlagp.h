@@ -169,6 +169,9 @@ int dlagp_batch_eval_device(dlagp_batch *batch, int64_t S, int kd, const double 
 int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, const double *nhi,
                      double *out);
 
+/* Null-model evidence of every sightline of the batch in one launch (dlagp_null per member); out[nb]. */
+int dlagp_batch_null(dlagp_batch *batch, double *out);
+
 /*
  * The whole occupation sweep of DLAGP.log_model_evidences / SubDLAGP.log_model_evidences
  * (reference dla_gp.py:92-225, subdla_gp.py:90-223) for every sightline of the batch, with no host

@@ -283,6 +283,7 @@ def test_batch_equals_single_sightline_launches():
         zs.append(np.stack([z, z[::-1]], axis=1))
         ns.append(np.stack([nhi, nhi[::-1]], axis=1))
     batch = DeviceBatch(devs)
+    np.testing.assert_allclose(batch.nulls(), [d.null() for d in devs], rtol=1e-14)  # dlagp_batch_null
     got = batch.eval(np.stack(zs), np.stack(ns))
     for b, dev in enumerate(devs):
         # the batch and the single launch may choose different pixel-split counts, i.e. a

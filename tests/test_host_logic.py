@@ -220,7 +220,7 @@ class OracleEngine:
         batch.states = list(sightlines)
         return batch
 
-    def nulls(self, sightlines):
+    def nulls(self, batch, sightlines):
         from oracle import ref_like
 
         return np.array([ref_like.null_log_model_evidence(st) for st in sightlines])

@@ -53,6 +53,10 @@ for kd in (1, 2, 3, 4):
     t = timed(lambda: ds.eval_device(S, kd, d_z.data_ptr(), d_n.data_ptr(), d_o.data_ptr(), stream), reps=100)
     out["one_sightline_kd%d_evals_per_s" % kd] = S / t
 
+# the host-pointer entry (dlagp_eval: H2D of z / nhi, launch, D2H of the log-likelihoods, synchronous)
+t = timed(lambda: ds.eval(z, nhi), reps=100)
+out["one_sightline_kd1_host_pointers_evals_per_s"] = S / t
+
 # config 3: 64 sightlines x 10 000 samples, DLA(1) + sub-DLA
 nb = 64
 sights = [make_sightline(i) for i in range(nb)]
