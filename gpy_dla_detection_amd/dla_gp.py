@@ -6,12 +6,14 @@ Drop-in for the model-evidence surface of the reference class
 `this_dla_gp`, `log_priors`, `maximum_a_posteriori`, and the side effects callers read
 (`sample_log_likelihoods`, `base_sample_inds`).
 
-What moved to the device: the body of the loop over the QMC samples (reference :132-159) --
-all `num_dla_samples` Voigt-absorbed models and low-rank Gaussian log-densities of one
-occupation level are one `dlagp_eval` call.  What stays on the host, on purpose: the
-separation masking, the log-mean-exp evidence and the posterior resampling with the legacy
-global NumPy RNG (reference :164-218), so that `np.random.seed` reproduces the reference's
-indices bit for bit.
+What moved to the device: the whole occupation sweep (reference :92-225).  The body of the loop over
+the QMC samples (:132-159) -- all `num_dla_samples` Voigt-absorbed models and low-rank Gaussian
+log-densities of a level -- is one launch sequence, and the levels are chained on the device
+(separation masking, log-mean-exp evidence, posterior resampling, :164-218; `dlagp_batch_sweep`).
+The resampling takes its random numbers from the legacy global NumPy RNG exactly as
+`np.random.choice` would (one `random_sample(S)` per resampled level), so `np.random.seed`
+reproduces the reference's `base_sample_inds` and leaves the generator in the reference's state.
+`host_levels = True` on an instance (or the class) keeps the levels' host half in NumPy.
 """
 from typing import Tuple
 
@@ -71,13 +73,44 @@ class _AbsorberGP(NullGP):
         return np.array([self.sample_log_likelihood_k_dlas(z[i], nhi[i]) for i in range(z.shape[0])])
 
     # -- the sweep -----------------------------------------------------------------------------
+    #: True: the levels' host half (mask, evidence, np.random.choice) runs in NumPy exactly as in the
+    #: reference.  False (default): all levels are chained on the device (dlagp_batch_sweep); the legacy
+    #: global RNG is consumed exactly as `np.random.choice` would consume it -- one `random_sample(S)` per
+    #: resampled level -- so `np.random.seed` gives the reference's `base_sample_inds` and leaves the
+    #: same RNG state behind.
+    host_levels = False
+
     def _sweep(self, max_dlas: int):
         sample_z = np.asarray(self._sample_redshifts(), dtype=np.float64)
         sample_nhi = np.asarray(self.dla_samples.nhi_samples, dtype=np.float64)
-        return occupation_sweep(
-            self._level_log_likelihoods, sample_z, sample_nhi, max_dlas, self.min_z_separation,
-            num_samples=self.params.num_dla_samples,
-        )
+        S = self.params.num_dla_samples
+        if self.host_levels or not self._stock_absorption() or max_dlas > 8:
+            return occupation_sweep(self._level_log_likelihoods, sample_z, sample_nhi, max_dlas,
+                                    self.min_z_separation, num_samples=S)
+        return self._sweep_on_device(sample_z, sample_nhi, max_dlas, S)
+
+    def _sweep_on_device(self, sample_z: np.ndarray, sample_nhi: np.ndarray, max_dlas: int, S: int):
+        from .sightline import DeviceBatch
+
+        # np.random.choice(S, S, p=...) draws random_sample(S) once per call (reference dla_gp.py:213-218):
+        # draw what a full sweep would draw, and give back what an early stop would not have drawn
+        rng_before = np.random.get_state()
+        uniforms = np.random.random_sample((1, max(max_dlas - 1, 0), S))
+        batch = DeviceBatch([self.device_sightline()])
+        try:
+            evidences, sample_ll, base = batch.sweep(sample_z[None, :], sample_nhi, max_dlas,
+                                                     self.min_z_separation, uniforms)
+        finally:
+            batch.close()
+        evidences, sample_ll, base = evidences[0], sample_ll[0], base[0]
+        nan_levels = np.flatnonzero(np.isnan(evidences))
+        if nan_levels.size and nan_levels[0] + 1 < max_dlas:  # reference :200-206: the sweep stopped there
+            stopped = int(nan_levels[0])
+            print("Finish the loop earlier because NaN value in log p(D | z_QSO, {} DLAs)".format(stopped))
+            np.random.set_state(rng_before)
+            for _ in range(stopped):  # the levels before it did resample
+                np.random.random_sample(S)
+        return evidences, sample_ll, base
 
 
 def level_parameters(sample_z: np.ndarray, sample_nhi: np.ndarray, base_sample_inds: np.ndarray, level: int):

@@ -756,3 +756,34 @@ def test_device_sweep_shapes(S, max_dlas, nb, restore_options):
     np.testing.assert_allclose(got[1], want[1], rtol=1e-11, equal_nan=True)
     np.testing.assert_allclose(got[0], want[0], rtol=1e-11, equal_nan=True)
     assert got[0].shape == (nb, max_dlas) and got[1].shape == (nb, S, max_dlas) and got[2].shape == (nb, max(max_dlas - 1, 0), S)
+
+
+def test_class_api_device_levels_consume_the_rng_like_the_reference():
+    """DLAGP.log_model_evidences: levels on the device (default) vs host levels -- same arrays, same RNG state after"""
+    sight = make_sightline(1, n_unmasked=400, n_masked=9)
+    _, _, dla = build_models(sight, 300)
+    results = {}
+    for host_levels in (False, True):
+        dla.host_levels = host_levels
+        np.random.seed(5)
+        ev = dla.log_model_evidences(4)
+        results[host_levels] = (ev, dla.sample_log_likelihoods.copy(), dla.base_sample_inds.copy(),
+                                np.random.get_state()[1].copy(), np.random.get_state()[2])
+    dev, host = results[False], results[True]
+    np.testing.assert_array_equal(dev[2], host[2])
+    np.testing.assert_allclose(dev[0], host[0], rtol=1e-12)
+    np.testing.assert_allclose(dev[1], host[1], rtol=1e-12, equal_nan=True)
+    assert np.array_equal(dev[3], host[3]) and dev[4] == host[4]      # legacy RNG left in the same state
+    assert dev[1].shape == (300, 4) and dev[2].shape == (3, 300) and dev[2].dtype == np.int32
+    # early stop (NaN evidence at the first level): nothing is drawn, as in the reference (dla_gp.py:200-206)
+    good = dla.dla_samples._nhi_samples
+    try:
+        dla.dla_samples._nhi_samples = np.full(300, np.nan)
+        for host_levels in (False, True):
+            dla.host_levels = host_levels
+            np.random.seed(9)
+            before = np.random.get_state()[1].copy()
+            ev = dla.log_model_evidences(3)
+            assert np.isnan(ev).all() and np.array_equal(np.random.get_state()[1], before)
+    finally:
+        dla.dla_samples._nhi_samples = good
