@@ -420,15 +420,42 @@ __global__ __launch_bounds__(DLAGP_EVIDENCE_THREADS) void level_evidence(double 
     const unsigned char *mask = too_close ? too_close + blockIdx.x * S : nullptr;
     const double log_s = log((double)S);
 
+    // Up to 16 values per thread stay in registers between the two passes, and all of a thread's loads are
+    // issued before the first use (a load / store / load chain on the same array serialised on memory
+    // latency: 10 us for 10 000 values); longer rows take the looping path.
+    constexpr int KEEP = 16;
+    const bool in_registers = S <= (long)KEEP * DLAGP_EVIDENCE_THREADS;
+    double kept[KEEP];
     double top = -__builtin_inf();
     bool any = false;
-    for (long i = tid; i < S; i += DLAGP_EVIDENCE_THREADS) {
-        double v = row[i] - log_s;
-        if (mask && mask[i]) v = __builtin_nan("");
-        row[i] = v;
-        if (v == v) {
-            top = fmax(top, v);
-            any = true;
+    if (in_registers) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const long i = tid + (long)k * DLAGP_EVIDENCE_THREADS;
+            kept[k] = i < S ? row[i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const long i = tid + (long)k * DLAGP_EVIDENCE_THREADS;
+            double v = kept[k] - log_s;
+            if (i < S && mask && mask[i]) v = __builtin_nan("");
+            if (i >= S) v = __builtin_nan("");
+            kept[k] = v;
+            if (i < S) row[i] = v;
+            if (v == v) {
+                top = fmax(top, v);
+                any = true;
+            }
+        }
+    } else {
+        for (long i = tid; i < S; i += DLAGP_EVIDENCE_THREADS) {
+            double v = row[i] - log_s;
+            if (mask && mask[i]) v = __builtin_nan("");
+            row[i] = v;
+            if (v == v) {
+                top = fmax(top, v);
+                any = true;
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) top = fmax(top, __shfl_xor(top, off));
@@ -439,11 +466,22 @@ __global__ __launch_bounds__(DLAGP_EVIDENCE_THREADS) void level_evidence(double 
     __syncthreads();
 
     double sum = 0.0, count = 0.0;
-    for (long i = tid; i < S; i += DLAGP_EVIDENCE_THREADS) {
-        const double v = row[i];
-        if (v == v) {
-            sum += exp(v - top);
-            count += 1.0;
+    if (in_registers) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const double v = kept[k];
+            if (v == v) {
+                sum += exp(v - top);
+                count += 1.0;
+            }
+        }
+    } else {
+        for (long i = tid; i < S; i += DLAGP_EVIDENCE_THREADS) {
+            const double v = row[i];
+            if (v == v) {
+                sum += exp(v - top);
+                count += 1.0;
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
