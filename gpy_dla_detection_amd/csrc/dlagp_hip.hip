@@ -665,6 +665,27 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     return DLAGP_OK;
 }
 
+// Context creation runs on its own non-blocking stream (one per host thread and device), never on the null
+// stream: a second host thread can then build the next batch's contexts while the first is inside a sweep --
+// uploads and set-up kernels no longer queue behind the sweep's kernels, nor does hipDeviceSynchronize wait for
+// them.
+static hipStream_t setup_stream(int device) {
+    static thread_local std::map<int, hipStream_t> streams;
+    auto it = streams.find(device);
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;  // fall back to the null stream
+    streams[device] = s;
+    return s;
+}
+
+// host -> device on the set-up stream, complete on return (the source may be a temporary)
+static int upload_now(void *dst, const void *src, size_t bytes, hipStream_t stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return DLAGP_OK;
+}
+
 // fill the group-level summary from its members and upload the descriptor table
 static int finish_group(LaunchGroup &g) {
     std::vector<SightlineDev> table;
@@ -685,8 +706,7 @@ static int finish_group(LaunchGroup &g) {
     }
     int rc = g.d_table.reserve(table.size() * sizeof(SightlineDev));
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(g.d_table.ptr, table.data(), table.size() * sizeof(SightlineDev), hipMemcpyHostToDevice));
-    return DLAGP_OK;
+    return upload_now(g.d_table.ptr, table.data(), table.size() * sizeof(SightlineDev), setup_stream(g.device));
 }
 
 // Everything of context creation that does not depend on where the model arrays come from:
@@ -781,10 +801,9 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     if (!rc) rc = ctx->aux.reserve(px * DLAGP_AUX_FIELDS);
     if (!rc) rc = ctx->dense_M.reserve((size_t)n * k_eff * sizeof(double));
     if (!rc) rc = ctx->P.reserve(p_bytes);
-    if (!rc && hipMemcpy(ctx->pos.ptr, hpos.data(), (size_t)sl.n_pad * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
-        rc = fail(DLAGP_EDEVICE, "upload of the window starts failed");
-    if (!rc && hipMemcpy(ctx->lam.ptr, wavelengths, (size_t)sl.num_entries * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
-        rc = fail(DLAGP_EDEVICE, "upload of the wavelength grid failed");
+    const hipStream_t setup = setup_stream(device);
+    if (!rc) rc = upload_now(ctx->pos.ptr, hpos.data(), (size_t)sl.n_pad * sizeof(int), setup);
+    if (!rc) rc = upload_now(ctx->lam.ptr, wavelengths, (size_t)sl.num_entries * sizeof(double), setup);
     if (!rc) rc = fill(ctx);
     if (rc) {
         dlagp_destroy(ctx);
@@ -799,12 +818,12 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     sl.P = ctx->P.as<double>();
     sl.aux = ctx->aux.as<double>();
 
-    hipLaunchKernelGGL(fill_records, dim3((sl.n_pad + 255) / 256), dim3(256), 0, nullptr, sl.n_pad, sl.y, sl.mu,
+    hipLaunchKernelGGL(fill_records, dim3((sl.n_pad + 255) / 256), dim3(256), 0, setup, sl.n_pad, sl.y, sl.mu,
                        sl.omega2, sl.v, sl.pos, ctx->aux.as<double>());
-    hipLaunchKernelGGL(build_shared_operand, dim3(1024), dim3(256), 0, nullptr, ctx->dense_M.as<double>(), n, sl.n_pad,
+    hipLaunchKernelGGL(build_shared_operand, dim3(1024), dim3(256), 0, setup, ctx->dense_M.as<double>(), n, sl.n_pad,
                        k_eff, sl.ntw, sl.ntq, sl.npair, ctx->P.as<double>());
     hipError_t err = hipGetLastError();
-    if (err == hipSuccess) err = hipDeviceSynchronize();
+    if (err == hipSuccess) err = hipStreamSynchronize(setup);
     if (err != hipSuccess) {
         dlagp_destroy(ctx);
         return fail(DLAGP_EDEVICE, "context set-up kernels failed: %s", hipGetErrorString(err));
@@ -821,11 +840,10 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
 }
 
 // upload n doubles padded to n_pad with `pad`
-static int upload_padded(DeviceBuffer &buf, const double *src, int n, int n_pad, double pad) {
+static int upload_padded(DeviceBuffer &buf, const double *src, int n, int n_pad, double pad, hipStream_t stream) {
     std::vector<double> host(n_pad, pad);
     std::copy(src, src + n, host.begin());
-    HIP_TRY(hipMemcpy(buf.ptr, host.data(), (size_t)n_pad * sizeof(double), hipMemcpyHostToDevice));
-    return DLAGP_OK;
+    return upload_now(buf.ptr, host.data(), (size_t)n_pad * sizeof(double), stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -850,16 +868,16 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
     if (!y || !mu || !M || !omega2 || !v) return fail(DLAGP_EINVAL, "NULL input array");
     return create_context(out, n, n_u, k, wavelengths, keep, num_lines, broadening, device, [&](dlagp_ctx *ctx) -> int {
         const SightlineDev &sl = ctx->sl;
-        int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0);
-        if (!rc) rc = upload_padded(ctx->mu, mu, n, sl.n_pad, 0.0);
-        if (!rc) rc = upload_padded(ctx->omega2, omega2, n, sl.n_pad, 0.0);
-        if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0);
+        const hipStream_t setup = setup_stream(ctx->device);
+        int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0, setup);
+        if (!rc) rc = upload_padded(ctx->mu, mu, n, sl.n_pad, 0.0, setup);
+        if (!rc) rc = upload_padded(ctx->omega2, omega2, n, sl.n_pad, 0.0, setup);
+        if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0, setup);
         if (rc) return rc;
         std::vector<double> hM((size_t)n * sl.k, 0.0);
         for (int i = 0; i < n; ++i)
             for (int c = 0; c < k; ++c) hM[(size_t)i * sl.k + c] = M[i * m_row_stride + c * m_col_stride];
-        HIP_TRY(hipMemcpy(ctx->dense_M.ptr, hM.data(), hM.size() * sizeof(double), hipMemcpyHostToDevice));
-        return DLAGP_OK;
+        return upload_now(ctx->dense_M.ptr, hM.data(), hM.size() * sizeof(double), setup);
     });
 }
 
@@ -949,21 +967,22 @@ int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, in
     return create_context(out, n, n_u, model->dev.k, wavelengths, keep, num_lines, broadening, model->device,
                           [&](dlagp_ctx *ctx) -> int {
         const SightlineDev &sl = ctx->sl;
-        int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0);
-        if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0);
+        const hipStream_t setup = setup_stream(ctx->device);
+        int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0, setup);
+        if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0, setup);
         if (rc) return rc;
         DeviceBuffer dx, dw;
         rc = dx.reserve((size_t)n * sizeof(double));
         if (!rc) rc = dw.reserve((size_t)n * sizeof(double));
+        if (!rc) rc = upload_now(dx.ptr, x, (size_t)n * sizeof(double), setup);
+        if (!rc) rc = upload_now(dw.ptr, this_wavelengths, (size_t)n * sizeof(double), setup);
         hipError_t err = hipSuccess;
-        if (!rc) err = hipMemcpy(dx.ptr, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
-        if (!rc && err == hipSuccess) err = hipMemcpy(dw.ptr, this_wavelengths, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
-        if (!rc && err == hipSuccess) {
-            hipLaunchKernelGGL(interp_model, dim3((sl.n_pad + 63) / 64), dim3(64), 0, nullptr, model->dev, n, sl.n_pad,
+        if (!rc) {
+            hipLaunchKernelGGL(interp_model, dim3((sl.n_pad + 63) / 64), dim3(64), 0, setup, model->dev, n, sl.n_pad,
                                sl.k, dx.as<const double>(), dw.as<const double>(), z_qso, ctx->mu.as<double>(),
                                ctx->omega2.as<double>(), ctx->dense_M.as<double>());
             err = hipGetLastError();
-            if (err == hipSuccess) err = hipDeviceSynchronize();
+            if (err == hipSuccess) err = hipStreamSynchronize(setup);
         }
         dx.release();
         dw.release();

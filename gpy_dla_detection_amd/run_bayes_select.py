@@ -18,6 +18,7 @@ Multi-GPU: `rank` / `world_size` shard the catalogue in contiguous blocks (one p
 every rank returns the full arrays after one all-gather per output (`parallel.gather_rows`).
 """
 from collections import namedtuple
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -141,12 +142,14 @@ def process_qso(
     group=None,
     qso_list: Optional[Sequence[str]] = None,
     engine=None,
+    prefetch: bool = True,
 ) -> Dict[str, np.ndarray]:
     """
     :param spectra: per quasar (observed wavelengths, flux, noise_variance, pixel_mask) -- what the
         reference's `read_spec(filename)` returns (run_bayes_select.py:147)
     :param learned: the learned GP model (`LearnedModel`; the reference loads it from a .mat file per spectrum)
     :param dla_samples, subdla_samples: QMC sample holders (`samples.DLASamples` / `SubDLASamples` or the *MAT loaders)
+    :param prefetch: prepare the next batch in a worker thread while the current one is swept
     :param engine: back end (default `DeviceEngine(learned, params, device)`)
     :param seed: the reference re-seeds the global RNG with 0 before every spectrum (:144)
     :return: dict keyed by the dataset names of processed_qsos_multi_meanflux.h5 (:248-295)
@@ -165,8 +168,8 @@ def process_qso(
     nhi_dla = np.asarray(dla_samples.nhi_samples, dtype=np.float64)
     nhi_sub = np.asarray(subdla_samples.nhi_samples, dtype=np.float64)
 
-    for start in range(lo, hi, batch_size):
-        stop = min(start + batch_size, hi)
+    def prepare(start: int, stop: int):
+        """host index logic + device contexts of spectra [start, stop): everything a sweep needs"""
         sightlines, z_dla, z_lls = [], [], []
         for q in range(start, stop):
             wavelengths, flux, noise_variance, pixel_mask = spectra[q]
@@ -178,14 +181,10 @@ def process_qso(
             z_lls.append(subdla_samples.sample_z_lls(st["this_wavelengths"], z_qso))
             local["min_z_dlas"][q - lo] = params.min_z_dla(wavelengths, z_qso)
             local["max_z_dlas"][q - lo] = params.max_z_dla(wavelengths, z_qso)
-        batch = engine.batch(sightlines)
-        z_dla, z_lls = np.stack(z_dla), np.stack(z_lls)
-        nulls = engine.nulls(batch, sightlines)
-        # the sub-DLA model is swept before the DLA model (model list order, run_bayes_select.py:189);
-        # with max_dlas = 1 it draws nothing from the RNG, so the DLA sweep sees the freshly seeded stream
-        ev_sub, ll_sub, _ = engine.sweep(batch, z_lls, nhi_sub, 1, min_sep, seed)
-        ev_dla, ll_dla, base = engine.sweep(batch, z_dla, nhi_dla, max_dlas, min_sep, seed)
+        return sightlines, engine.batch(sightlines), np.stack(z_dla), np.stack(z_lls)
 
+    def finish(start, stop, sightlines, batch, z_dla, nulls, ev_sub, ll_sub, ev_dla, ll_dla, base):
+        """priors, posteriors, MAP values of spectra [start, stop) into the result arrays; frees their contexts"""
         for b, q in enumerate(range(start, stop)):
             i = q - lo
             log_priors = occupation_log_priors(prior, z_qso_list[q], max_dlas, dla_samples, subdla_samples)
@@ -206,6 +205,36 @@ def process_qso(
             local["p_dlas"][i] = np.sum(posteriors[-max_dlas:])
             local["p_no_dlas"][i] = 1 - local["p_dlas"][i]
         engine.release(batch, sightlines)
+
+    # A worker thread prepares batch i + 1 (NumPy index logic, context creation on its own HIP stream) and
+    # finishes batch i - 1 (priors, posteriors, MAP, freeing contexts) while this thread is inside the sweeps of
+    # batch i (ctypes releases the GIL): the device never waits for the host.  `prefetch=False` runs everything in
+    # this thread, in order.
+    bounds = [(start, min(start + batch_size, hi)) for start in range(lo, hi, batch_size)]
+    pool = ThreadPoolExecutor(max_workers=1) if prefetch and len(bounds) > 1 else None
+    pending = pool.submit(prepare, *bounds[0]) if pool else None
+    finishing = []
+    for index, (start, stop) in enumerate(bounds):
+        if pool:
+            sightlines, batch, z_dla, z_lls = pending.result()
+            pending = pool.submit(prepare, *bounds[index + 1]) if index + 1 < len(bounds) else None
+        else:
+            sightlines, batch, z_dla, z_lls = prepare(start, stop)
+        nulls = engine.nulls(batch, sightlines)
+        # the sub-DLA model is swept before the DLA model (model list order, run_bayes_select.py:189);
+        # with max_dlas = 1 it draws nothing from the RNG, so the DLA sweep sees the freshly seeded stream
+        ev_sub, ll_sub, _ = engine.sweep(batch, z_lls, nhi_sub, 1, min_sep, seed)
+        ev_dla, ll_dla, base = engine.sweep(batch, z_dla, nhi_dla, max_dlas, min_sep, seed)
+
+        swept = (start, stop, sightlines, batch, z_dla, nulls, ev_sub, ll_sub, ev_dla, ll_dla, base)
+        if pool:
+            finishing.append(pool.submit(finish, *swept))
+        else:
+            finish(*swept)
+    for future in finishing:
+        future.result()
+    if pool:
+        pool.shutdown()
     if own_engine:
         engine.close()
 
