@@ -214,27 +214,29 @@ def process_qso(
     pool = ThreadPoolExecutor(max_workers=1) if prefetch and len(bounds) > 1 else None
     pending = pool.submit(prepare, *bounds[0]) if pool else None
     finishing = []
-    for index, (start, stop) in enumerate(bounds):
-        if pool:
-            sightlines, batch, z_dla, z_lls = pending.result()
-            pending = pool.submit(prepare, *bounds[index + 1]) if index + 1 < len(bounds) else None
-        else:
-            sightlines, batch, z_dla, z_lls = prepare(start, stop)
-        nulls = engine.nulls(batch, sightlines)
-        # the sub-DLA model is swept before the DLA model (model list order, run_bayes_select.py:189);
-        # with max_dlas = 1 it draws nothing from the RNG, so the DLA sweep sees the freshly seeded stream
-        ev_sub, ll_sub, _ = engine.sweep(batch, z_lls, nhi_sub, 1, min_sep, seed)
-        ev_dla, ll_dla, base = engine.sweep(batch, z_dla, nhi_dla, max_dlas, min_sep, seed)
+    try:
+        for index, (start, stop) in enumerate(bounds):
+            if pool:
+                sightlines, batch, z_dla, z_lls = pending.result()
+                pending = pool.submit(prepare, *bounds[index + 1]) if index + 1 < len(bounds) else None
+            else:
+                sightlines, batch, z_dla, z_lls = prepare(start, stop)
+            nulls = engine.nulls(batch, sightlines)
+            # the sub-DLA model is swept before the DLA model (model list order, run_bayes_select.py:189);
+            # with max_dlas = 1 it draws nothing from the RNG, so the DLA sweep sees the freshly seeded stream
+            ev_sub, ll_sub, _ = engine.sweep(batch, z_lls, nhi_sub, 1, min_sep, seed)
+            ev_dla, ll_dla, base = engine.sweep(batch, z_dla, nhi_dla, max_dlas, min_sep, seed)
 
-        swept = (start, stop, sightlines, batch, z_dla, nulls, ev_sub, ll_sub, ev_dla, ll_dla, base)
+            swept = (start, stop, sightlines, batch, z_dla, nulls, ev_sub, ll_sub, ev_dla, ll_dla, base)
+            if pool:
+                finishing.append(pool.submit(finish, *swept))
+            else:
+                finish(*swept)
+        for future in finishing:
+            future.result()
+    finally:
         if pool:
-            finishing.append(pool.submit(finish, *swept))
-        else:
-            finish(*swept)
-    for future in finishing:
-        future.result()
-    if pool:
-        pool.shutdown()
+            pool.shutdown()
     if own_engine:
         engine.close()
 

@@ -283,6 +283,12 @@ def test_process_qso_matches_reference_driver_golden(tmp_path):
                           qso_list=["spec-%d" % i for i in range(3)])
     assert np.array_equal(np.random.get_state()[1], before)
     assert_catalogue_matches_golden(results, g, rtol=1e-10)
+    in_order = process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned,
+                           max_dlas=int(g["max_dlas"]), batch_size=2, engine=OracleEngine(learned, params),
+                           prefetch=False)   # no worker thread: same arrays
+    for name in results:
+        if name != "qso_list":
+            np.testing.assert_array_equal(in_order[name], results[name], err_msg=name)
     path = write_results(results, str(tmp_path / "processed_qsos_multi_meanflux.h5"))
     if path.endswith(".npz"):
         back = np.load(path)
