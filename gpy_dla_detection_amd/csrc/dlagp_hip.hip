@@ -262,6 +262,7 @@ struct LaunchGroup {
     int max_entries = 0, max_npad = 0, max_chunks = 0;
     bool mfma_ok = false;
     bool grid_uniform = false;  // every member's wavelength grid is log-uniform (core patch eligible)
+    bool lls_break = false;     // members carry the Lyman-limit term (all or none, else no MFMA path)
     Workspace ws;
     std::map<int, std::unique_ptr<GroupPlan>> plans;
     void release() {
@@ -396,10 +397,21 @@ static int choose_splits(const LaunchGroup &g, int64_t S) {
 template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, GroupPlan *gp, int nsplit,
                         long S, int kd, int num_lines, const SampleSource &src, double *part, int *status,
-                        bool patch) {
+                        bool patch, bool lls) {
     // 16 samples + one spare row that the look-ahead of the sample loop may read
-    const size_t prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * kd * ((LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
+    const size_t prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * kd * (lls ? 6 : (LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
     if constexpr (LINES == 3) {
+        if (patch && lls) {  // Lyman-limit systems: single-absorber kernel with the continuum term
+            if (src.cache_mode == 1)
+                hipLaunchKernelGGL((accumulate_mfma<3, BROADEN, false, 1, true, true>), grid, dim3(DLAGP_MFMA_THREADS),
+                                   prep_lds, stream, table, gp->pass_ptrs.as<const PassDesc *>(),
+                                   gp->split_ptrs.as<const int2 *>(), nsplit, S, kd, src, part, status, (int)g_opt_debug);
+            else
+                hipLaunchKernelGGL((accumulate_mfma<3, BROADEN, false, 0, true, true>), grid, dim3(DLAGP_MFMA_THREADS),
+                                   prep_lds, stream, table, gp->pass_ptrs.as<const PassDesc *>(),
+                                   gp->split_ptrs.as<const int2 *>(), nsplit, S, kd, src, part, status, (int)g_opt_debug);
+            return;
+        }
         if (patch && !(g_opt_debug & 2)) {  // line cores repaired outside the sample loop (kd == 1, uniform grid)
             if (src.cache_mode == 1)
                 hipLaunchKernelGGL((accumulate_mfma<3, BROADEN, false, 1, true>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds,
@@ -427,10 +439,17 @@ static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table
     }
 }
 
-// whether a launch with kd absorbers per sample runs the MFMA kernel (else the generic one)
-static bool mfma_path_serves(const LaunchGroup &g, int kd) {
+// the single-absorber kernel with the cores repaired outside the sample loop (and, with it, the LLS term)
+static bool patch_serves(const LaunchGroup &g, int kd) {
+    return g.num_lines == 3 && kd == 1 && g.grid_uniform && g_opt_core_patch != 0;
+}
+
+// whether a launch with kd absorbers per sample runs the MFMA kernel (else the generic one); `cached`:
+// the launch multiplies cached profiles (levels > 1 of a sweep) and evaluates no Voigt profile itself
+static bool mfma_path_serves(const LaunchGroup &g, int kd, bool cached = false) {
     // the MFMA kernel keeps its 16 samples' per-absorber constants in dynamic LDS
     const size_t mfma_prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * std::max(kd, 1) * (g.num_lines + 1) * sizeof(double);
+    if (g.lls_break && !cached && !patch_serves(g, kd)) return false;  // the Lyman-limit term lives in that kernel only
     return g.mfma_ok && kd >= 1 && mfma_prep_lds <= 40 * 1024 && g_opt_path != 1;
 }
 
@@ -442,7 +461,7 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
     const long rows = (long)nb * S;
     const SightlineDev *table = g.d_table.as<SightlineDev>();
 
-    bool use_mfma = mfma_path_serves(g, kd);
+    bool use_mfma = mfma_path_serves(g, kd, src.cache_mode == 2);
     if (g_opt_path == 2 && kd >= 1 && !use_mfma)
         return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (rank > 20, ragged mask, or kd x lines too large)");
     const int nsplit = use_mfma ? choose_splits(g, S) : 1;
@@ -472,7 +491,8 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
         const long groups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
         dim3 grid((unsigned)(groups * nsplit), (unsigned)nb);
         const bool lines3 = g.num_lines == 3;
-        const bool patch = lines3 && kd == 1 && g.grid_uniform && g_opt_core_patch != 0;
+        const bool patch = patch_serves(g, kd);
+        const bool lls = g.lls_break;
         double *part = ws.part.as<double>();
         if (src.cache_mode == 2) {
             hipLaunchKernelGGL((accumulate_mfma<3, true, false, 2>), grid, dim3(DLAGP_MFMA_THREADS),
@@ -480,11 +500,11 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
                                gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, (long)S,
                                kd, src, part, ws.status.as<int>(), 0);
         } else if (g.broadening) {
-            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), patch);
-            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), false);
+            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), patch, lls);
+            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), false, false);
         } else {
-            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), patch);
-            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), false);
+            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), patch, lls);
+            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), false, false);
         }
         HIP_TRY(hipGetLastError());
     } else {
@@ -634,7 +654,7 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     // profile level 1 computes anyway.  Keeping them (8 S n_pad bytes per sightline) turns the Voigt work of
     // levels 2..max_dlas into HBM reads -- capacity traded for time on the shared FP64 pipe.
     bool use_cache = g_opt_profile_cache != 0 && max_dlas > 1;
-    for (int level = 0; level < max_dlas; ++level) use_cache = use_cache && mfma_path_serves(g, level + 1);
+    for (int level = 0; level < max_dlas; ++level) use_cache = use_cache && mfma_path_serves(g, level + 1, level > 0);
     const size_t cache_bytes = rows * (size_t)g.max_npad * sizeof(double);
     const size_t want_bytes = cache_bytes * (max_dlas > 2 ? 2 : 1);  // profiles + running products
     if (use_cache) {
@@ -695,7 +715,10 @@ static int finish_group(LaunchGroup &g) {
     g.broadening = g.ctxs[0]->sl.ntaps > 1;
     g.mfma_ok = true;
     g.grid_uniform = true;
+    g.lls_break = g.ctxs[0]->sl.lls_break != 0;
+    bool lls_mixed = false;
     for (dlagp_ctx *ctx : g.ctxs) {
+        lls_mixed = lls_mixed || (ctx->sl.lls_break != 0) != g.lls_break;
         g.grid_uniform = g.grid_uniform && ctx->sl.grid_uniform;
         table.push_back(ctx->sl);
         g.max_entries = std::max(g.max_entries, ctx->sl.num_entries);
@@ -704,6 +727,7 @@ static int finish_group(LaunchGroup &g) {
         g.mfma_ok = g.mfma_ok && ctx->mfma_ok && ctx->sl.num_lines == g.num_lines &&
                     (ctx->sl.ntaps > 1) == g.broadening;
     }
+    if (lls_mixed) g.mfma_ok = false;
     int rc = g.d_table.reserve(table.size() * sizeof(SightlineDev));
     if (rc) return rc;
     return upload_now(g.d_table.ptr, table.data(), table.size() * sizeof(SightlineDev), setup_stream(g.device));
@@ -786,8 +810,7 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     {
         std::vector<PassDesc> passes;
         std::vector<int2> splits;
-        // the Lyman-limit term is implemented in the generic kernel only
-        ctx->mfma_ok = k_eff == DLAGP_MFMA_RANK && !lls_break && plan_passes(hpos, sl.n_pad, sl.ntaps, 1, passes, splits);
+        ctx->mfma_ok = k_eff == DLAGP_MFMA_RANK && plan_passes(hpos, sl.n_pad, sl.ntaps, 1, passes, splits);
     }
 
     const size_t px = (size_t)sl.n_pad * sizeof(double);

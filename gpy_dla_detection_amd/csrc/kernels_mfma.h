@@ -230,7 +230,14 @@ __device__ __forceinline__ void lds_wave_sync() {
 // log-uniform grid) are examined 64 at a time and those inside the core get their exact profile value
 // 2^(-N log2e tau) (core form for that line, wing form for the other two); every pass copies the values
 // that fall into its window over raw[].
-template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, bool PATCH = false>
+//
+// LLS (PATCH kernels only): every absorber also carries the Lyman-limit continuum opacity of reference
+// voigt_lls.py:258-284, N / 10^17.2 (lambda_rest / 911.7641)^3 where lambda_rest = fl(lambda / (1 + z)) is not
+// above the limit.  Per sample two more constants: the scaled reciprocal that turns lambda into
+// (lambda_rest / limit) 10^(-17.2/3), and the smallest grid wavelength T with fl(T / (1 + z)) > limit, found
+// by stepping ulps around limit (1 + z), so that the in-loop test `lambda >= T` reproduces the reference's
+// `rest_wavelengths > lambda_Lyman_limit` (:280) exactly without a division per entry.
+template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, bool PATCH = false, bool LLS = false>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
     const int2 *const *__restrict__ split_tables, int nsplit, long S, int kd,
@@ -248,6 +255,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     __shared__ int patch_hit[NPAIR_MAX];       // per pass: active pairs touching the pass
     extern __shared__ double prep_lds[];
     static_assert(!PATCH || (LINES == 3 && MODE != 2), "the core patch is written for the 3-line Voigt loop");
+    static_assert(!LLS || PATCH, "the Lyman-limit term is implemented in the single-absorber kernel");
+    typedef double v4d_a16 __attribute__((ext_vector_type(4), aligned(16)));
 
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = 0;  // finalize raises it
     const int b = blockIdx.y;
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
 
     const long sample0 = group * DLAGP_MFMA_GROUP;  // first sample of this wave
     const int L = LINES > 0 ? LINES : sl.num_lines;
-    const int prep_stride = L + 1;
+    const int prep_stride = LLS ? 6 : L + 1;  // LLS rows: {m'_0, m'_1, m'_2, N log2e, scaled 1 / limit, T}
 
     // per-sample constants of this wave -> LDS (rows beyond S repeat the last sample; never stored)
     const int wave_prep = CACHED ? 0 : 16 * kd * prep_stride;
@@ -296,8 +305,26 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         smp = smp < S ? smp : S - 1;
         const int j = sample_abs % kd;
         const double zj = sample_z(src, b, smp, j, S, kd);
-        double value = which == L ? sample_nhi(src, b, smp, j, S, kd) * 1.44269504088896338700e+00
-                                  : line_multiplier(which, zj) * DLAGP_LINES.inv_sqrt2_sigma;
+        double value;
+        if (which < L) {
+            value = line_multiplier(which, zj) * DLAGP_LINES.inv_sqrt2_sigma;
+        } else if (which == L) {
+            value = sample_nhi(src, b, smp, j, S, kd) * 1.44269504088896338700e+00;
+        } else if (which == L + 1) {
+            // (lambda / (1 + z) / limit)^3 / 10^17.2 = (lambda * value)^3
+            value = 1.8478497974222906e-06 /* 10^(-17.2/3) */ / ((1.0 + zj) * DLAGP_LYMAN_LIMIT_ANGSTROM);
+        } else {
+            // smallest double T with fl(T / (1 + z)) > limit: start at limit (1 + z) and step ulps
+            const double zp1 = 1.0 + zj;
+            double t = DLAGP_LYMAN_LIMIT_ANGSTROM * zp1;
+            if (t > 0.0 && t < 1e300) {
+                for (int it = 0; it < 8 && t / zp1 > DLAGP_LYMAN_LIMIT_ANGSTROM; ++it)
+                    t = __longlong_as_double(__double_as_longlong(t) - 1);
+                for (int it = 0; it < 16 && !(t / zp1 > DLAGP_LYMAN_LIMIT_ANGSTROM); ++it)
+                    t = __longlong_as_double(__double_as_longlong(t) + 1);
+            }
+            value = t;
+        }
         // a NaN redshift makes every line NaN, np.nansum drops them all and the profile is 1 (voigt.py:309):
         // without the in-loop NaN test that is a zero column density
         // (and a finite multiplier, so that the optical depth the zero multiplies is finite)
@@ -359,6 +386,10 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                         const double xk = fma(lam_e, mrow[k], x_offset);
                         const double wing = wing_term(xk * xk, DLAGP_LINES.wing[k]);
                         if (k != l) tau += wing;  // Lyman lines are > 40 A apart: never two cores at one entry
+                    }
+                    if constexpr (LLS) {
+                        const double rho = lam_e * mrow[4];
+                        if (!(lam_e >= mrow[5])) tau += rho * rho * rho;  // voigt_lls.py:276-281
                     }
                     factor = fast_exp2(-mrow[3] * tau);
                 }
@@ -448,8 +479,13 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                     // The three line multipliers of the next sample are read right after their last use in this
                     // one, into the same registers (no copies); the column density, needed until the end of the
                     // body, rotates through one extra register pair.
-                    const v4d first = sp4[0];
+                    const v4d first = LLS ? (v4d)*reinterpret_cast<const v4d_a16 *>(prep_lds) : sp4[0];
                     double m0 = first.x, m1 = first.y, m2 = first.z, ncol = first.w;
+                    double lls_scale = 0.0, lls_edge = 0.0;
+                    if constexpr (LLS) {
+                        lls_scale = prep_lds[4];
+                        lls_edge = prep_lds[5];
+                    }
                     const double x_offset = -DLAGP_LINES.c * DLAGP_LINES.inv_sqrt2_sigma;
                     const double c8v = vgpr_constant(DLAGP_LINES.exp2c[8]);
                     const double w3v[3] = {vgpr_constant(DLAGP_LINES.wing[0][3]), vgpr_constant(DLAGP_LINES.wing[1][3]),
@@ -461,12 +497,19 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                     for (int ss = 0; ss < 16; ++ss) {
                         const double xs[3] = {fma(lam, m0, x_offset), fma(lam, m1, x_offset), fma(lam, m2, x_offset)};
                         __builtin_amdgcn_sched_barrier(0);
-                        const v4d nxt = sp4[(ss + 1) * kd];  // the last read lands in the spare 17th row
+                        // the last read lands in the spare 17th row
+                        const v4d nxt = LLS ? (v4d)*reinterpret_cast<const v4d_a16 *>(prep_lds + (ss + 1) * 6) : sp4[(ss + 1) * kd];
                         m0 = nxt.x;
                         m1 = nxt.y;
                         m2 = nxt.z;
                         __builtin_amdgcn_sched_barrier(0);
-                        const double tau = optical_depth<LINES, !PATCH>(lam, nullptr, 3, w3v, xs);
+                        double tau = optical_depth<LINES, !PATCH>(lam, nullptr, 3, w3v, xs);
+                        if constexpr (LLS) {
+                            const double rho = lam * lls_scale;
+                            tau += lam >= lls_edge ? 0.0 : rho * rho * rho;  // voigt_lls.py:276-281
+                            lls_scale = prep_lds[(ss + 1) * 6 + 4];
+                            lls_edge = prep_lds[(ss + 1) * 6 + 5];
+                        }
                         *raw_w = fast_exp2_table(-ncol * tau, DLAGP_LINES.exp2c, c8v);  // voigt.py:309
                         raw_w += DLAGP_RAW_STRIDE;
                         ncol = nxt.w;

@@ -54,7 +54,10 @@ extern "C" {
 #define DLAGP_FLAG_LLS_BREAK 2  /* absorbers also carry the Lyman-limit continuum opacity
                                    N / 10^17.2 (lambda_rest / 911.7641 A)^3 bluewards of the
                                    limit (reference voigt_lls.py:258-284, :348; the profile of
-                                   examples/gp_find_lls.py:159-224); evaluated by the generic kernel */
+                                   examples/gp_find_lls.py:159-224).  One absorber per sample on
+                                   a log-uniform grid (and the deeper levels of a sweep, which
+                                   multiply cached profiles) run the MFMA kernel, the rest the
+                                   generic one */
 
 typedef struct dlagp_ctx dlagp_ctx;     /* one sightline's model + data, resident in HBM    */
 typedef struct dlagp_batch dlagp_batch; /* a launch group of sightlines on one device       */

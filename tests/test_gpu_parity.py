@@ -667,6 +667,31 @@ def test_lls_profile_matches_reference_golden_and_oracle():
         np.testing.assert_allclose(got, ref, rtol=RTOL_LL)
         plain = DeviceSightline(y, mu, M, omega2, v, wl, keep, broadening=broadening).eval(z2, n2)
         assert np.max(np.abs(plain - got)) > 1.0  # the break matters on this grid
+        # one absorber per sample on this log-uniform grid: the MFMA kernel with the continuum term
+        z1, n1 = g["z"], 10.0 ** g["log_nhi"]
+        got1 = dev.eval(z1, n1)
+        ref1 = np.array([R.sample_log_likelihood_k_dlas(st, [z1[i]], [n1[i]]) for i in range(len(z1))])
+        np.testing.assert_allclose(got1, ref1, rtol=RTOL_LL)
+        from gpy_dla_detection_amd.sightline import set_option
+        set_option("path", 1)
+        try:
+            generic1 = dev.eval(z1, n1)
+        finally:
+            set_option("path", 0)
+        np.testing.assert_allclose(got1, generic1, rtol=1e-11)
+        if broadening:  # and the device-resident sweep on top of it (levels > 1 multiply cached LLS profiles)
+            from gpy_dla_detection_amd import parallel
+            from gpy_dla_detection_amd.sightline import DeviceBatch
+
+            S = 160
+            zq = 3.05 + 1.2 * halton(S, 2)
+            nq = 10.0 ** (17.0 + 5.5 * halton(S, 3))
+            batch = DeviceBatch([dev])
+            want = parallel.sweep_batch(batch.eval, zq[None, :], nq, 3, 0.01, seed=4)
+            have = parallel.sweep_batch_device(batch, zq[None, :], nq, 3, 0.01, seed=4)
+            np.testing.assert_array_equal(have[2], want[2])
+            np.testing.assert_allclose(have[0], want[0], rtol=1e-10)
+            np.testing.assert_allclose(have[1], want[1], rtol=1e-10, equal_nan=True)
     with pytest.raises(ValueError):
         from gpy_dla_detection_amd import _lib
         import ctypes
