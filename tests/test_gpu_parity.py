@@ -812,3 +812,46 @@ def test_class_api_device_levels_consume_the_rng_like_the_reference():
             assert np.isnan(ev).all() and np.array_equal(np.random.get_state()[1], before)
     finally:
         dla.dla_samples._nhi_samples = good
+
+
+def test_randomised_sightlines_against_oracle():
+    """
+    60 sightlines of random length, mask pattern, rank and redshift range, a few samples each, automatic
+    kernel selection (core-patch kernel where the mask allows the MFMA path, generic kernel otherwise).
+    """
+    from oracle import ref_like as R
+
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for trial in range(60):
+        n_u = int(rng.integers(40, 3200))
+        n_masked = int(rng.integers(0, max(1, n_u // 12)))
+        k = int(rng.choice([3, 20, 20, 20, 24]))
+        sight = make_sightline(1000 + trial, n_unmasked=n_u, n_masked=n_masked, k=k)
+        if trial % 7 == 3 and n_u > 200:  # a masked run inside the spectrum
+            keep = sight.keep.copy()
+            lo = int(rng.integers(10, n_u - 60))
+            run = int(rng.integers(2, 50))
+            sel = np.ones(int(keep.sum()), dtype=bool)
+            idx = np.cumsum(keep) - 1
+            gone = keep.copy()
+            gone[:] = False
+            gone[lo:lo + run] = keep[lo:lo + run]
+            sel[idx[gone]] = False
+            keep[lo:lo + run] = False
+            sight.keep = keep
+            sight.y, sight.v = sight.y[sel], sight.v[sel]
+            sight.this_mu, sight.this_M, sight.this_omega2 = sight.this_mu[sel], sight.this_M[sel], sight.this_omega2[sel]
+        dev = device_sightline(sight)
+        S = 24
+        z, _, nhi = make_qmc_samples(sight, S)
+        z = z + 1e-3 * rng.standard_normal(S)
+        got = dev.eval(z, nhi)
+        st = oracle_state(sight)
+        pick = rng.choice(S, 6, replace=False)
+        want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in pick])
+        rel = np.max(np.abs(got[pick] - want) / np.abs(want))
+        worst = max(worst, rel)
+        assert rel <= RTOL_LL, "trial %d (n_u=%d, masked=%d, k=%d): %.2e" % (trial, n_u, n_masked, k, rel)
+        assert abs(dev.null() - R.null_log_model_evidence(st)) <= RTOL_LL * abs(R.null_log_model_evidence(st))
+    assert worst < RTOL_LL
