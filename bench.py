@@ -12,7 +12,8 @@ n = 3000 kept pixels (3061 unmasked, 3067 padded), rank k = 20, and S = 10 000 H
 that batch: 10 000 x [Voigt-absorbed model -> low-rank Gaussian log-density] followed by the
 log-mean-exp model evidence on the device.  Samples, model and outputs are resident in HBM
 before the timed region.  With N > 1 every rank sweeps its own sightline (weak scaling,
-no data-path collective) and the per-sightline evidence is all-gathered over RCCL.
+no data-path collective) and the per-step evidences are all-gathered over RCCL once, at the end of the
+timed region.
 
 Prints ONE JSON line on rank 0: the driver's contract keys plus
   roofline      accumulate kernel only: algorithmic FLOP/launch / mean HIP-event duration of
@@ -173,28 +174,28 @@ def main() -> None:
     z = torch.from_numpy(z_host).to(device)
     nhi = torch.from_numpy(nhi_host).to(device)
     out = torch.empty(S, dtype=torch.float64, device=device)
-    # a small ring of result slots: the all-gather of step i may still be reading its slot while step i + 1 runs
-    RING = 4
-    evidences = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(RING)]
-    gathered = [[torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)] for _ in range(RING)]
-    in_flight = [None] * RING
+    # Every step's evidence lands in its own slot; the ranks exchange them with ONE all-gather at the end of
+    # the timed region -- the communication pattern of a sharded catalogue run (parallel.model_evidences_sharded:
+    # each rank sweeps its sightlines, one gather of the per-sightline evidences at the end).
+    slots = max(args.steps, args.warmup, 1)
+    evidences = torch.zeros(slots, dtype=torch.float64, device=device)
+    gathered = torch.zeros(world * slots, dtype=torch.float64, device=device) if world > 1 else None
     counter = [0]
-    evidence = evidences[0]
 
-    def step(collective=True):
-        slot = counter[0] % RING
+    def step():
+        slot = counter[0] % slots
         counter[0] += 1
-        if in_flight[slot] is not None:
-            in_flight[slot].wait()
-            in_flight[slot] = None
         stream = torch.cuda.current_stream().cuda_stream
         dev.eval_device(S, 1, z.data_ptr(), nhi.data_ptr(), out.data_ptr(), stream)
         # "- log S" and the log-mean-exp model evidence of the level (reference dla_gp.py:155-190)
-        sl.level_evidence_device(out.data_ptr(), 1, S, 0, evidences[slot].data_ptr(), device=local_rank, stream=stream)
-        if world > 1 and collective:
-            in_flight[slot] = dist.all_gather(gathered[slot], evidences[slot], async_op=True)
-            return in_flight[slot]
-        return None
+        sl.level_evidence_device(out.data_ptr(), 1, S, 0, evidences.data_ptr() + 8 * slot, device=local_rank,
+                                 stream=stream)
+
+    def exchange():
+        if world > 1 and args.rehearse_on_one_gpu:  # gloo has no all_gather_into_tensor for device tensors
+            dist.all_gather(list(gathered.view(world, slots).unbind(0)), evidences)
+        elif world > 1:
+            dist.all_gather_into_tensor(gathered, evidences)
 
     def fence():
         torch.cuda.synchronize()
@@ -205,25 +206,24 @@ def main() -> None:
     # The GPU leaves its idle power state only after tens of milliseconds of load: the first ~40 steps run
     # ~12 % slower than the sustained rate (profiles/r01_clock_ramp.txt).  Untimed steps until the device
     # has been busy for --ramp-ms, then the W warmup steps the contract asks for, then exactly K timed steps.
-    # (local work only: the loop is time-based, so ranks may run different numbers of iterations)
+    # (local work only -- step() never communicates: the loop is time-based, so ranks may run different numbers of
+    # iterations)
     ramp_start = time.perf_counter()
     while (time.perf_counter() - ramp_start) * 1e3 < args.ramp_ms:
         for _ in range(10):
-            step(collective=False)
+            step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
-        work = step()
-        if work is not None:
-            work.wait()
+        step()
+    exchange()
     fence()
+    counter[0] = 0
     sl.set_option("timing", 1)
     sl.timing_read(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    for work in in_flight:
-        if work is not None:
-            work.wait()
+    exchange()
     fence()
     elapsed = time.perf_counter() - t0
     sl.set_option("timing", 0)
@@ -262,7 +262,7 @@ def main() -> None:
                 "workload": "configs[1]: 1 sightline x %d QMC DLA samples per GPU, n=%d pixels (n_u=%d), rank k=%d, 3 Lyman lines, 1 absorber" % (S, sight.n, N_UNMASKED, sight.k),
                 "sightlines_per_gpu": 1,
                 "samples_per_sightline": S,
-                "parallelism": "sightlines sharded across GPUs, all-gather of per-sightline evidence",
+                "parallelism": "sightlines sharded across GPUs, one all-gather of the evidences at the end",
             },
             "spectra_per_s_equiv": value / (1 + S + 4 * S),
             "roofline": {
@@ -278,7 +278,7 @@ def main() -> None:
                 "flop_per_eval": flops,
                 "logical_hbm_frac": (S * 8.0 * sight.n * (sight.k + 5) / kernel_s / 8e12) if kernel_s > 0 else 0.0,
             },
-            "evidence": float(evidence.item()),
+            "evidence": float(evidences[0].item()),
         }
         if baseline is not None:
             line["cpu_baseline"] = baseline
