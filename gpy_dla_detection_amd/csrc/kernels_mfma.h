@@ -259,6 +259,12 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     typedef double v4d_a16 __attribute__((ext_vector_type(4), aligned(16)));
 
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = 0;  // finalize raises it
+    // Wave priorities.  The two waves of a SIMD share the FP64 pipe; an MFMA holds it for 64 cycles, a vector
+    // instruction for 4, so with equal priorities the wave that is in its MFMA loop starves the one that is in a
+    // vector phase, which then reaches its own MFMA loop late and leaves latencies uncovered.  Everything but
+    // the MFMAs runs at raised priority (2; the dependent weight arithmetic at the head of each step at 3), the
+    // MFMAs themselves at 0: -3 % kernel time (A/B on one device).
+    __builtin_amdgcn_s_setprio(2);
     const int b = blockIdx.y;
     const SightlineDev &sl = sightlines[b];
     const int split = blockIdx.x % nsplit;
@@ -630,6 +636,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         const double *a_row = &a_lds[s_loc * A_STRIDE + slot];
         double a = a_row[0];
         for (int st = 0; st < pass_steps; ++st) {
+            __builtin_amdgcn_s_setprio(3);
             const double a2 = a * a;
             const double d = fma(rec_ov.x, a2, rec_ov.y);
             const double h = fast_rcp1(d);
@@ -649,6 +656,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
             // keep the prefetches above in front of the MFMAs: their results are not needed before
             // the next step, 16 MFMAs (>= 1024 cycles) from here
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
             const int soff = nxt * STEP_BYTES;
 #pragma unroll
             for (int j = 0; j < NPAIR; ++j) {
@@ -667,6 +676,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
             }
         }
+        __builtin_amdgcn_s_setprio(2);
         // the next pass overwrites raw[] / a_lds[]: order the LDS reads above before those writes
         lds_wave_sync();
         if (stamps) t_mfma += stamp_now() - t_mark;
