@@ -261,9 +261,9 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = 0;  // finalize raises it
     // Wave priorities.  The two waves of a SIMD share the FP64 pipe; an MFMA holds it for 64 cycles, a vector
     // instruction for 4, so with equal priorities the wave that is in its MFMA loop starves the one that is in a
-    // vector phase, which then reaches its own MFMA loop late and leaves latencies uncovered.  Everything but
-    // the MFMAs runs at raised priority (2; the dependent weight arithmetic at the head of each step at 3), the
-    // MFMAs themselves at 0: -3 % kernel time (A/B on one device).
+    // vector phase, which then reaches its own MFMA loop late and leaves latencies uncovered.  Measured best
+    // (A/B on one device, -5 % kernel time against equal priorities): Voigt loop and pass set-up 2, the
+    // LDS-latency-bound convolution 1, the dependent weight arithmetic at the head of each step 3, MFMAs 0.
     __builtin_amdgcn_s_setprio(2);
     const int b = blockIdx.y;
     const SightlineDev &sl = sightlines[b];
@@ -557,6 +557,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                         lds_wave_sync();
                     }
                 }
+                __builtin_amdgcn_s_setprio(1);
                 // convolution (voigt.py:319) on the kept pixels (dla_gp.py:388), product over absorbers.
                 // Always all 14 steps, branch-free, so that the LDS reads of different steps overlap:
                 // lanes beyond the pass's pixels re-read a valid window and write unused slots.
