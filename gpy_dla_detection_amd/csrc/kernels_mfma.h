@@ -565,7 +565,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 // serialising them one ds_read + wait at a time), then the arithmetic runs on them.
                 const double *raw_row = raw + s_loc * DLAGP_RAW_STRIDE;
                 double *a_dst = &a_lds[s_loc * A_STRIDE + slot];
-                constexpr int CONV_GROUP = 4;
+                constexpr int CONV_GROUP = PATCH && MODE == 0 ? 7 : 4;  // reads of that many steps in flight; the single-absorber kernel has the registers for 7
                 constexpr int NW = BROADEN ? DLAGP_NUM_TAPS : 1;
 #pragma unroll
                 for (int g0 = 0; g0 < DLAGP_MAX_PASS_STEPS; g0 += CONV_GROUP) {
