@@ -855,3 +855,42 @@ def test_randomised_sightlines_against_oracle():
         assert rel <= RTOL_LL, "trial %d (n_u=%d, masked=%d, k=%d): %.2e" % (trial, n_u, n_masked, k, rel)
         assert abs(dev.null() - R.null_log_model_evidence(st)) <= RTOL_LL * abs(R.null_log_model_evidence(st))
     assert worst < RTOL_LL
+
+
+def test_device_entry_points_are_graph_capturable():
+    """
+    dlagp_eval_device + dlagp_level_evidence_device only enqueue work on the caller's stream once the workspace
+    exists (no allocation, no synchronisation): a HIP graph captured around them replays to the same numbers.
+    """
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch has no GPU")
+    from gpy_dla_detection_amd import sightline as sl
+
+    device = torch.device("cuda", 0)
+    sight = make_sightline(1, n_unmasked=900, n_masked=11)
+    dev = device_sightline(sight)
+    S = 2000
+    z, _, nhi = make_qmc_samples(sight, S)
+    d_z, d_n = torch.from_numpy(z).to(device), torch.from_numpy(nhi).to(device)
+    out = torch.empty(S, dtype=torch.float64, device=device)
+    ev = torch.zeros(1, dtype=torch.float64, device=device)
+
+    def step(stream):
+        dev.eval_device(S, 1, d_z.data_ptr(), d_n.data_ptr(), out.data_ptr(), stream)
+        sl.level_evidence_device(out.data_ptr(), 1, S, 0, ev.data_ptr(), device=0, stream=stream)
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        step(side.cuda_stream)  # first call sizes the workspace
+        torch.cuda.synchronize()
+        want, want_ev = out.clone(), ev.clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            step(torch.cuda.current_stream().cuda_stream)
+    out.zero_()
+    ev.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and torch.equal(ev, want_ev)
+    np.testing.assert_allclose(out.cpu().numpy() + np.log(S), dev.eval(z, nhi), rtol=1e-13)
