@@ -262,8 +262,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     // Wave priorities.  The two waves of a SIMD share the FP64 pipe; an MFMA holds it for 64 cycles, a vector
     // instruction for 4, so with equal priorities the wave that is in its MFMA loop starves the one that is in a
     // vector phase, which then reaches its own MFMA loop late and leaves latencies uncovered.  Measured best
-    // (A/B on one device, -5 % kernel time against equal priorities): Voigt loop and pass set-up 2, the
-    // LDS-latency-bound convolution 1, the dependent weight arithmetic at the head of each step 3, MFMAs 0.
+    // (A/B on one device, -5 % kernel time against equal priorities): Voigt loop 2, the latency-bound parts
+    // (pass set-up, convolution) 1, the dependent weight arithmetic at the head of each step 3, MFMAs 0.
     __builtin_amdgcn_s_setprio(2);
     const int b = blockIdx.y;
     const SightlineDev &sl = sightlines[b];
@@ -496,6 +496,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                     const double c8v = vgpr_constant(DLAGP_LINES.exp2c[8]);
                     const double w3v[3] = {vgpr_constant(DLAGP_LINES.wing[0][3]), vgpr_constant(DLAGP_LINES.wing[1][3]),
                                            vgpr_constant(DLAGP_LINES.wing[2][3])};
+                    __builtin_amdgcn_s_setprio(2);
                     // one running LDS address (hipcc otherwise rebuilds lane * 8 + offset for every sample)
                     __attribute__((address_space(3))) double *raw_w = (__attribute__((address_space(3))) double *)raw + lane;
                     asm volatile("" : "+v"(raw_w));
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
             }
         }
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(1);
         // the next pass overwrites raw[] / a_lds[]: order the LDS reads above before those writes
         lds_wave_sync();
         if (stamps) t_mfma += stamp_now() - t_mark;
