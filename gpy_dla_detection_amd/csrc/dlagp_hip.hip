@@ -54,10 +54,11 @@ static int fail(int code, const char *fmt, ...) {
 static int64_t g_opt_pixel_splits = 0;
 static int64_t g_opt_path = 0;
 static int64_t g_opt_timing = 0;
-static int64_t g_opt_debug = 0;
+static int64_t g_opt_debug = 0;  // bit 1: stamped instantiation of the MFMA kernel (diagnostics)
 static int64_t g_opt_core_patch = 1;     // MFMA kernel: line cores repaired outside the sample loop when eligible
 static int64_t g_opt_profile_cache = 1;  // multi-level sweeps keep level-1 profiles in HBM (0 = recompute)
-static int64_t g_opt_profile_cache_max_mb = 98304;  // never take more than this for the cache  // bit 1: stamped instantiation of the MFMA kernel (diagnostics)
+// never more than this for the cache (MB), and never more than half of the free HBM
+static int64_t g_opt_profile_cache_max_mb = 196608;
 
 struct EventPair {
     hipEvent_t start, stop;

@@ -229,7 +229,7 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
  *                     "profile_cache" (1 = dlagp_batch_sweep keeps the level-1 absorption profiles
  *                     of all QMC points in HBM, 8 S n_pad bytes per sightline, and multiplies cached
  *                     rows at the deeper levels instead of re-evaluating Voigt profiles; 0 = recompute),
- *                     "profile_cache_max_mb" (upper bound of that allocation, default 98304)
+ *                     "profile_cache_max_mb" (upper bound of that allocation, default 196608; never more than half of the free HBM)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.
  */
