@@ -294,3 +294,35 @@ def test_process_qso_matches_reference_driver_golden(tmp_path):
         back = np.load(path)
         np.testing.assert_array_equal(back["base_sample_inds"], results["base_sample_inds"])
         assert list(back["qso_list"]) == ["spec-0", "spec-1", "spec-2"]
+
+
+def test_occupation_log_priors_match_reference_model_selection():
+    """the driver's vectorised priors == what BayesModelSelect assembles from the three models (G6)"""
+    from gpy_dla_detection_amd.run_bayes_select import occupation_log_priors
+    from gpy_dla_detection_amd.samples import DLASamples, SubDLASamples
+
+    g = load_golden("model_selection.npz")
+    params = Parameters(num_dla_samples=16)
+    u = halton(16, 3)
+    dla = DLASamples(params, None, halton(16, 2), 20.0 + 3.0 * u)
+    sub = SubDLASamples(params, None, halton(16, 2), 19.5 + 0.5 * u, Z_dla=1.0, Z_lls=0.25)
+    got = occupation_log_priors(FixedPrior(), 3.0, 4, dla, sub)
+    np.testing.assert_allclose(got, g["log_priors"], rtol=1e-13)
+    assert abs(np.exp(got).sum() - 1.0) < 1e-12   # [null, sub-DLA, DLA(1..4)] is a complete partition
+
+
+def test_prepare_data_is_the_data_half_of_set_data():
+    """prepare_data (used by the catalogue driver) leaves exactly what NullGP.set_data leaves (G7)"""
+    from gpy_dla_detection_amd.null_gp import prepare_data
+
+    g = load_golden("set_data.npz")
+    z_qso, rest, flux, nv, mask, *_ = raw_spectrum_and_model()
+    st = prepare_data(Parameters(), rest, flux, nv, mask, z_qso, normalize=True)
+    for name in ("x", "y", "v", "padded_wavelengths", "unmasked_wavelengths", "this_wavelengths"):
+        np.testing.assert_allclose(st[name], g[name], rtol=1e-14, atol=0, err_msg=name)
+    np.testing.assert_array_equal(st["ind_unmasked"], g["ind_unmasked"])
+    keep = ~st["pixel_mask"][st["ind_unmasked"]]
+    assert keep.sum() == st["y"].shape[0] and keep.shape[0] == st["unmasked_wavelengths"].shape[0]
+    raw = prepare_data(Parameters(), rest, flux, nv, mask, z_qso, normalize=False)
+    np.testing.assert_allclose(raw["y"] / st["normalization_median"], st["y"], rtol=1e-15)
+    assert "normalization_median" not in raw
