@@ -316,26 +316,31 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     // All loads of a thread are issued before the first use (the loop is fully unrolled for the usual
     // split counts): issued one iteration at a time, the ~15 dependent round trips to L2/HBM were 70 % of
     // this kernel.
-    constexpr int ITER = (DLAGP_FIN_STAGED * NS + DLAGP_FIN_THREADS - 1) / DLAGP_FIN_THREADS;
+    // 16-byte loads: a thread takes two neighbouring samples of a column (the 16 samples of a column are 128
+    // contiguous bytes), which halves the number of load instructions in flight per byte.
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int PAIRS = DLAGP_FIN_STAGED * (NS / 2);
+    constexpr int ITER = (PAIRS + DLAGP_FIN_THREADS - 1) / DLAGP_FIN_THREADS;
     auto stage = [&](auto nsplit_c) {
         constexpr int H = decltype(nsplit_c)::value;
-        double v[ITER][H];
+        d2 v[ITER][H];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int idx = tid + it * DLAGP_FIN_THREADS;
-            const int cl = idx < DLAGP_FIN_STAGED * NS ? idx : tid;  // clamp: a valid address, value unused
-            const int c = cl / NS, smp = cl % NS;
+            const int cl = idx < PAIRS ? idx : tid;  // clamp: a valid address, value unused
+            const int c = cl / (NS / 2), smp = 2 * (cl % (NS / 2));
             const int src = c < NC ? c : (c < NC + K ? qbase + (c - NC) : sbase + (c - NC - K));
 #pragma unroll
-            for (int h = 0; h < H; ++h) v[it][h] = part[partial_index(h, nblocks, block, rw, src, smp)];
+            for (int h = 0; h < H; ++h)
+                v[it][h] = *reinterpret_cast<const d2 *>(part + partial_index(h, nblocks, block, rw, src, smp));
         }
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int idx = tid + it * DLAGP_FIN_THREADS;
-            double acc = 0.0;
+            d2 acc = d2{0.0, 0.0};
 #pragma unroll
             for (int h = 0; h < H; ++h) acc += v[it][h];
-            if (idx < DLAGP_FIN_STAGED * NS) fin_lds[idx] = acc;
+            if (idx < PAIRS) *reinterpret_cast<d2 *>(fin_lds + 2 * idx) = acc;
         }
     };
     if (nsplit == 1) stage(std::integral_constant<int, 1>{});
