@@ -51,6 +51,8 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "dlagp_level_evidence_device": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "dlagp_set_option": (c_int, [c_char_p, c_int64]),
+    "dlagp_plan_cut": (c_int, [c_int64, c_double, c_int64, POINTER(c_int), _dp]),
+    "dlagp_get_option": (c_int, [c_char_p, POINTER(c_int64)]),
     "dlagp_timing_read": (c_int, [_dp, POINTER(c_int64), c_int]),
     "dlagp_debug_read": (c_int, [POINTER(ctypes.c_uint64), c_int, c_int]),
 }

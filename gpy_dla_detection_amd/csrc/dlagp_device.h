@@ -8,6 +8,10 @@
 //   step    4 consecutive kept pixels = the K extent of one v_mfma_f64_16x16x4_f64
 //   tile    16 columns of the shared operand P (stored as interleaved tile pairs); "w-tiles" hold vech(M_i M_i') and are weighted
 //           by a^2/d, "q-tiles" hold M_i and are weighted by a r/d
+//   slot    position of a pixel in the MFMA path's own pixel order: the kept pixels in order, with zero-weight
+//           padding slots (y = mu = omega2 = 0, v = 1, zero operand rows: they contribute exactly nothing)
+//           inserted so that every chunk of 8 slots has its convolution windows inside 64 consecutive entries,
+//           whatever the pixel mask looks like (reference masks: null_gp.py:139-152, read_spec.py:38-71)
 #pragma once
 #include <stdint.h>
 
@@ -43,8 +47,12 @@ struct SightlineDev {
     const double *v;       // [n_pad]  padding: 1  (so d = 1, log d = 0, r = 0)
     const int *pos;        // [n_pad]  first entry of the pixel's window; padding: pos[n - 1]
     const double *lam;     // [E]      observed wavelength of every entry, Angstrom
-    const double *P;       // [nsteps][tile pairs][64][2] shared operand, see build_shared_operand
-    const double *aux;     // [n_pad][8] per-pixel records {y, mu, omega2, v, pos, 0, 0, 0} (MFMA path)
+    const double *P;       // [nsteps][tile pairs][64][2] shared operand of the generic path, see build_shared_operand
+    // MFMA path (rank padded to 20): slot-ordered copies
+    int n_slots;           // kept pixels + padding slots, a multiple of 8
+    int nsteps_m;          // n_slots / 4
+    const double *Pm;      // [nsteps_m][8 pairs][64][2] MFMA operand, see build_mfma_operand
+    const double *aux;     // [n_slots][8] per-slot records {y, mu, omega2, v, pos, 0, 0, 0}
     double taps[DLAGP_NUM_TAPS];  // instrument profile (or {1, 0, ...})
 };
 

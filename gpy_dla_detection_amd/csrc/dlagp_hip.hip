@@ -14,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/dlagp.h"
@@ -59,6 +60,11 @@ static int64_t g_opt_core_patch = 1;     // MFMA kernel: line cores repaired out
 static int64_t g_opt_profile_cache = 1;  // multi-level sweeps keep level-1 profiles in HBM (0 = recompute)
 // never more than this for the cache (MB), and never more than half of the free HBM
 static int64_t g_opt_profile_cache_max_mb = 196608;
+// read-only diagnostics of the most recent launch / sweep (dlagp_get_option): which kernel served it
+static int64_t g_last_launch_path = 0;    // 1 generic kernel, 2 MFMA kernel
+static int64_t g_last_launch_items = 0;   // work items (waves) of the last MFMA launch
+static int64_t g_last_launch_parts = 0;   // most pieces a block of 16 samples was cut into
+static int64_t g_last_sweep_cached = 0;   // the last multi-level sweep used the profile cache
 
 struct EventPair {
     hipEvent_t start, stop;
@@ -239,16 +245,18 @@ struct Workspace {
 static std::mutex g_spare_mutex;
 static std::map<int, Workspace> g_spare_workspace;  // per device: workspace of the last destroyed batch
 
-// pass / split tables of one sightline for one split count (MFMA path)
-struct SightlinePlan {
-    DeviceBuffer passes;  // PassDesc[npasses]
-    DeviceBuffer splits;  // int2[nsplit]: pass range of every split
-    int npasses = 0;
-};
-
-// the tables of every sightline of a launch group, as device arrays of device pointers
-struct GroupPlan {
-    DeviceBuffer pass_ptrs, split_ptrs;
+// Decomposition of one MFMA launch (a launch group at one sample count) into work items, see build_plan
+struct LaunchPlan {
+    DeviceBuffer passes;  // PassDesc[]: the pass lists of all items (shared between items with equal pixel ranges)
+    DeviceBuffer items;   // WorkItem[nitems], largest first
+    DeviceBuffer counts;  // unsigned char[nblocks]: pieces per block of 16 samples (partial-sum slots to add)
+    int nitems = 0;
+    int max_parts = 1;
+    void release() {
+        passes.release();
+        items.release();
+        counts.release();
+    }
 };
 
 struct dlagp_ctx;
@@ -260,19 +268,23 @@ struct LaunchGroup {
     DeviceBuffer d_table;  // SightlineDev[nb]
     int k = 0, row_width = 0, num_lines = 0;
     bool broadening = true;
-    int max_entries = 0, max_npad = 0, max_chunks = 0;
+    int max_entries = 0, max_npad = 0;
+    hipStream_t last_stream = nullptr;  // stream of the most recent launch (drained before buffers are recycled)
+    bool launched = false;
     bool mfma_ok = false;
     bool grid_uniform = false;  // every member's wavelength grid is log-uniform (core patch eligible)
     bool lls_break = false;     // members carry the Lyman-limit term (all or none, else no MFMA path)
     Workspace ws;
-    std::map<int, std::unique_ptr<GroupPlan>> plans;
+    int max_slots = 0;  // largest n_slots of a member (row stride of the profile cache)
+    std::map<std::pair<int64_t, int64_t>, std::unique_ptr<LaunchPlan>> plans;  // key: (S, forced split count)
     void release() {
+        // asynchronous entry points may have left kernels in flight that still use these buffers, and released
+        // buffers go back to a pool other contexts draw from
+        if (launched) (void)hipStreamSynchronize(last_stream);
+        launched = false;
         d_table.release();
         ws.release();
-        for (auto &kv : plans) {
-            kv.second->pass_ptrs.release();
-            kv.second->split_ptrs.release();
-        }
+        for (auto &kv : plans) kv.second->release();
         plans.clear();
     }
 };
@@ -290,10 +302,11 @@ struct dlagp_ctx {
     int user_k = 0;            // rank the caller passed (k <= 20 is zero-padded to 20 internally)
     SightlineDev sl{};         // host copy of the descriptor (device pointers inside)
     DeviceBuffer y, mu, omega2, v, pos, lam, P, aux;
+    DeviceBuffer Pm, slot_pixel, slot_pos;  // MFMA path: slot-ordered operand and slot tables
     DeviceBuffer dense_M;      // interpolated / uploaded factor, row-major [n][k], kept for dlagp_ctx_read_model
-    std::vector<int> h_pos;    // host copy of pos[], for planning
-    bool mfma_ok = false;      // rank padded to 20 and every 8-pixel chunk fits one 64-entry pass
-    std::map<int, std::unique_ptr<SightlinePlan>> plans;
+    std::vector<int> h_pos;    // host copy of pos[]
+    std::vector<int> h_slot_pos;  // window start of every slot (padding slots repeat their chunk's last pixel), for planning
+    bool mfma_ok = false;      // rank padded to 20
     LaunchGroup self;          // the group {this}
 };
 
@@ -302,142 +315,201 @@ struct dlagp_batch {
 };
 
 // ------------------------------------------------------------------------------------------------
-// planning: splits = equal ranges of 8-pixel chunks; passes = runs of <= 7 chunks whose
-// convolution windows fit in 64 consecutive entries (kernels_mfma.h)
+// planning (MFMA path)
+//   slots   the kept pixels in order, padded so that every chunk of 8 slots has its convolution windows inside
+//           64 consecutive entries (a mask gap of more than ~50 pixels closes the chunk with zero-weight slots)
+//   passes  runs of <= 7 chunks whose windows fit in 64 consecutive entries (kernels_mfma.h)
+//   items   one wave each: 16 samples x a range of chunks of one sightline
 // ------------------------------------------------------------------------------------------------
-static bool plan_passes(const std::vector<int> &pos, int n_pad, int ntaps, int nsplit,
-                        std::vector<PassDesc> &passes, std::vector<int2> &splits) {
-    const int nchunks = n_pad / DLAGP_CHUNK_PIXELS;
-    passes.clear();
-    splits.assign(nsplit, int2{0, 0});
-    for (int h = 0; h < nsplit; ++h) {
-        const int c0 = (int)((long)h * nchunks / nsplit);
-        const int c1 = (int)((long)(h + 1) * nchunks / nsplit);
-        splits[h].x = (int)passes.size();
-        int c = c0;
-        while (c < c1) {
-            PassDesc pd{pos[c * DLAGP_CHUNK_PIXELS], c, 0, 0};
-            while (c + pd.nchunks < c1 && pd.nchunks < DLAGP_MAX_PASS_CHUNKS &&
-                   pos[(c + pd.nchunks) * DLAGP_CHUNK_PIXELS + DLAGP_CHUNK_PIXELS - 1] + ntaps <=
-                       pd.entry_start + DLAGP_PASS_ENTRIES)
-                ++pd.nchunks;
-            if (pd.nchunks == 0) return false;  // a single chunk spans more than 64 entries
-            passes.push_back(pd);
-            c += pd.nchunks;
+static void plan_slots(const std::vector<int> &pos, int n, int ntaps, std::vector<int> &slot_pixel,
+                       std::vector<int> &slot_pos) {
+    slot_pixel.clear();
+    slot_pos.clear();
+    int i = 0;
+    while (i < n) {
+        const int first = pos[i];
+        int filled = 0;
+        while (i < n && filled < DLAGP_CHUNK_PIXELS && pos[i] + ntaps <= first + DLAGP_PASS_ENTRIES) {
+            slot_pixel.push_back(i);
+            slot_pos.push_back(pos[i]);
+            ++i;
+            ++filled;
         }
-        splits[h].y = (int)passes.size();
+        for (; filled < DLAGP_CHUNK_PIXELS; ++filled) {  // zero-weight slots: they re-read the last pixel's window
+            slot_pixel.push_back(-1);
+            slot_pos.push_back(slot_pos.back());
+        }
     }
-    return true;
 }
 
-static int sightline_plan(dlagp_ctx *ctx, int nsplit, SightlinePlan **out) {
-    auto it = ctx->plans.find(nsplit);
-    if (it != ctx->plans.end()) {
-        *out = it->second.get();
-        return DLAGP_OK;
+// passes of the chunk range [c0, c1) of one sightline, appended to `passes`
+static void plan_passes(const std::vector<int> &slot_pos, int ntaps, int c0, int c1, std::vector<PassDesc> &passes) {
+    int c = c0;
+    while (c < c1) {
+        PassDesc pd{slot_pos[c * DLAGP_CHUNK_PIXELS], c, 1, 0};  // a single chunk always fits (plan_slots)
+        while (c + pd.nchunks < c1 && pd.nchunks < DLAGP_MAX_PASS_CHUNKS &&
+               slot_pos[(c + pd.nchunks) * DLAGP_CHUNK_PIXELS + DLAGP_CHUNK_PIXELS - 1] + ntaps <=
+                   pd.entry_start + DLAGP_PASS_ENTRIES)
+            ++pd.nchunks;
+        passes.push_back(pd);
+        c += pd.nchunks;
     }
-    std::vector<PassDesc> passes;
-    std::vector<int2> splits;
-    if (!plan_passes(ctx->h_pos, ctx->sl.n_pad, ctx->sl.ntaps, nsplit, passes, splits))
-        return fail(DLAGP_EINVAL, "pixel mask too ragged for the MFMA path");
-    std::unique_ptr<SightlinePlan> plan(new SightlinePlan());
-    int rc = plan->passes.reserve(std::max<size_t>(1, passes.size()) * sizeof(PassDesc));
-    if (!rc) rc = plan->splits.reserve(splits.size() * sizeof(int2));
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(plan->passes.ptr, passes.data(), passes.size() * sizeof(PassDesc), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(plan->splits.ptr, splits.data(), splits.size() * sizeof(int2), hipMemcpyHostToDevice));
-    plan->npasses = (int)passes.size();
-    *out = plan.get();
-    ctx->plans[nsplit] = std::move(plan);
-    return DLAGP_OK;
 }
 
-static int group_plan(LaunchGroup &g, int nsplit, GroupPlan **out) {
-    auto it = g.plans.find(nsplit);
+// Work items of one launch.  A wave owns 16 samples ("group") of one sightline over a range of its chunks; the
+// chip holds 2048 such waves at a time (256 CUs x 4 SIMDs x 2, register-limited), and a SIMD's FP64 pipe is
+// busy for the sum of its waves' work.  Every group of a sightline is cut at the SAME chunk positions: the waves
+// then sweep the sightline's operand Pm (6 MB, more than one XCD's L2) as a few coherent fronts that stay
+// L2-resident -- cutting the (group, chunk) space into 2048 equal intervals balances perfectly but puts every wave
+// at a different position and came out 10 % slower (profiles/r02_work_decomposition.txt).  Two shapes of cut are
+// priced with a simple model (time of the busiest wave slot, in chunks; `o` = fixed cost of an item) and the
+// cheaper one is taken:
+//   (A) h equal pieces per group, h = 1..8:            ceil(groups h / 2048) (C / h + o)
+//   (B) f = floor(2048 / groups) full pieces of F chunks plus a remainder piece R = C - f F; the 2048 - f groups
+//       slots left over work through the remainder pieces, m = ceil(groups / slots left) each:
+//                                                        F + o = m (R + o)
+//       One sightline x 10 000 samples = 625 groups: (A) h = 3 leaves 173 of the 2048 slots empty (129 chunks per
+//       slot); (B) f = 3, F = 117, R = 24 fills them (122).
+// Items are dispatched in index order as slots free up: full pieces first, then the remainders; the order affects
+// only the balance, never the results.  Every block of 16 samples adds its pieces' partial sums in piece order
+// (finalize kernels, `counts`), so results are deterministic.  Option pixel_splits = h forces (A) with that h.
+// the cut, as fractions of a sightline's chunks: `full` pieces of `frac` each, then a remainder if frac * full < 1
+static void choose_cut(long groups, double C, int64_t forced, int *full_out, double *frac_out) {
+    const long slots = 2048;
+    const double o = 5.0;  // prologue + epilogue of an item ~ 5 chunks of work
+    int full = 1;
+    double frac = 1.0, best = 1e300;
+    const int h_max = (int)std::max(1.0, std::min(8.0, std::floor(C / DLAGP_MAX_PASS_CHUNKS)));
+    for (int h = 1; h <= h_max; ++h) {
+        if (forced > 0 && h != std::min<int64_t>(forced, h_max)) continue;
+        const double cost = (double)((groups * h + slots - 1) / slots) * (C / h + o);
+        if (cost < best) {
+            best = cost;
+            full = h;
+            frac = 1.0 / h;
+        }
+    }
+    const long f = slots / std::max<long>(groups, 1);
+    if (forced <= 0 && f >= 1 && slots - f * groups > 0) {
+        const long m = (groups + (slots - f * groups) - 1) / (slots - f * groups);
+        const double F = (m * (C + o) - o) / (1.0 + (double)m * f);
+        const double R = C - f * F;
+        if (R >= DLAGP_MAX_PASS_CHUNKS && F + o < best) {
+            full = (int)f;
+            frac = F / C;
+        }
+    }
+    *full_out = full;
+    *frac_out = frac;
+}
+
+static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
+    const std::pair<int64_t, int64_t> key(S, g_opt_pixel_splits);
+    auto it = g.plans.find(key);
     if (it != g.plans.end()) {
         *out = it->second.get();
         return DLAGP_OK;
     }
-    std::vector<const PassDesc *> pp;
-    std::vector<const int2 *> sp;
-    for (dlagp_ctx *ctx : g.ctxs) {
-        SightlinePlan *plan = nullptr;
-        int rc = sightline_plan(ctx, nsplit, &plan);
-        if (rc) return rc;
-        pp.push_back(plan->passes.as<PassDesc>());
-        sp.push_back(plan->splits.as<int2>());
+    const int nb = (int)g.ctxs.size();
+    const long ngroups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
+    const long groups = (long)nb * ngroups;
+    std::vector<long> chunks(nb);
+    double mean_chunks = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        chunks[b] = g.ctxs[b]->sl.n_slots / DLAGP_CHUNK_PIXELS;
+        mean_chunks += (double)chunks[b] / nb;
     }
-    std::unique_ptr<GroupPlan> gp(new GroupPlan());
-    int rc = gp->pass_ptrs.reserve(pp.size() * sizeof(void *));
-    if (!rc) rc = gp->split_ptrs.reserve(sp.size() * sizeof(void *));
+    int full = 1;
+    double frac = 1.0;
+    choose_cut(groups, mean_chunks, g_opt_pixel_splits, &full, &frac);
+    struct Piece {
+        int b, group, part, c0, c1;
+        bool rest;
+    };
+    std::vector<Piece> pieces;
+    const bool remainder = frac * full < 1.0 - 1e-9;
+    std::vector<unsigned char> counts((size_t)groups, 1);
+    int max_parts = 1;
+    for (int b = 0; b < nb; ++b) {
+        // cut positions of sightline b (the same for all of its groups); empty pieces are dropped
+        std::vector<Piece> cuts;
+        int c0 = 0;
+        for (int j = 1; j <= full + (remainder ? 1 : 0); ++j) {
+            const bool last = j == full + (remainder ? 1 : 0);
+            const int c1 = last ? (int)chunks[b] : (int)std::min<long>(chunks[b], std::llround(j * frac * chunks[b]));
+            if (c1 > c0) cuts.push_back({b, 0, (int)cuts.size(), c0, c1, remainder && last});
+            c0 = c1;
+        }
+        max_parts = std::max(max_parts, (int)cuts.size());
+        for (long grp = 0; grp < ngroups; ++grp) {
+            counts[b * ngroups + grp] = (unsigned char)cuts.size();
+            for (Piece pc : cuts) {
+                pc.group = (int)grp;
+                pieces.push_back(pc);
+            }
+        }
+    }
+    // dispatch order: the full pieces in (sightline, group, piece) order, then the remainders
+    if (remainder) std::stable_partition(pieces.begin(), pieces.end(), [](const Piece &x) { return !x.rest; });
+    std::vector<PassDesc> passes;
+    std::map<std::tuple<int, int, int>, std::pair<int, int>> ranges;  // (b, c0, c1) -> pass range
+    std::vector<WorkItem> items;
+    items.reserve(pieces.size());
+    for (const Piece &pc : pieces) {
+        const auto rkey = std::make_tuple(pc.b, pc.c0, pc.c1);
+        auto rit = ranges.find(rkey);
+        if (rit == ranges.end()) {
+            const int begin = (int)passes.size();
+            plan_passes(g.ctxs[pc.b]->h_slot_pos, g.ctxs[pc.b]->sl.ntaps, pc.c0, pc.c1, passes);
+            rit = ranges.emplace(rkey, std::make_pair(begin, (int)passes.size())).first;
+        }
+        items.push_back(WorkItem{pc.b, pc.group, pc.part, rit->second.first, rit->second.second, 0, 0, 0});
+    }
+    std::unique_ptr<LaunchPlan> plan(new LaunchPlan());
+    int rc = plan->passes.reserve(std::max<size_t>(1, passes.size()) * sizeof(PassDesc));
+    if (!rc) rc = plan->items.reserve(std::max<size_t>(1, items.size()) * sizeof(WorkItem));
+    if (!rc) rc = plan->counts.reserve(std::max<size_t>(1, counts.size()));
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(gp->pass_ptrs.ptr, pp.data(), pp.size() * sizeof(void *), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(gp->split_ptrs.ptr, sp.data(), sp.size() * sizeof(void *), hipMemcpyHostToDevice));
-    *out = gp.get();
-    g.plans[nsplit] = std::move(gp);
+    // planning runs on the launching thread, ahead of the launch on the caller's stream: blocking copies
+    HIP_TRY(hipMemcpy(plan->passes.ptr, passes.data(), passes.size() * sizeof(PassDesc), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(plan->items.ptr, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(plan->counts.ptr, counts.data(), counts.size(), hipMemcpyHostToDevice));
+    plan->nitems = (int)items.size();
+    plan->max_parts = max_parts;
+    *out = plan.get();
+    g.plans[key] = std::move(plan);
     return DLAGP_OK;
-}
-
-// Number of pixel splits.  Every SIMD holds 2 waves only when all 2048 resident wave slots are
-// taken; a single sightline with S = 10 000 has just 625 sample groups (one wave each), so its
-// pixels are cut into floor(2048 / groups) equal splits whose
-// partial sums the finalize kernel adds in a fixed order.  More splits than that would only add
-// partial-sum traffic and halo recomputation.
-static int choose_splits(const LaunchGroup &g, int64_t S) {
-    const int max_h = std::max(1, g.max_chunks);
-    if (g_opt_pixel_splits > 0) return (int)std::min<int64_t>(g_opt_pixel_splits, max_h);
-    const long groups = (long)g.ctxs.size() * ((S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP);
-    const long slots = 2048;  // 256 CUs x 4 SIMDs x 2 resident waves
-    long h = groups >= slots ? 1 : slots / groups;
-    return (int)std::min<long>(std::max<long>(1, h), std::max(1, max_h / DLAGP_MAX_PASS_CHUNKS));
 }
 
 // ------------------------------------------------------------------------------------------------
 // launch sequence common to single-sightline and batch evaluation
 // ------------------------------------------------------------------------------------------------
+#define DLAGP_LAUNCH_MFMA(...)                                                                                     \
+    hipLaunchKernelGGL((accumulate_mfma<__VA_ARGS__>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream, table,     \
+                       plan->passes.as<const PassDesc>(), plan->items.as<const WorkItem>(), nb, S, kd, src, part, \
+                       status, (int)g_opt_debug)
+
 template <int LINES, bool BROADEN>
-static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, GroupPlan *gp, int nsplit,
+static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, const LaunchPlan *plan, int nb,
                         long S, int kd, int num_lines, const SampleSource &src, double *part, int *status,
                         bool patch, bool lls) {
     // 16 samples + one spare row that the look-ahead of the sample loop may read
     const size_t prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * kd * (lls ? 6 : (LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
     if constexpr (LINES == 3) {
         if (patch && lls) {  // Lyman-limit systems: single-absorber kernel with the continuum term
-            if (src.cache_mode == 1)
-                hipLaunchKernelGGL((accumulate_mfma<3, BROADEN, false, 1, true, true>), grid, dim3(DLAGP_MFMA_THREADS),
-                                   prep_lds, stream, table, gp->pass_ptrs.as<const PassDesc *>(),
-                                   gp->split_ptrs.as<const int2 *>(), nsplit, S, kd, src, part, status, (int)g_opt_debug);
-            else
-                hipLaunchKernelGGL((accumulate_mfma<3, BROADEN, false, 0, true, true>), grid, dim3(DLAGP_MFMA_THREADS),
-                                   prep_lds, stream, table, gp->pass_ptrs.as<const PassDesc *>(),
-                                   gp->split_ptrs.as<const int2 *>(), nsplit, S, kd, src, part, status, (int)g_opt_debug);
+            if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 1, true, true);
+            else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, true, true);
             return;
         }
         if (patch && !(g_opt_debug & 2)) {  // line cores repaired outside the sample loop (kd == 1, uniform grid)
-            if (src.cache_mode == 1)
-                hipLaunchKernelGGL((accumulate_mfma<3, BROADEN, false, 1, true>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds,
-                                   stream, table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(),
-                                   nsplit, S, kd, src, part, status, (int)g_opt_debug);
-            else
-                hipLaunchKernelGGL((accumulate_mfma<3, BROADEN, false, 0, true>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds,
-                                   stream, table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(),
-                                   nsplit, S, kd, src, part, status, (int)g_opt_debug);
+            if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 1, true);
+            else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, true);
             return;
         }
     }
-    if (src.cache_mode == 1) {  // level 1 of a cached multi-level sweep: also stores the profiles
-        hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, false, 1>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
-                           table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
-                           kd, src, part, status, (int)g_opt_debug);
-    } else if (g_opt_debug & 2) {  // diagnostic instantiation with per-phase cycle stamps
-        hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, true>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
-                           table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
-                           kd, src, part, status, (int)g_opt_debug);
-    } else {
-        hipLaunchKernelGGL((accumulate_mfma<LINES, BROADEN, false>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream,
-                           table, gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, S,
-                           kd, src, part, status, (int)g_opt_debug);
-    }
+    if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(LINES, BROADEN, false, 1);  // level 1 of a cached sweep: also stores the profiles
+    else if (g_opt_debug & 2) DLAGP_LAUNCH_MFMA(LINES, BROADEN, true);     // diagnostic instantiation with per-phase cycle stamps
+    else DLAGP_LAUNCH_MFMA(LINES, BROADEN, false);
 }
 
 // the single-absorber kernel with the cores repaired outside the sample loop (and, with it, the LLS term)
@@ -464,48 +536,56 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
 
     bool use_mfma = mfma_path_serves(g, kd, src.cache_mode == 2);
     if (g_opt_path == 2 && kd >= 1 && !use_mfma)
-        return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (rank > 20, ragged mask, or kd x lines too large)");
-    const int nsplit = use_mfma ? choose_splits(g, S) : 1;
+        return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (rank > 20, mixed line counts / broadening / Lyman-limit flags, or kd x lines too large)");
+    if (!use_mfma && src.cache_mode)
+        return fail(DLAGP_EINVAL, "internal: the profile cache is only served by the MFMA path");
+    int rc;
+    LaunchPlan *plan = nullptr;
+    if (use_mfma && (rc = build_plan(g, S, &plan))) return rc;
+    const int nparts = plan ? plan->max_parts : 1;
 
-    // partial sums: [split][sightline x ceil(S/16) blocks][row_width columns][16 samples]
+    // partial sums: [piece][sightline x ceil(S/16) blocks][row_width columns][16 samples]
     const size_t nblocks = (size_t)nb * ((S + 15) / 16);
-    int rc = ws.part.reserve((size_t)nsplit * nblocks * g.row_width * 16 * sizeof(double));
-    if (rc) return rc;
-    rc = ws.status.reserve(sizeof(int));
-    if (rc) return rc;
-    GroupPlan *gp = nullptr;
-    if (use_mfma) {
-        if ((rc = group_plan(g, nsplit, &gp))) return rc;
-    }
+    const size_t part_bytes = (size_t)nparts * nblocks * g.row_width * 16 * sizeof(double);
+    // kernels enqueued earlier on this stream may still be using the buffer that a larger request replaces
+    if (ws.part.ptr && part_bytes > ws.part.bytes) HIP_TRY(hipStreamSynchronize(stream));
+    if ((rc = ws.part.reserve(part_bytes))) return rc;
+    if ((rc = ws.status.reserve(sizeof(int)))) return rc;
+    g.last_stream = stream;
+    g.launched = true;
 
     EventPair ev{};
     const bool timing = g_opt_timing != 0;
     if (timing) {
         HIP_TRY(hipEventCreate(&ev.start));
-        HIP_TRY(hipEventCreate(&ev.stop));
+        if (hipEventCreate(&ev.stop) != hipSuccess) {
+            (void)hipEventDestroy(ev.start);
+            return fail(DLAGP_EDEVICE, "hipEventCreate failed");
+        }
+        std::lock_guard<std::mutex> lock(g_timing_mutex);
+        g_timing_events.push_back(ev);  // owned by the list from here on: dlagp_timing_read destroys them
         HIP_TRY(hipEventRecord(ev.start, stream));
     }
 
-    if (!use_mfma && src.cache_mode)
-        return fail(DLAGP_EINVAL, "internal: the profile cache is only served by the MFMA path");
+    g_last_launch_path = use_mfma ? 2 : 1;
     if (use_mfma) {
-        const long groups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
-        dim3 grid((unsigned)(groups * nsplit), (unsigned)nb);
+        g_last_launch_items = plan->nitems;
+        g_last_launch_parts = plan->max_parts;
+        dim3 grid((unsigned)plan->nitems);
         const bool lines3 = g.num_lines == 3;
         const bool patch = patch_serves(g, kd);
         const bool lls = g.lls_break;
         double *part = ws.part.as<double>();
+        int *status = ws.status.as<int>();
         if (src.cache_mode == 2) {
-            hipLaunchKernelGGL((accumulate_mfma<3, true, false, 2>), grid, dim3(DLAGP_MFMA_THREADS),
-                               (size_t)DLAGP_MFMA_GROUP * sizeof(double), stream, table,
-                               gp->pass_ptrs.as<const PassDesc *>(), gp->split_ptrs.as<const int2 *>(), nsplit, (long)S,
-                               kd, src, part, ws.status.as<int>(), 0);
+            const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * sizeof(double);
+            DLAGP_LAUNCH_MFMA(3, true, false, 2);
         } else if (g.broadening) {
-            if (lines3) launch_mfma<3, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), patch, lls);
-            else launch_mfma<0, true>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), false, false);
+            if (lines3) launch_mfma<3, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls);
+            else launch_mfma<0, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false);
         } else {
-            if (lines3) launch_mfma<3, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), patch, lls);
-            else launch_mfma<0, false>(grid, stream, table, gp, nsplit, S, kd, g.num_lines, src, part, ws.status.as<int>(), false, false);
+            if (lines3) launch_mfma<3, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls);
+            else launch_mfma<0, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false);
         }
         HIP_TRY(hipGetLastError());
     } else {
@@ -524,21 +604,19 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
         HIP_TRY(hipGetLastError());
     }
 
-    if (timing) {
-        HIP_TRY(hipEventRecord(ev.stop, stream));
-        std::lock_guard<std::mutex> lock(g_timing_mutex);
-        g_timing_events.push_back(ev);
-    }
+    if (timing) HIP_TRY(hipEventRecord(ev.stop, stream));
 
     if (g.k == DLAGP_FIN_K) {
         const size_t lds_bytes = DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double);
         hipLaunchKernelGGL(finalize_rank20, dim3((unsigned)nblocks),
                            dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
-                           ws.part.as<double>(), nsplit, rows, (long)S, table, d_out, ws.status.as<int>());
+                           ws.part.as<double>(), nparts, rows, (long)S, table, d_out, ws.status.as<int>(),
+                           plan ? plan->counts.as<const unsigned char>() : nullptr);
     } else {
         const int threads = DLAGP_FINALIZE_THREADS;
         hipLaunchKernelGGL(finalize_samples<0>, dim3((unsigned)((rows + threads - 1) / threads)), dim3(threads), 0,
-                           stream, ws.part.as<double>(), nsplit, rows, (long)S, table, d_out, ws.status.as<int>());
+                           stream, ws.part.as<double>(), nparts, rows, (long)S, table, d_out, ws.status.as<int>(),
+                           plan ? plan->counts.as<const unsigned char>() : nullptr);
     }
     HIP_TRY(hipGetLastError());
     return DLAGP_OK;
@@ -656,7 +734,7 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     // levels 2..max_dlas into HBM reads -- capacity traded for time on the shared FP64 pipe.
     bool use_cache = g_opt_profile_cache != 0 && max_dlas > 1;
     for (int level = 0; level < max_dlas; ++level) use_cache = use_cache && mfma_path_serves(g, level + 1, level > 0);
-    const size_t cache_bytes = rows * (size_t)g.max_npad * sizeof(double);
+    const size_t cache_bytes = rows * (size_t)g.max_slots * sizeof(double);
     const size_t want_bytes = cache_bytes * (max_dlas > 2 ? 2 : 1);  // profiles + running products
     if (use_cache) {
         const size_t have = ws.cache.bytes + ws.running.bytes;
@@ -668,10 +746,11 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
         if (use_cache && (rc = ws.cache.reserve(cache_bytes))) return rc;
         if (use_cache && max_dlas > 2 && (rc = ws.running.reserve(cache_bytes))) return rc;
     }
+    g_last_sweep_cached = use_cache ? 1 : 0;
     if (use_cache) {
         src.cache = ws.cache.as<double>();
         src.running = ws.running.as<double>();
-        src.cache_stride = g.max_npad;
+        src.cache_stride = g.max_slots;
     }
     for (int level = 0; level < max_dlas; ++level) {
         src.cache_mode = use_cache ? (level == 0 ? 1 : 2) : 0;
@@ -724,7 +803,7 @@ static int finish_group(LaunchGroup &g) {
         table.push_back(ctx->sl);
         g.max_entries = std::max(g.max_entries, ctx->sl.num_entries);
         g.max_npad = std::max(g.max_npad, ctx->sl.n_pad);
-        g.max_chunks = std::max(g.max_chunks, ctx->sl.n_pad / DLAGP_CHUNK_PIXELS);
+        g.max_slots = std::max(g.max_slots, ctx->sl.n_slots);
         g.mfma_ok = g.mfma_ok && ctx->mfma_ok && ctx->sl.num_lines == g.num_lines &&
                     (ctx->sl.ntaps > 1) == g.broadening;
     }
@@ -808,24 +887,37 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
         // 16 sqrt2 sigma / c ln10 = 2.98e-4 dex
         if (uniform && 2.98e-4 / dlog > 3.1) sl.grid_uniform = 0;
     }
-    {
-        std::vector<PassDesc> passes;
-        std::vector<int2> splits;
-        ctx->mfma_ok = k_eff == DLAGP_MFMA_RANK && plan_passes(hpos, sl.n_pad, sl.ntaps, 1, passes, splits);
+    // MFMA path: slot order (zero-weight slots close a chunk at a wide mask gap, so every mask is plannable)
+    std::vector<int> slot_pixel;
+    ctx->mfma_ok = k_eff == DLAGP_MFMA_RANK;
+    if (ctx->mfma_ok) {
+        std::vector<int> real_pos(hpos.begin(), hpos.begin() + n);
+        plan_slots(real_pos, n, sl.ntaps, slot_pixel, ctx->h_slot_pos);
     }
+    sl.n_slots = (int)slot_pixel.size();
+    sl.nsteps_m = sl.n_slots / DLAGP_STEP_PIXELS;
 
     const size_t px = (size_t)sl.n_pad * sizeof(double);
     const size_t p_bytes = (size_t)sl.nsteps * sl.npair * 2 * DLAGP_TILE_DOUBLES * sizeof(double);
+    const size_t pm_bytes = (size_t)sl.nsteps_m * DLAGP_MFMA_PAIRS * 2 * DLAGP_TILE_DOUBLES * sizeof(double);
     rc = ctx->y.reserve(px);
     if (!rc) rc = ctx->mu.reserve(px);
     if (!rc) rc = ctx->omega2.reserve(px);
     if (!rc) rc = ctx->v.reserve(px);
     if (!rc) rc = ctx->pos.reserve((size_t)sl.n_pad * sizeof(int));
     if (!rc) rc = ctx->lam.reserve((size_t)sl.num_entries * sizeof(double));
-    if (!rc) rc = ctx->aux.reserve(px * DLAGP_AUX_FIELDS);
     if (!rc) rc = ctx->dense_M.reserve((size_t)n * k_eff * sizeof(double));
     if (!rc) rc = ctx->P.reserve(p_bytes);
     const hipStream_t setup = setup_stream(device);
+    if (!rc && ctx->mfma_ok) {
+        const size_t sb = (size_t)sl.n_slots * sizeof(int);
+        rc = ctx->aux.reserve((size_t)sl.n_slots * DLAGP_AUX_FIELDS * sizeof(double));
+        if (!rc) rc = ctx->Pm.reserve(pm_bytes);
+        if (!rc) rc = ctx->slot_pixel.reserve(sb);
+        if (!rc) rc = ctx->slot_pos.reserve(sb);
+        if (!rc) rc = upload_now(ctx->slot_pixel.ptr, slot_pixel.data(), sb, setup);
+        if (!rc) rc = upload_now(ctx->slot_pos.ptr, ctx->h_slot_pos.data(), sb, setup);
+    }
     if (!rc) rc = upload_now(ctx->pos.ptr, hpos.data(), (size_t)sl.n_pad * sizeof(int), setup);
     if (!rc) rc = upload_now(ctx->lam.ptr, wavelengths, (size_t)sl.num_entries * sizeof(double), setup);
     if (!rc) rc = fill(ctx);
@@ -840,10 +932,16 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     sl.pos = ctx->pos.as<int>();
     sl.lam = ctx->lam.as<double>();
     sl.P = ctx->P.as<double>();
+    sl.Pm = ctx->Pm.as<double>();
     sl.aux = ctx->aux.as<double>();
 
-    hipLaunchKernelGGL(fill_records, dim3((sl.n_pad + 255) / 256), dim3(256), 0, setup, sl.n_pad, sl.y, sl.mu,
-                       sl.omega2, sl.v, sl.pos, ctx->aux.as<double>());
+    if (ctx->mfma_ok) {
+        hipLaunchKernelGGL(fill_records, dim3((sl.n_slots + 255) / 256), dim3(256), 0, setup, sl.n_slots,
+                           ctx->slot_pixel.as<const int>(), ctx->slot_pos.as<const int>(), sl.y, sl.mu, sl.omega2, sl.v,
+                           ctx->aux.as<double>());
+        hipLaunchKernelGGL(build_mfma_operand, dim3(1024), dim3(256), 0, setup, ctx->dense_M.as<double>(),
+                           ctx->slot_pixel.as<const int>(), sl.n_slots, ctx->Pm.as<double>());
+    }
     hipLaunchKernelGGL(build_shared_operand, dim3(1024), dim3(256), 0, setup, ctx->dense_M.as<double>(), n, sl.n_pad,
                        k_eff, sl.ntw, sl.ntq, sl.npair, ctx->P.as<double>());
     hipError_t err = hipGetLastError();
@@ -1033,6 +1131,7 @@ int dlagp_ctx_read_model(dlagp_ctx *ctx, double *this_mu, double *this_M, double
 void dlagp_destroy(dlagp_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    ctx->self.release();  // first: drains the stream of the last asynchronous launch
     ctx->y.release();
     ctx->mu.release();
     ctx->omega2.release();
@@ -1041,12 +1140,10 @@ void dlagp_destroy(dlagp_ctx *ctx) {
     ctx->lam.release();
     ctx->P.release();
     ctx->aux.release();
+    ctx->Pm.release();
+    ctx->slot_pixel.release();
+    ctx->slot_pos.release();
     ctx->dense_M.release();
-    for (auto &kv : ctx->plans) {
-        kv.second->passes.release();
-        kv.second->splits.release();
-    }
-    ctx->self.release();
     delete ctx;
 }
 
@@ -1162,6 +1259,8 @@ int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
 void dlagp_batch_destroy(dlagp_batch *batch) {
     if (!batch) return;
     (void)hipSetDevice(batch->group.device);
+    // the workspace goes to the next batch, which may launch on another stream
+    if (batch->group.launched) (void)hipStreamSynchronize(batch->group.last_stream);
     // A catalogue run builds one batch after the other: the sweep workspace (partial sums, profile cache --
     // gigabytes) is handed to the next batch of this device instead of being freed and allocated again.
     // One workspace per device is kept; option "pool_mb" = 0 turns this off as well.
@@ -1314,6 +1413,30 @@ int dlagp_set_option(const char *name, int64_t value) {
     }
     else if (!strcmp(name, "profile_cache")) g_opt_profile_cache = value;
     else if (!strcmp(name, "profile_cache_max_mb")) g_opt_profile_cache_max_mb = value;
+    else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
+    return DLAGP_OK;
+}
+
+int dlagp_plan_cut(int64_t groups, double chunks, int64_t forced_splits, int *full, double *frac) {
+    if (!full || !frac || groups < 1 || !(chunks >= 1.0)) return fail(DLAGP_EINVAL, "bad argument");
+    choose_cut((long)groups, chunks, forced_splits, full, frac);
+    return DLAGP_OK;
+}
+
+int dlagp_get_option(const char *name, int64_t *value) {
+    if (!name || !value) return fail(DLAGP_EINVAL, "NULL argument");
+    if (!strcmp(name, "pixel_splits")) *value = g_opt_pixel_splits;
+    else if (!strcmp(name, "path")) *value = g_opt_path;
+    else if (!strcmp(name, "timing")) *value = g_opt_timing;
+    else if (!strcmp(name, "debug")) *value = g_opt_debug;
+    else if (!strcmp(name, "core_patch")) *value = g_opt_core_patch;
+    else if (!strcmp(name, "pool_mb")) *value = g_opt_pool_mb;
+    else if (!strcmp(name, "profile_cache")) *value = g_opt_profile_cache;
+    else if (!strcmp(name, "profile_cache_max_mb")) *value = g_opt_profile_cache_max_mb;
+    else if (!strcmp(name, "last_launch_path")) *value = g_last_launch_path;
+    else if (!strcmp(name, "last_launch_items")) *value = g_last_launch_items;
+    else if (!strcmp(name, "last_launch_parts")) *value = g_last_launch_parts;
+    else if (!strcmp(name, "last_sweep_cached")) *value = g_last_sweep_cached;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 }

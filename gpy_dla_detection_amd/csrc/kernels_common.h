@@ -161,18 +161,87 @@ __global__ void interp_model(ModelDev model, int n, int n_pad, int k_out, const 
                         : 0.0;
 }
 
-// per-pixel records {y, mu, omega2, v, window start, 3 spare} streamed by the MFMA kernel
-__global__ void fill_records(int n_pad, const double *__restrict__ y, const double *__restrict__ mu,
+// ---------------------------------------------------------------------------------------------
+// MFMA operand of one sightline (rank padded to 20), slot-ordered (dlagp_device.h "slot"):
+//   Pm[step][pair j][lane][2],  step = 4 consecutive slots.
+//   pairs 0..6 hold the 14 full tiles t = 2j, 2j+1 for v_mfma_f64_16x16x4_f64 (B operand: lane = slot-in-step * 16 +
+//   column-in-tile):  t < 13: vech(M_i M_i') columns 16t .. 16t+15;  t = 13: M_i columns 0..15.
+//   pair 7 holds the operands of two v_mfma_f64_4x4x4_4b_f64 (profiles/r02_microbench_mfma_f64_4x4.txt: B operand
+//   lane = slot-in-step * 16 + block * 4 + column, one 4x4 product per block of four samples; the same four
+//   columns are replicated over the four blocks):  x: vech columns 208, 209 (+ two zero columns);
+//   y: M_i columns 16..19.
+// 210 + 20 useful columns ride on 14 x 64 + 2 x 16 = 928 MFMA cycles per step instead of 16 x 64 = 1024.
+// Padding slots (slot_pixel < 0) are zero rows.  M_dev is dense row-major [n][20].
+// ---------------------------------------------------------------------------------------------
+#define DLAGP_MFMA_BIG_TILES 14
+#define DLAGP_MFMA_W_TILES 13      // full tiles weighted by w; tile 13 is weighted by q
+#define DLAGP_MFMA_PAIRS 8
+#define DLAGP_MFMA_SMALL_W_COL 208  // first vech column carried by the small w-MFMA
+#define DLAGP_MFMA_SMALL_Q_COL 16   // first column of M carried by the small q-MFMA
+
+__device__ __forceinline__ void vech_invert(int col, int &a, int &b) {
+    a = (int)((sqrt(8.0 * col + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= col) ++a;
+    while (a * (a + 1) / 2 > col) --a;
+    b = col - a * (a + 1) / 2;
+}
+
+__global__ void build_mfma_operand(const double *__restrict__ M_dev, const int *__restrict__ slot_pixel, int n_slots,
+                                   double *__restrict__ Pm) {
+    constexpr int K = 20;
+    const long total = (long)n_slots * DLAGP_MFMA_PAIRS * 16 * 2;  // (slot, pair, lane-in-slot 0..15, half)
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int half = idx & 1;
+        const int cc = (idx >> 1) & 15;
+        const int pair = (idx >> 5) % DLAGP_MFMA_PAIRS;
+        const int slot = idx / (32 * DLAGP_MFMA_PAIRS);
+        const int i = slot_pixel[slot];
+        double val = 0.0;
+        if (i >= 0) {
+            const double *row = M_dev + (long)i * K;
+            if (pair < DLAGP_MFMA_PAIRS - 1) {
+                const int tile = 2 * pair + half;
+                if (tile < DLAGP_MFMA_W_TILES) {
+                    int a, b;
+                    vech_invert(tile * 16 + cc, a, b);
+                    val = row[a] * row[b];
+                } else {
+                    val = row[cc];
+                }
+            } else {
+                const int j = cc & 3;  // replicated over the four blocks cc >> 2
+                if (half == 0) {
+                    const int col = DLAGP_MFMA_SMALL_W_COL + j;
+                    if (col < K * (K + 1) / 2) {
+                        int a, b;
+                        vech_invert(col, a, b);
+                        val = row[a] * row[b];
+                    }
+                } else {
+                    val = row[DLAGP_MFMA_SMALL_Q_COL + j];
+                }
+            }
+        }
+        const int step = slot / DLAGP_STEP_PIXELS, s_in = slot % DLAGP_STEP_PIXELS;
+        Pm[(((long)step * DLAGP_MFMA_PAIRS + pair) * 64 + s_in * 16 + cc) * 2 + half] = val;
+    }
+}
+
+// per-slot records {y, mu, omega2, v, window start, 3 spare} streamed by the MFMA kernel; padding slots
+// (slot_pixel < 0) carry y = mu = omega2 = 0, v = 1: d = 1, log d = 0, r = 0, zero operand rows
+__global__ void fill_records(int n_slots, const int *__restrict__ slot_pixel, const int *__restrict__ slot_pos,
+                             const double *__restrict__ y, const double *__restrict__ mu,
                              const double *__restrict__ omega2, const double *__restrict__ v,
-                             const int *__restrict__ pos, double *__restrict__ aux) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pad) return;
-    double *rec = aux + (long)i * 8;
-    rec[0] = y[i];
-    rec[1] = mu[i];
-    rec[2] = omega2[i];
-    rec[3] = v[i];
-    rec[4] = (double)pos[i];
+                             double *__restrict__ aux) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    const int i = slot_pixel[s];
+    double *rec = aux + (long)s * 8;
+    rec[0] = i >= 0 ? y[i] : 0.0;
+    rec[1] = i >= 0 ? mu[i] : 0.0;
+    rec[2] = i >= 0 ? omega2[i] : 0.0;
+    rec[3] = i >= 0 ? v[i] : 1.0;
+    rec[4] = (double)slot_pos[s];
     rec[5] = rec[6] = rec[7] = 0.0;
 }
 
@@ -192,7 +261,8 @@ __global__ void fill_records(int n_pad, const double *__restrict__ y, const doub
 template <int KT>
 __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const double *__restrict__ part, int nsplit, long rows, long S,
                                  const SightlineDev *__restrict__ sightlines,
-                                 double *__restrict__ out, int *__restrict__ status) {
+                                 double *__restrict__ out, int *__restrict__ status,
+                                 const unsigned char *__restrict__ part_counts) {
     const long row = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (row >= rows) return;
     const long b = row / S, smp = row % S;
@@ -205,6 +275,7 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
     const long nblocks = (rows / S) * ngroups;
     const long block = b * ngroups + smp / 16;
     const int lane16 = (int)(smp % 16);
+    if (part_counts) nsplit = part_counts[block];  // pieces this block of 16 samples was cut into
     auto partial = [&](int h, int col) { return part[partial_index(h, nblocks, block, rw, col, lane16)]; };
 
     constexpr int KMAX = KT > 0 ? KT : DLAGP_MAX_RANK;
@@ -293,7 +364,8 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
 
 __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const double *__restrict__ part, int nsplit, long rows, long S,
                                                       const SightlineDev *__restrict__ sightlines,
-                                                      double *__restrict__ out, int *__restrict__ status) {
+                                                      double *__restrict__ out, int *__restrict__ status,
+                                                      const unsigned char *__restrict__ part_counts) {
     extern __shared__ double fin_lds[];
     constexpr int K = DLAGP_FIN_K;
     constexpr int NC = DLAGP_FIN_COLS;
@@ -302,6 +374,7 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     const long ngroups = (S + NS - 1) / NS;
     const long nblocks = (rows / S) * ngroups;
     const long block = blockIdx.x;
+    if (part_counts) nsplit = part_counts[block];  // pieces this block's pixels were cut into (work items, dlagp_hip.hip)
     const long b = block / ngroups, g = block % ngroups;
     const long row0 = b * S + g * NS;          // first output row of this workgroup
     const int valid = (int)((S - g * NS) < NS ? (S - g * NS) : NS);
@@ -347,6 +420,7 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     else if (nsplit == 2) stage(std::integral_constant<int, 2>{});
     else if (nsplit == 3) stage(std::integral_constant<int, 3>{});
     else if (nsplit == 4) stage(std::integral_constant<int, 4>{});
+    else if (nsplit == 5) stage(std::integral_constant<int, 5>{});
     else
         for (int idx = tid; idx < DLAGP_FIN_STAGED * NS; idx += DLAGP_FIN_THREADS) {
             const int c = idx / NS, smp = idx % NS;

@@ -40,8 +40,8 @@ namespace dlagp {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define DLAGP_MFMA_RANK 20
-#define DLAGP_MFMA_NTW 14
-#define DLAGP_MFMA_NT 16
+#define DLAGP_MFMA_NTW DLAGP_MFMA_W_TILES    // 13 full tiles weighted by w
+#define DLAGP_MFMA_NT DLAGP_MFMA_BIG_TILES   // 14 full tiles; two 4x4x4 MFMAs carry the remaining 2 + 4 columns
 #define DLAGP_MFMA_GROUP 16      // samples per wave / workgroup
 #define DLAGP_MFMA_THREADS 64
 #define DLAGP_PASS_ENTRIES 64
@@ -54,9 +54,15 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct PassDesc {
     int entry_start;  // first entry computed by phase 1
-    int chunk_begin;  // first chunk (8 kept pixels) consumed by phase 2
+    int chunk_begin;  // first chunk (8 slots) consumed by phase 2
     int nchunks;      // 1..7
     int pad;
+};
+
+// One wave's work: 16 samples (`group`) of sightline `b` over the passes [pass_begin, pass_end) of the launch
+// plan's pass list; its sums go to partial slot `part` of the block (dlagp_hip.hip: build_plan).
+struct WorkItem {
+    int b, group, part, pass_begin, pass_end, pad0, pad1, pad2;
 };
 
 // Per-(sample, absorber) constants, computed by each wave for its 16 samples into LDS:
@@ -209,8 +215,7 @@ __device__ __forceinline__ void lds_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// grid: (ngroups * nsplit, nb); block: one wave.
-//   block L -> split = L % nsplit, sample group (16 samples) = L / nsplit.
+// grid: one wave (= workgroup) per work item of the launch plan.
 // BROADEN: 7-tap instrument convolution (true) or the raw profile itself (false).
 // Any number of absorbers kd >= 1: each absorber's profile is convolved and multiplied into the LDS
 // buffer a[sample][pixel of the pass] before the MFMA loop (dla_gp.py:370-388).
@@ -239,8 +244,8 @@ __device__ __forceinline__ void lds_wave_sync() {
 // `rest_wavelengths > lambda_Lyman_limit` (:280) exactly without a division per entry.
 template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, bool PATCH = false, bool LLS = false>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
-    const SightlineDev *__restrict__ sightlines, const PassDesc *const *__restrict__ pass_tables,
-    const int2 *const *__restrict__ split_tables, int nsplit, long S, int kd,
+    const SightlineDev *__restrict__ sightlines, const PassDesc *__restrict__ passes,
+    const WorkItem *__restrict__ items, int nb, long S, int kd,
     SampleSource src, double *__restrict__ part, int *__restrict__ status, int debug_flags) {
     constexpr bool CACHED = MODE == 2;
     constexpr int A_STRIDE = 4 * DLAGP_MAX_PASS_STEPS + 2;  // 58: stride/2 odd -> conflict-free b64 reads
@@ -258,17 +263,18 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     static_assert(!LLS || PATCH, "the Lyman-limit term is implemented in the single-absorber kernel");
     typedef double v4d_a16 __attribute__((ext_vector_type(4), aligned(16)));
 
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = 0;  // finalize raises it
+    if (blockIdx.x == 0 && threadIdx.x == 0) *status = 0;  // finalize raises it
     // Wave priorities.  The two waves of a SIMD share the FP64 pipe; an MFMA holds it for 64 cycles, a vector
     // instruction for 4, so with equal priorities the wave that is in its MFMA loop starves the one that is in a
     // vector phase, which then reaches its own MFMA loop late and leaves latencies uncovered.  Measured best
     // (A/B on one device, -5 % kernel time against equal priorities): Voigt loop 2, the latency-bound parts
     // (pass set-up, convolution) 1, the dependent weight arithmetic at the head of each step 3, MFMAs 0.
     __builtin_amdgcn_s_setprio(2);
-    const int b = blockIdx.y;
+    const WorkItem &item = items[blockIdx.x];
+    const int b = __builtin_amdgcn_readfirstlane(item.b);
     const SightlineDev &sl = sightlines[b];
-    const int split = blockIdx.x % nsplit;
-    const long group = blockIdx.x / nsplit;
+    const int split = __builtin_amdgcn_readfirstlane(item.part);
+    const long group = __builtin_amdgcn_readfirstlane(item.group);
     const int lane = threadIdx.x;
     const int s_loc = lane & 15;
     const int slot = lane >> 4;
@@ -279,9 +285,9 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     // P and the per-pixel records are streamed with buffer loads: scalar resource + per-lane byte
     // offset + scalar step offset + immediate, i.e. no vector address arithmetic in the loops
     const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)as_global<gptr_d>(sl.P), 0, sl.nsteps * (DLAGP_MFMA_NT * DLAGP_TILE_DOUBLES * 8), DLAGP_BUFFER_FLAGS);
+        (void *)as_global<gptr_d>(sl.Pm), 0, sl.nsteps_m * (2 * DLAGP_MFMA_PAIRS * DLAGP_TILE_DOUBLES * 8), DLAGP_BUFFER_FLAGS);
     const __amdgpu_buffer_rsrc_t aux_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)as_global<gptr_d>(sl.aux), 0, sl.n_pad * (DLAGP_AUX_FIELDS * 8), DLAGP_BUFFER_FLAGS);
+        (void *)as_global<gptr_d>(sl.aux), 0, sl.n_slots * (DLAGP_AUX_FIELDS * 8), DLAGP_BUFFER_FLAGS);
     const int p_voff = lane * 16;                         // one double2 per lane and tile pair
     const int rec_voff = slot * (DLAGP_AUX_FIELDS * 8);   // this lane's pixel within a step
     double tap[4];  // symmetric profile: taps 0..3 (tap[t] == tap[6 - t], checked in dlagp_create)
@@ -338,10 +344,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         prep_lds[i] = value;
     }
 
-    const PassDesc *passes = pass_tables[b];
-    const int2 span_v = split_tables[b][split];  // passes [x, y)
-    const int pass_begin = __builtin_amdgcn_readfirstlane(span_v.x);
-    const int pass_end = __builtin_amdgcn_readfirstlane(span_v.y);
+    const int pass_begin = __builtin_amdgcn_readfirstlane(item.pass_begin);
+    const int pass_end = __builtin_amdgcn_readfirstlane(item.pass_end);
 
     // ---------------- core patch factors of this wave (PATCH) ----------------
     int npatch = 0;  // active (sample, line) pairs, wave-uniform
@@ -408,6 +412,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     d4 acc[DLAGP_MFMA_NT];
 #pragma unroll
     for (int t = 0; t < DLAGP_MFMA_NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+    double acc_sw = 0.0, acc_sq = 0.0;  // the two 4x4x4 MFMAs: vech columns 208.. and M columns 16..
     double sum_r2 = 0.0;
     LogProduct dprod;
 
@@ -420,8 +425,9 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     // B operand: 8 x double2 per lane and step (tile pair j -> tiles 2j, 2j+1); per-pixel record
     // {y, mu | omega2, v}.  Inside a pass both are reloaded one step ahead of use; the first step
     // of a pass is loaded after the convolution so that the registers are free during phase 1.
-    constexpr int NPAIR = DLAGP_MFMA_NT / 2;
-    constexpr int STEP_BYTES = DLAGP_MFMA_NT * DLAGP_TILE_DOUBLES * 8;        // 8192
+    constexpr int NPAIR = DLAGP_MFMA_PAIRS;
+    constexpr int NBIGPAIR = DLAGP_MFMA_NT / 2;
+    constexpr int STEP_BYTES = 2 * DLAGP_MFMA_PAIRS * DLAGP_TILE_DOUBLES * 8;  // 8192
     constexpr int REC_STEP_BYTES = DLAGP_STEP_PIXELS * DLAGP_AUX_FIELDS * 8;  // 256
     v2d frag[NPAIR];
     v2d rec_ym, rec_ov;
@@ -664,9 +670,15 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
 #pragma unroll
             for (int j = 0; j < NPAIR; ++j) {
                 const v2d f = frag[j];
-                acc[2 * j] = __builtin_amdgcn_mfma_f64_16x16x4f64(2 * j < DLAGP_MFMA_NTW ? w : q, f.x, acc[2 * j], 0, 0, 0);
-                acc[2 * j + 1] =
-                    __builtin_amdgcn_mfma_f64_16x16x4f64(2 * j + 1 < DLAGP_MFMA_NTW ? w : q, f.y, acc[2 * j + 1], 0, 0, 0);
+                if (j < NBIGPAIR) {
+                    acc[2 * j] = __builtin_amdgcn_mfma_f64_16x16x4f64(2 * j < DLAGP_MFMA_NTW ? w : q, f.x, acc[2 * j], 0, 0, 0);
+                    acc[2 * j + 1] =
+                        __builtin_amdgcn_mfma_f64_16x16x4f64(2 * j + 1 < DLAGP_MFMA_NTW ? w : q, f.y, acc[2 * j + 1], 0, 0, 0);
+                } else {
+                    // A operand lane = pixel * 16 + sample is also the 4-block form's (sample = block * 4 + row)
+                    acc_sw = __builtin_amdgcn_mfma_f64_4x4x4f64(w, f.x, acc_sw, 0, 0, 0);
+                    acc_sq = __builtin_amdgcn_mfma_f64_4x4x4f64(q, f.y, acc_sq, 0, 0, 0);
+                }
                 // rolling prefetch: this register pair is next used one full step later
                 frag[j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(
                                                       p_rsrc, p_voff + (j & 3) * 1024, soff + (j >> 2) * 4096, 0));
@@ -692,23 +704,34 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const int rw = sl.row_width;
     const long rows_left = S - sample0;  // valid samples of this wave
     const long ngroups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
-    const long nblocks = gridDim.y * ngroups;
+    const long nblocks = (long)nb * ngroups;
     // this wave's block of the partial sums: [column][16 samples], contiguous
     __attribute__((address_space(1))) double *base =
         (__attribute__((address_space(1))) double *)(part) + partial_index(split, nblocks, b * ngroups + group, rw, 0, 0);
     constexpr int TR_STRIDE = 17;  // [16 columns][16 samples + 1]
+    // row layout of the finalize kernels (kernels_common.h): vech columns 0..223, then u at 224..
+    constexpr int QBASE = 14 * DLAGP_TILE_COLS;
 #pragma unroll
     for (int t = 0; t < DLAGP_MFMA_NT; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) raw[s_loc * TR_STRIDE + slot + 4 * r] = acc[t][r];
         lds_wave_sync();
+        const int col0 = t < DLAGP_MFMA_NTW ? t * DLAGP_TILE_COLS : QBASE;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
             const int col = cc * 4 + slot;  // lane -> (sample = s_loc, column = col)
             const double val = raw[col * TR_STRIDE + s_loc];
-            if (s_loc < rows_left) base[(t * DLAGP_TILE_COLS + col) * 16 + s_loc] = val;  // 512 contiguous bytes
+            if (s_loc < rows_left) base[(col0 + col) * 16 + s_loc] = val;  // 512 contiguous bytes
         }
         lds_wave_sync();
+    }
+    {
+        // 4x4x4 outputs: lane = row * 16 + block * 4 + column  ->  sample = block * 4 + row
+        const int smp = ((lane >> 2) & 3) * 4 + (lane >> 4), j = lane & 3;
+        if (smp < rows_left) {
+            if (j < 2) base[(DLAGP_MFMA_SMALL_W_COL + j) * 16 + smp] = acc_sw;
+            base[(QBASE + DLAGP_MFMA_SMALL_Q_COL + j) * 16 + smp] = acc_sq;
+        }
     }
     double logd = dprod.log_value();
     sum_r2 += __shfl_xor(sum_r2, 16);
@@ -716,9 +739,10 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     logd += __shfl_xor(logd, 16);
     logd += __shfl_xor(logd, 32);
     if (slot == 0 && s_loc < rows_left) {
-        base[(DLAGP_MFMA_NT * DLAGP_TILE_COLS) * 16 + s_loc] = sum_r2;
-        base[(DLAGP_MFMA_NT * DLAGP_TILE_COLS + 1) * 16 + s_loc] = logd;
-        base[(DLAGP_MFMA_NT * DLAGP_TILE_COLS + 2) * 16 + s_loc] = split == 0 ? sl.n * DLAGP_LOG_2PI : 0.0;
+        constexpr int SBASE = 16 * DLAGP_TILE_COLS;  // (ntw + ntq) * 16 of the rank-20 row layout
+        base[SBASE * 16 + s_loc] = sum_r2;
+        base[(SBASE + 1) * 16 + s_loc] = logd;
+        base[(SBASE + 2) * 16 + s_loc] = split == 0 ? sl.n * DLAGP_LOG_2PI : 0.0;
     }
     if (stamps && lane == 0) {
         const unsigned long long now = stamp_now();

@@ -314,6 +314,14 @@ def set_option(name: str, value: int) -> None:
     _lib.check(_lib.load().dlagp_set_option(name.encode(), int(value)))
 
 
+def get_option(name: str) -> int:
+    """current value of an option, or of a read-only diagnostic of the last launch ("last_launch_path": 1 generic /
+    2 MFMA kernel, "last_launch_items", "last_launch_parts", "last_sweep_cached")"""
+    value = ctypes.c_int64()
+    _lib.check(_lib.load().dlagp_get_option(name.encode(), ctypes.byref(value)))
+    return int(value.value)
+
+
 def timing_read(reset: bool = True):
     """(total accumulate-kernel milliseconds, launches) recorded while option 'timing' was on"""
     total = ctypes.c_double()

@@ -157,6 +157,11 @@ int dlagp_absorption(dlagp_ctx *ctx, int kd, const double *z, const double *nhi,
  * Device-resident sweep: d_z, d_nhi ([S][kd]) and d_out ([S]) are HBM pointers on the context's
  * device; the work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream)
  * and NOT synchronised.  Failures of the finalisation (non-PD B) surface as NaN in d_out.
+ * Stream rules of every *_device entry point: a context / batch may have launches in flight on ONE
+ * stream at a time (its scratch buffers are shared by its launches; successive launches on the same
+ * stream are ordered, a call that needs larger scratch drains that stream first); dlagp_destroy /
+ * dlagp_batch_destroy drain the stream of the last launch before they recycle device memory.  To move
+ * a context to another stream, synchronise the old one first.
  */
 int dlagp_eval_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, const double *d_nhi,
                       double *d_out, void *stream);
@@ -216,7 +221,8 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
 
 /*
  * Tuning / measurement hooks.
- *   dlagp_set_option: "pixel_splits" (0 = automatic), "path" (0 = automatic, 1 = generic
+ *   dlagp_set_option: "pixel_splits" (0 = automatic work decomposition, h > 0 = every block of 16 samples
+ *                     is cut into h equal pixel ranges), "path" (0 = automatic, 1 = generic
  *                     kernel, 2 = MFMA kernel), "timing" (1 = bracket the accumulate kernel
  *                     of every launch with HIP events on its stream), "debug" (bit 1: launch the
  *                     stamped instantiation of the MFMA kernel, see dlagp_debug_read),
@@ -234,6 +240,15 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
  *                     reset; synchronises the recorded events.
  */
 int dlagp_set_option(const char *name, int64_t value);
+/* Reads an option back, or one of the read-only diagnostics of the most recent launch on this process:
+ * "last_launch_path" (1 = generic kernel, 2 = MFMA kernel), "last_launch_items" (waves of the last MFMA
+ * launch), "last_launch_parts" (most pieces a block of 16 samples was cut into), "last_sweep_cached"
+ * (1 = the last dlagp_batch_sweep* used the profile cache). */
+int dlagp_get_option(const char *name, int64_t *value);
+/* The work decomposition the MFMA path would choose for `groups` blocks of 16 samples of sightlines with `chunks`
+ * chunks of 8 pixel slots each (pure host arithmetic, no device needed): every block is cut into `full` pieces of
+ * `frac` of its chunks each, plus one remainder piece when full * frac < 1.  forced_splits as option "pixel_splits". */
+int dlagp_plan_cut(int64_t groups, double chunks, int64_t forced_splits, int *full, double *frac);
 int dlagp_timing_read(double *total_ms, int64_t *launches, int reset);
 /* Diagnostic build aid: with option "debug" bit 1 set the MFMA kernel sums shader-clock stamps per
  * phase over all waves (current device): [0] Voigt loop, [1] convolution, [2] weights + MFMA loop,

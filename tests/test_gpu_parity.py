@@ -299,9 +299,12 @@ def test_full_size_properties():
     z, log_nhi, nhi = make_qmc_samples(sight, S)
     ll = dev.eval(z, nhi)
     assert ll.shape == (S,) and np.all(np.isfinite(ll))
-    # (1) order independence: a permuted sweep returns the permuted results bit for bit
+    # (1) determinism: the same sweep twice is identical bit for bit (pieces are added in a fixed order);
+    # order independence: a permuted sweep returns the permuted results to rounding (a sample's pixel range is
+    # cut where its block of 16 samples is cut, so the summation order depends on the block it lands in)
+    np.testing.assert_array_equal(dev.eval(z, nhi), ll)
     perm = np.random.default_rng(0).permutation(S)
-    np.testing.assert_array_equal(dev.eval(z[perm], nhi[perm]), ll[perm])
+    np.testing.assert_allclose(dev.eval(z[perm], nhi[perm]), ll[perm], rtol=1e-13)
     # (2) the best sample sits on the injected absorber
     best = int(np.argmax(ll))
     assert abs(z[best] - sight.injected_z[0]) < 0.02 and abs(log_nhi[best] - sight.injected_log_nhi[0]) < 0.4
@@ -418,30 +421,73 @@ def test_sharded_driver_on_device_matches_oracle_driver():
     assert np.array_equal(np.argmax(got, axis=1), np.argmax(want, axis=1))  # identical model selection
 
 
-def test_ragged_mask_falls_back_to_generic_path(restore_options):
-    """a masked run longer than one 64-entry pass makes the sightline ineligible for the MFMA kernel"""
-    from oracle import ref_like as R
-
-    set_option = restore_options
-    sight = make_sightline(4, n_unmasked=600, n_masked=0)
+def gapped_sightline(index=4, n_unmasked=600, gaps=((203, 333),), comb=(400, 420, 2), k=20):
+    """a synthetic sightline whose mask has long masked runs (> one 64-entry pass) and a comb of single pixels,
+    the shapes real SDSS masks have (reference read_spec.py:38-71: runs of ivar == 0; null_gp.py:139-152)"""
+    sight = make_sightline(index, n_unmasked=n_unmasked, n_masked=0, k=k)
     keep = sight.keep.copy()
-    keep[203:333] = False          # 130 consecutive masked pixels, straddled by an 8-pixel chunk
-    keep[400:420:2] = False        # and a comb
-    idx = np.cumsum(sight.keep) - 1  # all kept originally: index map is the identity
-    sel = keep[sight.keep]
+    for lo, hi in gaps:
+        keep[lo:hi] = False
+    if comb:
+        keep[comb[0]:comb[1]:comb[2]] = False
+    sel = keep[sight.keep]  # all kept originally: the index map is the identity
     sight.keep = keep
     sight.y, sight.v = sight.y[sel], sight.v[sel]
     sight.this_mu, sight.this_M, sight.this_omega2 = sight.this_mu[sel], sight.this_M[sel], sight.this_omega2[sel]
-    dev = device_sightline(sight)
-    z, _, nhi = make_qmc_samples(sight, 40)
-    got = dev.eval(z, nhi)  # automatic path selection
-    st = oracle_state(sight)
-    want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in range(40)])
-    np.testing.assert_allclose(got, want, rtol=RTOL_LL)
-    set_option("path", 2)
-    with pytest.raises(ValueError):
-        dev.eval(z, nhi)           # the MFMA kernel cannot plan this mask
-    del idx
+    return sight
+
+
+def test_ragged_mask_runs_on_the_mfma_path(restore_options):
+    """masked runs longer than one 64-entry pass are planned with zero-weight slots: MFMA kernel, oracle parity"""
+    from oracle import ref_like as R
+
+    set_option = restore_options
+    for gaps in (((203, 333),), ((10, 75), (76, 140), (300, 520)), ((0, 64), (500, 597))):
+        sight = gapped_sightline(gaps=gaps)
+        dev = device_sightline(sight)
+        z, _, nhi = make_qmc_samples(sight, 40)
+        st = oracle_state(sight)
+        want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in range(40)])
+        set_option("path", 2)  # must not raise: every mask is plannable
+        for splits in (0, 1, 3):
+            set_option("pixel_splits", splits)
+            np.testing.assert_allclose(dev.eval(z, nhi), want, rtol=RTOL_LL)
+        set_option("pixel_splits", 0)
+        z2, n2 = np.stack([z, z[::-1]], axis=1), np.stack([nhi, nhi[::-1]], axis=1)
+        want2 = np.array([R.sample_log_likelihood_k_dlas(st, z2[i], n2[i]) for i in range(0, 40, 5)])
+        np.testing.assert_allclose(dev.eval(z2, n2)[::5], want2, rtol=RTOL_LL)
+        set_option("path", 0)
+        assert abs(dev.null() - R.null_log_model_evidence(st)) <= RTOL_LL * abs(R.null_log_model_evidence(st))
+
+
+def test_one_gapped_sightline_does_not_slow_the_batch_down(restore_options):
+    """one gapped + 15 clean sightlines in one DeviceBatch.sweep: MFMA kernel and profile cache stay on"""
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch, get_option
+
+    set_option = restore_options
+    sights = [make_sightline(i, n_unmasked=420 + 8 * i, n_masked=5) for i in range(15)]
+    sights.insert(7, gapped_sightline(index=21, n_unmasked=500, gaps=((100, 230), (301, 369))))
+    devs = [device_sightline(s) for s in sights]
+    batch = DeviceBatch(devs)
+    S, max_dlas = 320, 3
+    z = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    set_option("path", 2)  # the generic kernel is not allowed to serve any launch of this sweep
+    ev, ll, base = parallel.sweep_batch_device(batch, z, nhi, max_dlas, 0.01)
+    assert get_option("last_sweep_cached") == 1
+    set_option("path", 0)
+    want_ev, want_ll, want_base = parallel.sweep_batch(batch.eval, z, nhi, max_dlas, 0.01)
+    np.testing.assert_allclose(ev, want_ev, rtol=1e-11)
+    np.testing.assert_allclose(ll, want_ll, rtol=1e-11, equal_nan=True)
+    assert np.array_equal(base, want_base)
+    # and the gapped member against the oracle
+    from oracle import ref_like as R
+
+    st = oracle_state(sights[7])
+    pick = np.arange(3, S, 37)
+    want = np.array([R.sample_log_likelihood_k_dlas(st, [z[7, i]], [nhi[i]]) for i in pick]) - np.log(S)
+    np.testing.assert_allclose(ll[7, pick, 0], want, rtol=RTOL_LL)
 
 
 def test_config3_batch_of_sightlines_full_size():
