@@ -127,6 +127,7 @@ def main() -> None:
     ap.add_argument("--samples", type=int, default=NUM_SAMPLES, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--splits", type=int, default=0, help=argparse.SUPPRESS)  # tuning: force the pixel-split count
+    ap.add_argument("--option", action="append", default=[], help=argparse.SUPPRESS)  # tuning: library option name=value
     ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)  # 2: per-phase cycle stamps (diagnostic)
     # rehearsal of the N > 1 code path on a one-GPU box: every rank on device 0, gloo instead of RCCL
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help=argparse.SUPPRESS)
@@ -171,6 +172,9 @@ def main() -> None:
         sl.set_option("pixel_splits", args.splits)
     if args.debug:
         sl.set_option("debug", args.debug)
+    for item in args.option:
+        name, value = item.split("=")
+        sl.set_option(name, int(value))
     z = torch.from_numpy(z_host).to(device)
     nhi = torch.from_numpy(nhi_host).to(device)
     out = torch.empty(S, dtype=torch.float64, device=device)

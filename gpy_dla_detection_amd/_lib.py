@@ -6,6 +6,7 @@ library is missing or no GPU is usable, the first evaluation raises.
 """
 import ctypes
 import os
+import sys
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_ssize_t, c_ubyte, c_void_p
 
 import numpy as np
@@ -49,11 +50,18 @@ SIGNATURES = {
                                   POINTER(ctypes.c_int32)]),
     "dlagp_batch_sweep_device": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_double, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dlagp_batch_level_eval_device": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
+                                              c_void_p, c_int, c_void_p, c_void_p]),
+    "dlagp_sweep_state_init_device": (c_int, [c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                              c_void_p]),
+    "dlagp_level_finish_device": (c_int, [c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_double, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dlagp_level_evidence_device": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "dlagp_set_option": (c_int, [c_char_p, c_int64]),
     "dlagp_plan_cut": (c_int, [c_int64, c_double, c_int64, POINTER(c_int), _dp]),
     "dlagp_get_option": (c_int, [c_char_p, POINTER(c_int64)]),
     "dlagp_timing_read": (c_int, [_dp, POINTER(c_int64), c_int]),
+    "dlagp_debug_voigt": (c_int, [c_int, c_int, c_int64, _dp, _dp, c_int]),
     "dlagp_debug_read": (c_int, [POINTER(ctypes.c_uint64), c_int, c_int]),
 }
 
@@ -69,6 +77,15 @@ def load():
                 "libdlagp_hip.so not found at {} -- build it with `make -C gpy_dla_detection_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback".format(LIB_PATH)
             )
+        # Two HIP runtimes can live in one process (torch bundles its own); the second one to initialise does not
+        # see the GPU.  RCCL runs inside torch's, so when torch is already imported its runtime goes first.
+        torch = sys.modules.get("torch")
+        if torch is not None and hasattr(torch, "cuda"):
+            try:
+                if torch.cuda.is_available() and not torch.cuda.is_initialized():
+                    torch.cuda.init()
+            except Exception:  # a CPU-only torch build, or no device: nothing to order
+                pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -80,16 +80,23 @@ struct SampleSource {
     long cache_stride;
     int cache_mode;    // 0 off, 1 store level-1 profiles, 2 multiply cached rows
     int cache_write;   // mode 2: write the running product back (not needed at the last level)
+    // Indexed mode on a slice of the samples (one rank's share when ONE sightline's samples are split over several
+    // GPUs): the launch evaluates samples [sample_offset, sample_offset + S) of tables that hold table_S samples
+    // per sightline.  table_S == 0: the launch covers the whole table (offset 0, table_S = S).
+    long sample_offset;
+    long table_S;
 };
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ long sample_point(const SampleSource &src, long b, long s, int j, long S, int kd) {
     if (!src.indexed) return (b * S + s) * kd + j;
-    return j == 0 ? s : (long)src.base[(b * src.base_levels + (j - 1)) * S + s];
+    const long T = src.table_S ? src.table_S : S;
+    const long g = s + src.sample_offset;
+    return j == 0 ? g : (long)src.base[(b * src.base_levels + (j - 1)) * T + g];
 }
 __device__ __forceinline__ double sample_z(const SampleSource &src, long b, long s, int j, long S, int kd) {
     const long p = sample_point(src, b, s, j, S, kd);
-    return src.indexed ? src.z[b * S + p] : src.z[p];
+    return src.indexed ? src.z[b * (src.table_S ? src.table_S : S) + p] : src.z[p];
 }
 __device__ __forceinline__ double sample_nhi(const SampleSource &src, long b, long s, int j, long S, int kd) {
     const long p = sample_point(src, b, s, j, S, kd);

@@ -60,6 +60,8 @@ static int64_t g_opt_core_patch = 1;     // MFMA kernel: line cores repaired out
 static int64_t g_opt_profile_cache = 1;  // multi-level sweeps keep level-1 profiles in HBM (0 = recompute)
 // never more than this for the cache (MB), and never more than half of the free HBM
 static int64_t g_opt_profile_cache_max_mb = 196608;
+static int64_t g_opt_plan_item_cost = 50;   // fixed cost of a work item in the planner's model, tenths of a chunk
+static int64_t g_opt_plan_rest_first = 0;   // dispatch the remainder pieces before the full ones (tuning)
 // read-only diagnostics of the most recent launch / sweep (dlagp_get_option): which kernel served it
 static int64_t g_last_launch_path = 0;    // 1 generic kernel, 2 MFMA kernel
 static int64_t g_last_launch_items = 0;   // work items (waves) of the last MFMA launch
@@ -376,7 +378,7 @@ static void plan_passes(const std::vector<int> &slot_pos, int ntaps, int c0, int
 // the cut, as fractions of a sightline's chunks: `full` pieces of `frac` each, then a remainder if frac * full < 1
 static void choose_cut(long groups, double C, int64_t forced, int *full_out, double *frac_out) {
     const long slots = 2048;
-    const double o = 5.0;  // prologue + epilogue of an item ~ 5 chunks of work
+    const double o = 0.1 * (double)g_opt_plan_item_cost;  // prologue + epilogue of an item ~ 5 chunks of work
     int full = 1;
     double frac = 1.0, best = 1e300;
     const int h_max = (int)std::max(1.0, std::min(8.0, std::floor(C / DLAGP_MAX_PASS_CHUNKS)));
@@ -404,7 +406,7 @@ static void choose_cut(long groups, double C, int64_t forced, int *full_out, dou
 }
 
 static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
-    const std::pair<int64_t, int64_t> key(S, g_opt_pixel_splits);
+    const std::pair<int64_t, int64_t> key(S, g_opt_pixel_splits + 1000 * g_opt_plan_item_cost + 1000000 * g_opt_plan_rest_first);
     auto it = g.plans.find(key);
     if (it != g.plans.end()) {
         *out = it->second.get();
@@ -450,7 +452,8 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
         }
     }
     // dispatch order: the full pieces in (sightline, group, piece) order, then the remainders
-    if (remainder) std::stable_partition(pieces.begin(), pieces.end(), [](const Piece &x) { return !x.rest; });
+    const bool rest_first = g_opt_plan_rest_first != 0;
+    if (remainder) std::stable_partition(pieces.begin(), pieces.end(), [=](const Piece &x) { return x.rest == rest_first; });
     std::vector<PassDesc> passes;
     std::map<std::tuple<int, int, int>, std::pair<int, int>> ranges;  // (b, c0, c1) -> pass range
     std::vector<WorkItem> items;
@@ -694,7 +697,7 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
     }
     tr.download(out, ws.out.ptr, (size_t)rows * sizeof(double));
     if ((rc = tr.reserve()) || (rc = tr.run_uploads())) return rc;
-    rc = launch_sweep(g, S, kd, SampleSource{ws.z.as<double>(), ws.nhi.as<double>(), nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0},
+    rc = launch_sweep(g, S, kd, SampleSource{ws.z.as<double>(), ws.nhi.as<double>(), nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0},
                       ws.out.as<double>(), nullptr);
     if (rc) return rc;
     if ((rc = tr.run_downloads())) return rc;
@@ -728,7 +731,7 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
         hipLaunchKernelGGL(fill_i32, dim3((unsigned)std::min<long>((n_base + 255) / 256, 2048)), dim3(256), 0, stream,
                            d_base, n_base, 0);
     HIP_TRY(hipGetLastError());
-    SampleSource src{d_sample_z, d_sample_nhi, d_base, 1, (long)nhi_stride, max_dlas - 1, nullptr, nullptr, 0, 0, 0};
+    SampleSource src{d_sample_z, d_sample_nhi, d_base, 1, (long)nhi_stride, max_dlas - 1, nullptr, nullptr, 0, 0, 0, 0, 0};
     // Profile cache: every absorber of every level is one of the sightline's S QMC points, whose convolved
     // profile level 1 computes anyway.  Keeping them (8 S n_pad bytes per sightline) turns the Voigt work of
     // levels 2..max_dlas into HBM reads -- capacity traded for time on the shared FP64 pipe.
@@ -1220,7 +1223,7 @@ int dlagp_eval_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, cons
     int rc = check_eval_args(ctx, S, kd, d_z, d_nhi, d_out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    return launch_sweep(ctx->self, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0}, d_out,
+    return launch_sweep(ctx->self, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0}, d_out,
                         static_cast<hipStream_t>(stream));
 }
 
@@ -1288,7 +1291,7 @@ int dlagp_batch_eval_device(dlagp_batch *batch, int64_t S, int kd, const double 
     int rc = check_eval_args(batch, S, kd, d_z, d_nhi, d_out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(batch->group.device));
-    return launch_sweep(batch->group, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0}, d_out,
+    return launch_sweep(batch->group, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0}, d_out,
                         static_cast<hipStream_t>(stream));
 }
 
@@ -1369,6 +1372,67 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
     return DLAGP_OK;
 }
 
+// ---- one sightline's samples split over several GPUs (SURVEY 8e "secondary", reference dla_gp.py:132-159 is
+// independent per sample, :209-218 needs all S): every rank evaluates its slice of a level, the slices are
+// all-gathered by the caller (RCCL), and every rank finishes the level on the full vector with the same uniforms
+int dlagp_batch_level_eval_device(dlagp_batch *batch, int64_t S_total, int64_t s_begin, int64_t s_count, int level,
+                                  const double *d_sample_z, const double *d_sample_nhi, int64_t nhi_stride,
+                                  const int32_t *d_base_inds, int base_levels, double *d_out, void *stream) {
+    if (!batch) return fail(DLAGP_EINVAL, "NULL batch");
+    if (S_total <= 0 || s_begin < 0 || s_count < 0 || s_begin + s_count > S_total)
+        return fail(DLAGP_EINVAL, "sample slice [%lld, %lld) outside [0, %lld)", (long long)s_begin,
+                    (long long)(s_begin + s_count), (long long)S_total);
+    if (level < 0 || level >= DLAGP_MAX_ABSORBERS) return fail(DLAGP_EINVAL, "level %d outside [0, %d)", level, DLAGP_MAX_ABSORBERS);
+    if (level > base_levels) return fail(DLAGP_EINVAL, "level %d needs %d rows of base indices, have %d", level, level, base_levels);
+    if (nhi_stride != 0 && nhi_stride < S_total) return fail(DLAGP_EINVAL, "nhi_stride must be 0 (shared) or >= S_total");
+    if (!d_sample_z || !d_sample_nhi || (level > 0 && !d_base_inds) || (s_count > 0 && !d_out))
+        return fail(DLAGP_EINVAL, "NULL argument");
+    if (s_count == 0) return DLAGP_OK;
+    HIP_TRY(hipSetDevice(batch->group.device));
+    const SampleSource src{d_sample_z, d_sample_nhi, d_base_inds, 1, (long)nhi_stride, base_levels, nullptr, nullptr,
+                           0, 0, 0, (long)s_begin, (long)S_total};
+    return launch_sweep(batch->group, s_count, level + 1, src, d_out, static_cast<hipStream_t>(stream));
+}
+
+int dlagp_sweep_state_init_device(int nb, int64_t S, int max_dlas, double *d_sample_ll, double *d_evidences,
+                                  int32_t *d_base_inds, int32_t *d_flags, int device, void *stream_) {
+    if (nb <= 0 || S <= 0 || max_dlas < 1 || max_dlas > DLAGP_MAX_ABSORBERS) return fail(DLAGP_EINVAL, "bad shape");
+    if (!d_sample_ll || !d_evidences || !d_flags || (max_dlas > 1 && !d_base_inds)) return fail(DLAGP_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    const long n_ll = (long)nb * S * max_dlas, n_base = (long)nb * S * (max_dlas - 1);
+    hipLaunchKernelGGL(fill_f64, dim3((unsigned)std::min<long>((n_ll + 255) / 256, 2048)), dim3(256), 0, stream,
+                       d_sample_ll, n_ll, nan);
+    hipLaunchKernelGGL(fill_f64, dim3(1), dim3(256), 0, stream, d_evidences, (long)nb * max_dlas, nan);
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(256), 0, stream, d_flags, (long)nb, 1);
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, stream, d_flags + nb, 2L, 0);
+    if (n_base > 0)
+        hipLaunchKernelGGL(fill_i32, dim3((unsigned)std::min<long>((n_base + 255) / 256, 2048)), dim3(256), 0, stream,
+                           d_base_inds, n_base, 0);
+    HIP_TRY(hipGetLastError());
+    return DLAGP_OK;
+}
+
+int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const double *d_ll, const double *d_sample_z,
+                              double min_z_separation, const double *d_uniforms, double *d_sample_ll,
+                              double *d_evidences, int32_t *d_base_inds, double *d_cdf_scratch, int32_t *d_flags,
+                              int device, void *stream) {
+    if (nb <= 0 || S <= 0 || level < 0 || level >= max_dlas || max_dlas > DLAGP_MAX_ABSORBERS)
+        return fail(DLAGP_EINVAL, "bad shape");
+    if (!d_ll || !d_sample_z || !d_sample_ll || !d_evidences || !d_cdf_scratch || !d_flags ||
+        (max_dlas > 1 && (!d_base_inds || !d_uniforms)))
+        return fail(DLAGP_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    // the kernel reads the redshifts of a sample's absorbers through the index table; column densities are not used
+    const SampleSource src{d_sample_z, d_sample_z, d_base_inds, 1, 0, max_dlas - 1, nullptr, nullptr, 0, 0, 0, 0, 0};
+    hipLaunchKernelGGL(level_finish, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS), 0, static_cast<hipStream_t>(stream),
+                       d_ll, (long)S, level, max_dlas, src, min_z_separation, d_uniforms, d_sample_ll, d_evidences,
+                       d_base_inds, d_cdf_scratch, d_flags, d_flags + nb + 1, d_flags + nb);
+    HIP_TRY(hipGetLastError());
+    return DLAGP_OK;
+}
+
 int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, const uint8_t *d_too_close,
                                 double *d_evidence, int device, void *stream) {
     if (!d_ll || !d_evidence) return fail(DLAGP_EINVAL, "NULL argument");
@@ -1377,6 +1441,31 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
     hipLaunchKernelGGL(level_evidence, dim3((unsigned)nb), dim3(DLAGP_EVIDENCE_THREADS), 0,
                        static_cast<hipStream_t>(stream), d_ll, (long)S, level, d_too_close, d_evidence);
     HIP_TRY(hipGetLastError());
+    return DLAGP_OK;
+}
+
+int dlagp_debug_voigt(int form, int line, int64_t n, const double *velocity, double *out, int device) {
+    if (!velocity || !out || n < 0) return fail(DLAGP_EINVAL, "bad argument");
+    if (form < 0 || form > 1) return fail(DLAGP_EINVAL, "form must be 0 (generic kernels) or 1 (MFMA kernel)");
+    if (line < 0 || line >= DLAGP_MAX_LINES) return fail(DLAGP_EINVAL, "line %d outside [0, %d)", line, DLAGP_MAX_LINES);
+    if (n == 0) return DLAGP_OK;
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    DeviceBuffer d_in, d_out;
+    if ((rc = d_in.reserve((size_t)n * sizeof(double))) || (rc = d_out.reserve((size_t)n * sizeof(double)))) {
+        d_in.release();
+        return rc;
+    }
+    hipError_t err = hipMemcpy(d_in.ptr, velocity, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(voigt_forms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, form, line, (long)n,
+                           d_in.as<const double>(), 1.0 / (std::sqrt(2.0 * M_PI) * DLAGP_SIGMA_CGS), d_out.as<double>());
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpy(out, d_out.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    d_in.release();
+    d_out.release();
+    if (err != hipSuccess) return fail(DLAGP_EDEVICE, "dlagp_debug_voigt failed: %s", hipGetErrorString(err));
     return DLAGP_OK;
 }
 
@@ -1413,6 +1502,8 @@ int dlagp_set_option(const char *name, int64_t value) {
     }
     else if (!strcmp(name, "profile_cache")) g_opt_profile_cache = value;
     else if (!strcmp(name, "profile_cache_max_mb")) g_opt_profile_cache_max_mb = value;
+    else if (!strcmp(name, "plan_item_cost")) g_opt_plan_item_cost = value;
+    else if (!strcmp(name, "plan_rest_first")) g_opt_plan_rest_first = value;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 }

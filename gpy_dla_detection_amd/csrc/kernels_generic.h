@@ -140,7 +140,7 @@ __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void absorption_generic(
     double *a = raw + lds_entries;
     double *mult = a + lds_pixels;
     const SightlineDev &sl = sightlines[0];
-    const SampleSource src{z, nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0};
+    const SampleSource src{z, nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0};
     sample_absorption(sl, kd, src, 0, 0, 1, raw, a, mult);
     for (int i = threadIdx.x; i < sl.n; i += DLAGP_GENERIC_THREADS) out[i] = a[i];
 }

@@ -755,4 +755,22 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     }
 }
 
+// Diagnostic (dlagp_debug_voigt): the Voigt profile V(v; sigma, gamma_l) = Re w((v + i gamma_l)/(sqrt2 sigma)) /
+// (sqrt(2 pi) sigma) of reference voigt.py:241-248 exactly as the kernels form it -- form 0: generic kernels
+// (line_optical_depth: asymptotic series / Taylor table), form 1: MFMA kernel (degree-4 wing fit with the
+// constants folded per line / Taylor table inside 16 Doppler widths) -- so that tests can hold the device
+// Faddeeva evaluation itself to the reference's golden grid.
+__global__ void voigt_forms(int form, int line, long n, const double *__restrict__ velocity, double inv_sqrt_2pi_sigma,
+                            double *__restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = velocity[i] * DLAGP_LINES.inv_sqrt2_sigma;
+    const double x2 = x * x;
+    double term;  // lc_l V / lc_l * k_core, i.e. k_core Re w
+    if (!(x2 >= DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT)) term = DLAGP_LINES.k_core[line] * core_taylor(x, DLAGP_LINES.y[line]);
+    else if (form == 0) term = DLAGP_LINES.k_wing[line] * wing_series(x, DLAGP_LINES.y[line] * DLAGP_LINES.y[line]);
+    else term = wing_term(x2, DLAGP_LINES.wing[line]);
+    out[i] = term / DLAGP_LINES.k_core[line] * inv_sqrt_2pi_sigma;
+}
+
 }  // namespace dlagp

@@ -13,8 +13,9 @@
 //               giving  Re w = (y/sqrt(pi)) u [A(u) - y^2 u B(u)],  u = 1/x^2,
 //               A(u) = sum_m (2m+1)!!/2^m u^m (10 terms),  B(u) = 1 + 5u + 26.25u^2
 //
-// Measured against scipy.special.wofz on 400k points x 31 lines: max relative
-// difference 2.7e-14 (tests/test_faddeeva.py re-checks on the reference's golden grid).
+// tests/test_gpu_parity.py::test_device_voigt_profile_matches_reference_golden holds both forms the kernels use
+// (dlagp_debug_voigt) to the reference's own Voigt values on golden grid G1, all 31 lines, and records the
+// measured maximum relative differences (profiles/r02_faddeeva_accuracy.txt).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -10,7 +10,13 @@ The reference processes one spectrum at a time in a single Python process
     saving and restoring the legacy global RNG state around each sightline's turn;
   * shards sightlines over ranks in contiguous blocks (one process per GPU, no data-path
     collective) and gathers the per-sightline log-evidences to every rank with one all-gather --
-    RCCL over xGMI when the process group is `nccl`, `gloo` in the CPU tests.
+    RCCL over xGMI when the process group is `nccl`, `gloo` in the CPU tests;
+  * splits the samples of ONE sightline over the ranks (`sweep_sharded_samples*`, the single-spectrum
+    scaling point): the S samples of an occupation level are independent (reference dla_gp.py:132-159;
+    MATLAB parallelises this axis, multi_dlas/process_qsos_multiple_dlas_meanflux.m:333), the
+    resampling between levels needs all of them (:209-218) -- one all-gather of S/G doubles per level,
+    then every rank finishes the level with the same random numbers, so `base_sample_inds` agree on all
+    ranks without a broadcast.
 
 Message sizes: (2 + max_dlas) doubles per sightline -- 48 B for the default model list
 [null, sub-DLA, DLA(1..4)] -- so the gather is latency-bound (1024 sightlines = 48 KB).
@@ -46,7 +52,11 @@ def gather_rows(local_rows: np.ndarray, total_rows: int, group=None, device=None
     m = local_rows.shape[1]
     largest = shard_range(total_rows, world, 0)[1]
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        if dist.get_backend(group) == "nccl":
+            _require_torch_gpu(torch)
+            device = torch.device("cuda", torch.cuda.current_device())
+        else:
+            device = torch.device("cpu")
     send = torch.full((largest, m), float("nan"), dtype=torch.float64, device=device)
     send[: local_rows.shape[0]] = torch.from_numpy(local_rows).to(device)
     recv = [torch.empty_like(send) for _ in range(world)]
@@ -56,6 +66,118 @@ def gather_rows(local_rows: np.ndarray, total_rows: int, group=None, device=None
         lo, hi = shard_range(total_rows, world, r)
         out[lo:hi] = recv[r][: hi - lo].cpu().numpy()
     return out
+
+
+def _require_torch_gpu(torch) -> None:
+    """RCCL needs torch's HIP runtime to own the GPU: it must have initialised before libdlagp_hip's"""
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "the process group is `nccl` but torch sees no GPU: initialise torch's HIP runtime (torch.cuda.init()) "
+            "before the first call into libdlagp_hip.so -- the second HIP runtime to start in a process does not see "
+            "the device (gpy_dla_detection_amd._lib.load() does this by itself when torch is already imported)")
+
+
+def sweep_sharded_samples(level_eval: Callable[[np.ndarray, np.ndarray], np.ndarray], sample_z: np.ndarray,
+                          sample_nhi: np.ndarray, max_dlas: int, min_z_separation: float,
+                          rank: int = 0, world_size: int = 1, group=None):
+    """
+    Occupation sweep (reference dla_gp.py:92-225) of ONE sightline with the samples of every level split over the
+    ranks: rank r evaluates samples `shard_range(S, world_size, r)` (`level_eval(z (s, kd), nhi (s, kd)) -> (s,)`,
+    e.g. `DeviceSightline.eval`), the slices are all-gathered (S / world_size doubles per rank and level), and
+    every rank runs the level's host half (`dla_gp.finish_level`) on the full vector.  The legacy global NumPy RNG
+    must be in the same state on every rank (seed it the same way, as the reference driver does per spectrum,
+    run_bayes_select.py:144): the resampled `base_sample_inds` are then identical everywhere and equal to a
+    single-process sweep's.
+
+    :return: evidences (max_dlas,), sample_log_likelihoods (S, max_dlas), base_sample_inds (max_dlas - 1, S) int32
+    """
+    S = sample_z.shape[0]
+    lo, hi = shard_range(S, world_size, rank)
+    evidences = np.full((max_dlas,), np.nan)
+    base_sample_inds = np.zeros((max_dlas - 1, S), dtype=np.int32)
+    sample_log_likelihoods = np.full((S, max_dlas), np.nan)
+    for level in range(max_dlas):
+        z, nhi, idx = level_parameters(sample_z, sample_nhi, base_sample_inds, level)
+        local = np.asarray(level_eval(z[lo:hi], nhi[lo:hi]), dtype=np.float64).reshape(hi - lo, 1)
+        full = gather_rows(local, S, group=group)[:, 0] if world_size > 1 else local[:, 0]
+        sample_log_likelihoods[:, level] = full - np.log(S)  # dla_gp.py:155-159
+        evidences[level], keep_going = finish_level(
+            sample_log_likelihoods, level, sample_z, idx, min_z_separation, max_dlas, base_sample_inds)
+        if not keep_going:
+            break
+    return evidences, sample_log_likelihoods, base_sample_inds
+
+
+def sweep_sharded_samples_device(batch, sample_z: np.ndarray, sample_nhi: np.ndarray, max_dlas: int,
+                                 min_z_separation: float, uniforms: Optional[np.ndarray] = None,
+                                 rank: int = 0, world_size: int = 1, group=None, slices: Optional[Sequence] = None):
+    """
+    The same by-sample split with everything resident in HBM (C ABI `dlagp_batch_level_eval_device`,
+    `dlagp_level_finish_device`): per level one slice evaluation, one all-gather of the slice
+    (`torch.distributed.all_gather_into_tensor` = RCCL over xGMI when the group is `nccl`) and the level's
+    device half on every rank with the same `uniforms` (`resampling_uniforms`) -- no host round trip.
+
+    :param batch: `sightline.DeviceBatch` of the nb sightlines whose samples are split (normally one)
+    :param sample_z: (nb, S); sample_nhi: (S,) shared or (nb, S); uniforms: (nb, max_dlas - 1, S)
+    :param slices: testing aid on one GPU: evaluate these [(lo, hi), ...] slices one after the other in this
+        process instead of one slice per rank (no process group involved)
+    :return: evidences (nb, max_dlas), sample_log_likelihoods (nb, S, max_dlas), base_sample_inds (nb, max_dlas - 1, S)
+    """
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib
+
+    lib = _lib.load()
+    nb, S = sample_z.shape
+    if max_dlas > 1 and (uniforms is None or uniforms.shape != (nb, max_dlas - 1, S)):
+        raise ValueError("uniforms must be (nb, max_dlas - 1, S)")
+    distributed = world_size > 1 and slices is None
+    if distributed and dist.get_backend(group) == "nccl":
+        _require_torch_gpu(torch)
+    dev = torch.device("cuda", batch.sightlines[0].device)
+    f64 = dict(dtype=torch.float64, device=dev)
+    d_z = torch.from_numpy(np.ascontiguousarray(sample_z, dtype=np.float64)).to(dev)
+    d_nhi = torch.from_numpy(np.ascontiguousarray(sample_nhi, dtype=np.float64)).to(dev)
+    nhi_stride = 0 if sample_nhi.ndim == 1 else S
+    d_uniforms = torch.from_numpy(np.ascontiguousarray(uniforms, dtype=np.float64)).to(dev) if max_dlas > 1 else None
+    d_sample_ll = torch.empty((nb, max_dlas, S), **f64)
+    d_evidences = torch.empty((nb, max_dlas), **f64)
+    d_base = torch.zeros((nb, max(max_dlas - 1, 1), S), dtype=torch.int32, device=dev)
+    d_flags = torch.zeros(nb + 2, dtype=torch.int32, device=dev)
+    d_cdf = torch.empty((nb, S), **f64)
+    per_rank = -(-S // world_size)  # equal slices (the last may be short): one fixed-size collective per level
+    mine = slices if slices is not None else [(min(rank * per_rank, S), min((rank + 1) * per_rank, S))]
+    d_local = torch.zeros((nb, per_rank if slices is None else max(hi - lo for lo, hi in mine)), **f64)
+    d_all = torch.zeros((world_size, nb, per_rank), **f64) if distributed else None
+    d_ll = torch.empty((nb, S), **f64)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+
+    _lib.check(lib.dlagp_sweep_state_init_device(nb, S, max_dlas, ptr(d_sample_ll), ptr(d_evidences), ptr(d_base),
+                                                 ptr(d_flags), dev.index, stream))
+    for level in range(max_dlas):
+        for lo, hi in mine:
+            out = d_local[:, : hi - lo].contiguous() if d_local.shape[1] != hi - lo else d_local
+            _lib.check(lib.dlagp_batch_level_eval_device(
+                batch._handle, S, lo, hi - lo, level, ptr(d_z), ptr(d_nhi), nhi_stride, ptr(d_base),
+                max(max_dlas - 1, 0), ptr(out), stream))
+            if not distributed:
+                d_ll[:, lo:hi] = out
+            elif out is not d_local:
+                d_local[:, : hi - lo] = out
+        if distributed:
+            if dist.get_backend(group) == "nccl":
+                dist.all_gather_into_tensor(d_all, d_local, group=group)
+            else:  # gloo rehearsal
+                dist.all_gather(list(d_all.unbind(0)), d_local, group=group)
+            d_ll.copy_(d_all.permute(1, 0, 2).reshape(nb, world_size * per_rank)[:, :S])
+        _lib.check(lib.dlagp_level_finish_device(
+            nb, S, level, max_dlas, ptr(d_ll), ptr(d_z), float(min_z_separation), ptr(d_uniforms), ptr(d_sample_ll),
+            ptr(d_evidences), ptr(d_base), ptr(d_cdf), ptr(d_flags), dev.index, stream))
+    torch.cuda.synchronize(dev)
+    base = d_base[:, : max_dlas - 1].cpu().numpy() if max_dlas > 1 else np.zeros((nb, 0, S), dtype=np.int32)
+    return (d_evidences.cpu().numpy(), np.ascontiguousarray(d_sample_ll.cpu().numpy().transpose(0, 2, 1)), base)
 
 
 def sweep_batch(

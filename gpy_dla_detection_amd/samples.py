@@ -94,13 +94,20 @@ class DLASamples:
         import h5py  # optional dependency
 
         with h5py.File(dla_samples_file, "r") as f:
-            return cls(
+            self = cls(
                 params,
                 prior,
                 f["offset_samples"][:, 0],
                 f["log_nhi_samples"][:, 0],
                 f["nhi_samples"][:, 0],
             )
+            # the file must have been generated with these parameters (reference dla_samples.py:69-70) ...
+            assert self.alpha == f["alpha"][0, 0]
+            assert self.uniform_min_log_nhi == f["uniform_min_log_nhi"][0, 0]
+            # ... and its column-density range is the one the MCMC prior uses (reference :76-77)
+            self.uniform_min_log_nhi = f["uniform_min_log_nhi"][0, 0]
+            self.uniform_max_log_nhi = f["uniform_max_log_nhi"][0, 0]
+        return self
 
     @classmethod
     def halton_synthetic(cls, params: Parameters, prior=None, num: Optional[int] = None):
@@ -151,7 +158,7 @@ class SubDLASamples(DLASamples):
         import h5py  # optional dependency
 
         with h5py.File(sub_dla_samples_file, "r") as f:
-            return cls(
+            self = cls(
                 params,
                 prior,
                 f["offset_samples"][:, 0],
@@ -161,6 +168,10 @@ class SubDLASamples(DLASamples):
                 Z_lls=f["Z_lls"][0, 0],
                 extrapolate_min_log_nhi=f["extrapolate_min_log_nhi"][0, 0],
             )
+            # consistency with the parameters the file was generated with (reference subdla_samples.py:83-84)
+            assert self.alpha == f["alpha"][0, 0]
+            assert self.num_dla_samples == f["num_dla_samples"][0, 0]
+        return self
 
     @classmethod
     def halton_synthetic(cls, params: Parameters, prior=None, num: Optional[int] = None):

@@ -330,6 +330,15 @@ def timing_read(reset: bool = True):
     return total.value, launches.value
 
 
+def debug_voigt(form: int, line: int, velocity, device: int = 0) -> np.ndarray:
+    """Voigt profile of series member `line` at `velocity` [cm/s] as the kernels evaluate it (0 generic, 1 MFMA)"""
+    velocity = np.ascontiguousarray(_lib.as_f64(velocity)).ravel()
+    out = np.empty_like(velocity)
+    _lib.check(_lib.load().dlagp_debug_voigt(int(form), int(line), velocity.shape[0], _lib.ptr(velocity),
+                                             _lib.ptr(out), int(device)))
+    return out
+
+
 def debug_read(reset: bool = True):
     """per-phase shader-clock totals recorded while option 'debug' bit 1 was set (diagnostics)"""
     buf = (ctypes.c_uint64 * 8)()

@@ -220,6 +220,31 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
                                 double *d_evidence, int device, void *stream);
 
 /*
+ * One sightline's samples split over several GPUs (by-sample partition).  The samples of an
+ * occupation level are independent (reference dla_gp.py:132-159; MATLAB parfor,
+ * multi_dlas/process_qsos_multiple_dlas_meanflux.m:333) but the resampling needs all of them (:209-218).  Per level:
+ *   dlagp_batch_level_eval_device  every rank evaluates samples [s_begin, s_begin + s_count) of level `level`
+ *                                  (absorber 0 = QMC point s, absorber j = point base_inds[b][j-1][s], tables of
+ *                                  S_total samples per sightline) -> d_out[nb][s_count], raw log-likelihoods;
+ *   (caller) all-gather the slices into d_ll[nb][S_total] -- RCCL, S_total / G doubles per rank;
+ *   dlagp_level_finish_device      every rank: minus log S, separation mask, log-mean-exp evidence, resampling of
+ *                                  base_inds[b][level][:] with the SAME uniforms (:155-218) -- identical indices on
+ *                                  every rank, no broadcast.
+ * dlagp_sweep_state_init_device NaN-/zero-fills sample_ll [nb][max_dlas][S], evidences [nb][max_dlas], base_inds
+ * [nb][max_dlas-1][S] and the nb + 2 int32 flags (alive per sightline, sticky status, zero) before level 0.
+ * d_cdf_scratch: nb * S doubles.  All pointers are HBM addresses; everything is enqueued on `stream`.
+ */
+int dlagp_batch_level_eval_device(dlagp_batch *batch, int64_t S_total, int64_t s_begin, int64_t s_count, int level,
+                                  const double *d_sample_z, const double *d_sample_nhi, int64_t nhi_stride,
+                                  const int32_t *d_base_inds, int base_levels, double *d_out, void *stream);
+int dlagp_sweep_state_init_device(int nb, int64_t S, int max_dlas, double *d_sample_ll, double *d_evidences,
+                                  int32_t *d_base_inds, int32_t *d_flags, int device, void *stream);
+int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const double *d_ll, const double *d_sample_z,
+                              double min_z_separation, const double *d_uniforms, double *d_sample_ll,
+                              double *d_evidences, int32_t *d_base_inds, double *d_cdf_scratch, int32_t *d_flags,
+                              int device, void *stream);
+
+/*
  * Tuning / measurement hooks.
  *   dlagp_set_option: "pixel_splits" (0 = automatic work decomposition, h > 0 = every block of 16 samples
  *                     is cut into h equal pixel ranges), "path" (0 = automatic, 1 = generic
@@ -254,6 +279,11 @@ int dlagp_timing_read(double *total_ms, int64_t *launches, int reset);
  * phase over all waves (current device): [0] Voigt loop, [1] convolution, [2] weights + MFMA loop,
  * [3] epilogue, [4] whole wave, [5] waves.  Not for production launches. */
 int dlagp_debug_read(uint64_t *out, int n, int reset);
+/* Diagnostic: the Voigt profile V(v; sigma, gamma_line) of reference voigt.py:241-248 (replaces scipy.special.wofz
+ * there) at n velocities [cm/s] (host pointers), evaluated exactly as the kernels evaluate it: form 0 = generic
+ * kernels (asymptotic series / Taylor table), form 1 = MFMA kernel (per-line wing fit / Taylor table).  Lets the
+ * tests pin the device Faddeeva evaluation to the reference's golden grid directly. */
+int dlagp_debug_voigt(int form, int line, int64_t n, const double *velocity, double *out, int device);
 
 #ifdef __cplusplus
 }

@@ -362,15 +362,67 @@ def test_generic_and_mfma_paths_agree(shape, restore_options):
 
 
 def test_mfma_path_other_line_counts(restore_options):
+    """1, 5 and all 31 series members on the MFMA kernel: against the oracle, and against the generic kernel"""
+    from oracle import ref_like as R
+
     set_option = restore_options
     sight = make_sightline(2, n_unmasked=600, n_masked=11)
     z, _, nhi = make_qmc_samples(sight, 96)
     for lines in (1, 5, 31):
         dev = device_sightline(sight, num_lines=lines)
-        set_option("path", 1)
-        want = dev.eval(z, nhi)
+        st = oracle_state(sight, num_lines=lines)
+        pick = np.arange(0, 96, 4)
+        want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in pick])
         set_option("path", 2)
-        np.testing.assert_allclose(dev.eval(z, nhi), want, rtol=1e-11)
+        got = dev.eval(z, nhi)
+        np.testing.assert_allclose(got[pick], want, rtol=RTOL_LL, err_msg="%d lines" % lines)
+        set_option("path", 1)
+        np.testing.assert_allclose(got, dev.eval(z, nhi), rtol=1e-11)
+    # two absorbers x 31 lines on the MFMA kernel
+    dev = device_sightline(sight, num_lines=31)
+    st = oracle_state(sight, num_lines=31)
+    z2, n2 = np.stack([z, z[::-1]], axis=1), np.stack([nhi, nhi[::-1]], axis=1)
+    set_option("path", 2)
+    got = dev.eval(z2, n2)
+    want = np.array([R.sample_log_likelihood_k_dlas(st, z2[i], n2[i]) for i in range(0, 96, 12)])
+    np.testing.assert_allclose(got[::12], want, rtol=RTOL_LL)
+
+
+def test_device_voigt_profile_matches_reference_golden():
+    """
+    The device Faddeeva evaluation itself (not end-to-end): both forms the kernels use, for all 31 series members,
+    against the reference's voigt.Voigt values on golden grid G1 (801 velocities from the line centre to |x| ~ 4e4
+    Doppler widths).  The measured maxima go to profiles/r02_faddeeva_accuracy.txt.
+    """
+    import os
+
+    from gpy_dla_detection_amd import lyman_series as ls
+    from gpy_dla_detection_amd.sightline import debug_voigt
+
+    g = load_golden("voigt_profile.npz")
+    v, want = g["velocity"], g["profile"]
+    x = np.abs(v) / (np.sqrt(2) * ls.SIGMA_CGS)
+    core, wing = x < 16.0, x >= 16.0
+    assert core.sum() > 100 and wing.sum() > 100
+    worst = {}
+    for form, name in ((0, "generic"), (1, "mfma")):
+        for line in range(31):
+            got = debug_voigt(form, line, v)
+            rel = np.abs(got - want[line]) / np.abs(want[line])
+            for region, sel in (("core", core), ("wing", wing)):
+                key = (name, region)
+                worst[key] = max(worst.get(key, 0.0), float(rel[sel].max()))
+    lines = ["max relative difference of the device Voigt profile to the reference's (scipy.special.wofz), golden grid G1,",
+             "31 lines x 801 velocities; core = |x| < 16 Doppler widths (Taylor table, both forms), wing = |x| >= 16"]
+    for key in sorted(worst):
+        lines.append("  %-8s %-5s %.2e" % (key[0], key[1], worst[key]))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "faddeeva_accuracy.txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+    assert worst[("generic", "core")] < 2e-13 and worst[("mfma", "core")] < 2e-13, worst
+    assert worst[("generic", "wing")] < 1e-13, worst
+    assert worst[("mfma", "wing")] < 2e-12, worst   # degree-4 fit of the wing, DESIGN.md section 6
 
 
 def test_level_evidence_kernel_matches_numpy():
@@ -581,6 +633,41 @@ def test_device_sweep_equals_host_level_logic(path, cache, restore_options):
     np.testing.assert_allclose(got[0], want[0], rtol=1e-12)
 
 
+@pytest.mark.parametrize("tag", ["small", "full2k"])
+def test_by_sample_split_on_device_matches_reference_golden(tag):
+    """
+    SURVEY 8e by-sample partition through the C ABI (dlagp_batch_level_eval_device + dlagp_level_finish_device):
+    every level evaluated in slices of the samples, as G ranks would, then finished on the full vector -- the
+    reference's evidences, likelihoods and base indices (golden G5), and bit-identical to the unsliced device sweep.
+    """
+    import torch
+
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    torch.cuda.init()
+    g = load_golden("evidences_%s.npz" % tag)
+    kwargs = {k[len("sight_"):]: int(g[k]) for k in g.files if k.startswith("sight_") and k != "sight_crc"}
+    sight = make_sightline(**kwargs)
+    S, max_dlas = int(g["S"]), g["dla_evidences"].shape[0]
+    nhi = 10.0 ** (20.0 + 3.0 * halton(S, 3))
+    z = g["dla_sample_z"][None, :]
+    uniforms = parallel.resampling_uniforms(1, max_dlas, S, seed=0)
+    batch = DeviceBatch([device_sightline(sight)])
+    min_sep = float(g["dla_min_z_separation"])
+    results = []
+    for slices in (None, [(0, S // 3), (S // 3, S // 3 + 7), (S // 3 + 7, S)]):
+        ev, ll, base = parallel.sweep_sharded_samples_device(batch, z, nhi, max_dlas, min_sep, uniforms, slices=slices)
+        np.testing.assert_array_equal(base[0], g["dla_base_inds"])
+        np.testing.assert_allclose(ev[0], g["dla_evidences"], rtol=RTOL_LL)
+        np.testing.assert_allclose(ll[0], g["dla_sample_ll"], rtol=RTOL_LL, equal_nan=True)
+        results.append((ev, ll, base))
+    want_ev, want_ll, want_base = batch.sweep(z, nhi, max_dlas, min_sep, uniforms)
+    assert np.array_equal(results[0][2], want_base) and np.array_equal(results[1][2], want_base)
+    np.testing.assert_allclose(results[0][0], want_ev, rtol=1e-12)
+    np.testing.assert_allclose(results[1][1], want_ll, rtol=1e-12, equal_nan=True)
+
+
 def test_device_sweep_stops_a_sightline_on_nan_evidence():
     """reference dla_gp.py:200-206: a NaN evidence ends that sightline's sweep; the others go on"""
     from gpy_dla_detection_amd import parallel
@@ -646,6 +733,144 @@ def test_process_qso_on_device_matches_reference_driver_golden():
     results = process_qso(spectra, z_qsos, params, Prior(), dla_samples, sub_samples, learned,
                           max_dlas=int(g["max_dlas"]), batch_size=2)
     assert_catalogue_matches_golden(results, g, rtol=RTOL_LL)
+
+
+# ------------------------------------------------------------------------------------------------
+# INTEGRATION route A: the reference driver's loop body (run_bayes_select.py:141-230) with the imports swapped
+# ------------------------------------------------------------------------------------------------
+def test_reference_driver_loop_with_swapped_imports_matches_golden():
+    """
+    What a maintainer gets by changing only the import lines of the reference's run_bayes_select.py: three
+    GP objects per spectrum, `set_data` on each, `BayesModelSelect.model_selection`, `maximum_a_posteriori`,
+    `np.random.seed(0)` per spectrum -- against every array of golden set G8 (the reference's own classes
+    in the same loop).
+    """
+    from gpy_dla_detection_amd.bayesian_model_selection import BayesModelSelect
+    from gpy_dla_detection_amd.dla_gp import DLAGP
+    from gpy_dla_detection_amd.null_gp import NullGP
+    from gpy_dla_detection_amd.subdla_gp import SubDLAGP
+    from tests.test_host_logic import FixedPrior, assert_catalogue_matches_golden, catalogue_inputs
+
+    g = load_golden("catalogue.npz")
+    S, max_dlas = int(g["S"]), int(g["max_dlas"])
+    learned, spectra, z_qso_list, param, dla_samples, subdla_samples = catalogue_inputs(S)
+    learned = tuple(learned)[:7]
+    prior = FixedPrior()
+    broadening = True
+    bayes = BayesModelSelect([0, 1, max_dlas], 2)
+    num_quasars = len(spectra)
+    out = dict(
+        min_z_dlas=np.full((num_quasars,), np.nan), max_z_dlas=np.full((num_quasars,), np.nan),
+        log_priors_no_dla=np.full((num_quasars,), np.nan), log_priors_dla=np.full((num_quasars, max_dlas), np.nan),
+        log_priors_lls=np.full((num_quasars,), np.nan),
+        log_likelihoods_no_dla=np.full((num_quasars,), np.nan), log_likelihoods_dla=np.full((num_quasars, max_dlas), np.nan),
+        log_likelihoods_lls=np.full((num_quasars,), np.nan),
+        log_posteriors_no_dla=np.full((num_quasars,), np.nan), log_posteriors_dla=np.full((num_quasars, max_dlas), np.nan),
+        log_posteriors_lls=np.full((num_quasars,), np.nan),
+        sample_log_likelihoods_dla=np.full((num_quasars, S, max_dlas), np.nan),
+        base_sample_inds=np.zeros((num_quasars, S, max_dlas - 1), dtype=np.int32),
+        sample_log_likelihoods_lls=np.full((num_quasars, S), np.nan),
+        MAP_z_dlas=np.full((num_quasars, max_dlas, max_dlas), np.nan),
+        MAP_log_nhis=np.full((num_quasars, max_dlas, max_dlas), np.nan),
+        model_posteriors=np.full((num_quasars, 1 + 1 + max_dlas), np.nan),
+        p_dlas=np.full((num_quasars,), np.nan), p_no_dlas=np.full((num_quasars,), np.nan),
+    )
+    for quasar_ind, (spectrum, z_qso) in enumerate(zip(spectra, z_qso_list)):
+        np.random.seed(0)
+        wavelengths, flux, noise_variance, pixel_mask = spectrum  # read_spec(filename)
+        rest_wavelengths = param.emitted_wavelengths(wavelengths, z_qso)
+
+        gp = NullGP(param, prior, *learned)
+        gp.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
+        dla_gp = DLAGP(param, prior, dla_samples, *learned, min_z_separation=3000.0, broadening=broadening)
+        dla_gp.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
+        subdla_gp = SubDLAGP(param, prior, subdla_samples, *learned, min_z_separation=3000.0, broadening=broadening)
+        subdla_gp.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
+
+        bayes.model_selection([gp, subdla_gp, dla_gp], z_qso)
+
+        out["min_z_dlas"][quasar_ind] = dla_gp.params.min_z_dla(wavelengths, z_qso)
+        out["max_z_dlas"][quasar_ind] = dla_gp.params.max_z_dla(wavelengths, z_qso)
+        out["log_priors_no_dla"][quasar_ind] = bayes.log_priors[0]
+        out["log_priors_dla"][quasar_ind, :] = bayes.log_priors[-max_dlas:]
+        out["log_priors_lls"][quasar_ind] = bayes.log_priors[1]
+        out["log_likelihoods_no_dla"][quasar_ind] = bayes.log_likelihoods[0]
+        out["log_likelihoods_dla"][quasar_ind, :] = bayes.log_likelihoods[-max_dlas:]
+        out["log_likelihoods_lls"][quasar_ind] = bayes.log_likelihoods[1]
+        out["log_posteriors_no_dla"][quasar_ind] = bayes.log_posteriors[0]
+        out["log_posteriors_dla"][quasar_ind, :] = bayes.log_posteriors[-max_dlas:]
+        out["log_posteriors_lls"][quasar_ind] = bayes.log_posteriors[1]
+        out["sample_log_likelihoods_dla"][quasar_ind, :, :] = dla_gp.sample_log_likelihoods[:, :]
+        out["base_sample_inds"][quasar_ind, :, :] = dla_gp.base_sample_inds[:, :].T
+        out["sample_log_likelihoods_lls"][quasar_ind, :] = subdla_gp.sample_log_likelihoods[:, 0]
+        MAP_z_dla, MAP_log_nhi = dla_gp.maximum_a_posteriori()
+        out["MAP_z_dlas"][quasar_ind, :, :] = MAP_z_dla[:, :]
+        out["MAP_log_nhis"][quasar_ind, :, :] = MAP_log_nhi[:, :]
+        out["model_posteriors"][quasar_ind, :] = bayes.model_posteriors[:]
+        out["p_dlas"][quasar_ind] = bayes.p_dla
+        out["p_no_dlas"][quasar_ind] = bayes.p_no_dla
+    out["z_qsos"] = np.array(z_qso_list)
+    out["num_dla_samples"], out["k"] = param.num_dla_samples, param.k
+    assert_catalogue_matches_golden(out, g, rtol=RTOL_LL)
+
+
+def test_overridden_this_dla_gp_is_honoured_sample_by_sample():
+    """
+    The hook of reference examples/gp_find_lls.py:159-224: a subclass that overrides `this_dla_gp` changes
+    the model, so the sweep must call it for every sample (no batched launch of the stock profile) and
+    agree with the oracle evaluated on the modified model.
+    """
+    from gpy_dla_detection_amd.dla_gp import DLAGP
+    from gpy_dla_detection_amd.set_parameters import Parameters
+    from oracle import ref_like as R
+    from tests.golden_inputs import raw_spectrum_and_model
+
+    calls = []
+
+    class DimmedDLAGP(DLAGP):
+        def this_dla_gp(self, z_dlas, nhis):
+            calls.append(len(z_dlas))
+            mu, M, omega2 = super().this_dla_gp(z_dlas, nhis)
+            dim = 1.0 - 0.1 * np.exp(-0.5 * ((self.this_wavelengths - 4300.0) / 150.0) ** 2)  # an extra, fixed factor
+            return mu * dim, M * dim[:, None], omega2 * dim ** 2
+
+    S, max_dlas = 48, 2
+    z_qso, rest, flux, noise_variance, pixel_mask, rest_grid, mu, M, log_omega, lc0, lt0, lb = raw_spectrum_and_model()
+    params = Parameters(num_dla_samples=S)
+    from gpy_dla_detection_amd.samples import DLASamples
+
+    samples = DLASamples(params, None, halton(S, 2), 20.0 + 3.0 * halton(S, 3))
+    gp = DimmedDLAGP(params, None, samples, rest_grid, mu, M, log_omega, lc0, lt0, lb)
+    gp.set_data(rest, flux, noise_variance, pixel_mask, z_qso, build_model=True)
+    np.random.seed(0)
+    got = gp.log_model_evidences(max_dlas)
+    assert len(calls) == S * max_dlas and calls[0] == 1 and calls[-1] == 2  # the per-sample path was taken
+
+    # oracle on the same modified model, the reference's loop (dla_gp.py:92-225) with the same seed
+    st = R.SpectrumState(gp.y, gp.v, gp.this_mu, gp.this_M, gp.this_omega2, gp.padded_wavelengths,
+                         gp.unmasked_wavelengths, ~gp.pixel_mask[gp.ind_unmasked])
+    dim = 1.0 - 0.1 * np.exp(-0.5 * ((gp.this_wavelengths - 4300.0) / 150.0) ** 2)
+
+    def sample_ll(z_dlas, nhis):
+        a = np.ones_like(st.this_mu)
+        for z, n in zip(z_dlas, nhis):
+            a = a * R.voigt_absorption(st.padded_wavelengths, n, z)[st.keep]
+        a = a * dim
+        return R.log_mvnpdf_low_rank(st.y, st.this_mu * a, st.this_M * a[:, None], st.this_omega2 * a ** 2 + st.v)
+
+    from gpy_dla_detection_amd.dla_gp import occupation_sweep
+
+    np.random.seed(0)
+    sample_z = samples.sample_z_dlas(gp.this_wavelengths, z_qso)
+    want, want_ll, want_base = occupation_sweep(
+        lambda z, nhi: np.array([sample_ll(z[i], nhi[i]) for i in range(z.shape[0])]),
+        sample_z, samples.nhi_samples, max_dlas, gp.min_z_separation, S)
+    np.testing.assert_allclose(got, want, rtol=RTOL_LL)
+    np.testing.assert_allclose(gp.sample_log_likelihoods, want_ll, rtol=RTOL_LL, equal_nan=True)
+    assert np.array_equal(gp.base_sample_inds, want_base)
+    # a single overridden sample, too
+    one = gp.sample_log_likelihood_k_dlas(np.array([sample_z[3]]), np.array([samples.nhi_samples[3]]))
+    assert abs(one - sample_ll([sample_z[3]], [samples.nhi_samples[3]])) <= RTOL_LL * abs(one)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -138,6 +138,20 @@ learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(96
 res = process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=3,
                   rank=rank, world_size=world, engine=OracleEngine(learned, params))
 np.savez(os.path.join(os.environ["DLAGP_OUT"], "catalogue_rank%d.npz" % rank), **res)
+
+# ONE sightline, its samples split over the ranks: all-gather of S / world doubles per level, every rank resamples
+from gpy_dla_detection_amd.samples import halton
+from tests.conftest import load_golden
+from tests.test_host_logic import oracle_level_evaluator
+g = load_golden("evidences_small.npz")
+sight = make_sightline(int(g["sight_index"]), n_unmasked=int(g["sight_n_unmasked"]),
+                       n_masked=int(g["sight_n_masked"]), k=int(g["sight_k"]))
+S = int(g["S"])
+np.random.seed(0)
+ev, sll, base = parallel.sweep_sharded_samples(oracle_level_evaluator(sight), g["dla_sample_z"],
+                                               10.0 ** (20.0 + 3.0 * halton(S, 3)), 4,
+                                               float(g["dla_min_z_separation"]), rank=rank, world_size=world)
+np.savez(os.path.join(os.environ["DLAGP_OUT"], "by_sample_rank%d.npz" % rank), ev=ev, sll=sll, base=base)
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -187,6 +201,14 @@ def test_sharded_evidences_gloo_world_size_2(tmp_path):
     for name in cat0.files:
         np.testing.assert_array_equal(cat0[name], cat1[name], err_msg=name)
     assert_catalogue_matches_golden(cat0, g, rtol=1e-10)
+    # by-sample split of one sightline (each rank evaluated half of the samples of every level): both ranks hold
+    # the reference's evidences, per-sample likelihoods and -- exactly -- its resampled base indices
+    g = load_golden("evidences_small.npz")
+    for r in (0, 1):
+        got = np.load(tmp_path / ("by_sample_rank%d.npz" % r))
+        np.testing.assert_array_equal(got["base"], g["dla_base_inds"])
+        np.testing.assert_allclose(got["ev"], g["dla_evidences"], rtol=1e-12)
+        np.testing.assert_allclose(got["sll"], g["dla_sample_ll"], rtol=1e-12, equal_nan=True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -326,3 +348,67 @@ def test_prepare_data_is_the_data_half_of_set_data():
     raw = prepare_data(Parameters(), rest, flux, nv, mask, z_qso, normalize=False)
     np.testing.assert_allclose(raw["y"] / st["normalization_median"], st["y"], rtol=1e-15)
     assert "normalization_median" not in raw
+
+
+def test_write_results_hdf5_branch_with_a_stand_in_h5py(tmp_path, monkeypatch):
+    """
+    `write_results` through its h5py branch (h5py is not installed here): a recording stand-in module checks that
+    every dataset of the reference's writer (run_bayes_select.py:248-295) is created, with its shape and dtype.
+    """
+    import sys
+    import types
+
+    from gpy_dla_detection_amd.run_bayes_select import process_qso, write_results
+
+    created = {}
+
+    class File:
+        def __init__(self, name, mode):
+            assert mode == "w"
+            created["__file__"] = name
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+        def create_dataset(self, name, data=None):
+            assert name not in created, "dataset written twice: " + name
+            created[name] = np.asarray(data)
+
+    fake = types.ModuleType("h5py")
+    fake.File = File
+    fake.string_dtype = lambda encoding="utf-8": np.dtype("S32")
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+
+    g = load_golden("catalogue.npz")
+    S, max_dlas = int(g["S"]), int(g["max_dlas"])
+    learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(S)
+    results = process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned,
+                          max_dlas=max_dlas, batch_size=3, engine=OracleEngine(learned, params),
+                          qso_list=["spec-%d" % i for i in range(3)])
+    target = str(tmp_path / "processed_qsos_multi_meanflux.h5")
+    assert write_results(results, target) == target and created.pop("__file__") == target
+    N = 3
+    reference_datasets = {  # name -> shape, in the reference's order of creation
+        "prior_z_qso_increase": (), "k": (), "normalization_min_lambda": (), "normalization_max_lambda": (),
+        "min_z_cut": (), "max_z_cut": (), "num_dla_samples": (), "num_lines": (), "num_forest_lines": (),
+        "min_z_dlas": (N,), "max_z_dlas": (N,),
+        "sample_log_likelihoods_dla": (N, S, max_dlas), "base_sample_inds": (N, S, max_dlas - 1),
+        "log_priors_no_dla": (N,), "log_priors_lls": (N,), "log_priors_dla": (N, max_dlas),
+        "log_likelihoods_no_dla": (N,), "log_likelihoods_lls": (N,), "log_likelihoods_dla": (N, max_dlas),
+        "log_posteriors_no_dla": (N,), "log_posteriors_lls": (N,), "log_posteriors_dla": (N, max_dlas),
+        "MAP_z_dlas": (N, max_dlas, max_dlas), "MAP_log_nhis": (N, max_dlas, max_dlas),
+        "p_dlas": (N,), "p_no_dlas": (N,), "model_posteriors": (N, 2 + max_dlas),
+        "z_qsos": (N,), "qso_list": (N,),
+    }
+    for name, shape in reference_datasets.items():
+        assert name in created, name
+        assert created[name].shape == shape, (name, created[name].shape)
+    assert created["base_sample_inds"].dtype == np.int32
+    assert created["qso_list"].dtype.kind == "S" and created["qso_list"][1] == b"spec-1"
+    assert int(created["num_dla_samples"]) == S and int(created["k"]) == params.k
+    np.testing.assert_array_equal(created["base_sample_inds"], g["base_sample_inds"])
+    # the only dataset beyond the reference's list: the sub-DLA sample likelihoods the driver keeps in memory (:124)
+    assert set(created) - set(reference_datasets) == {"sample_log_likelihoods_lls"}
