@@ -542,33 +542,124 @@ def test_one_gapped_sightline_does_not_slow_the_batch_down(restore_options):
     np.testing.assert_allclose(ll[7, pick, 0], want, rtol=RTOL_LL)
 
 
-def test_config3_batch_of_sightlines_full_size():
-    """BASELINE config 3 at reduced width: 16 sightlines x 10 000 samples, DLA(1) and sub-DLA in one batch each"""
-    from gpy_dla_detection_amd.sightline import DeviceBatch
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs[2..4] at their one-GPU widths (S = 10 000, n = 3000, k = 20)
+# ------------------------------------------------------------------------------------------------
+_FULL = {}
+
+
+def full_size_sightlines(count):
+    """the synthetic sightlines 0..count-1 of the bench workload, created once per test session"""
+    for i in range(len(_FULL), count):
+        _FULL[i] = make_sightline(i)
+    return [_FULL[i] for i in range(count)]
+
+
+def oracle_spot(sight, zs, ns):
     from oracle import ref_like as R
 
-    sights = [make_sightline(i) for i in range(16)]
+    st = oracle_state(sight)
+    return np.array([R.sample_log_likelihood_k_dlas(st, np.atleast_1d(z), np.atleast_1d(n)) for z, n in zip(zs, ns)])
+
+
+def test_config3_batch_of_64_sightlines_full_size():
+    """BASELINE configs[2]: 64 sightlines x 10 000 samples, DLA(1) and sub-DLA, one batch launch each"""
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    sights = full_size_sightlines(64)
     devs = [device_sightline(s) for s in sights]
     batch = DeviceBatch(devs)
     S = 10000
     z = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    pick = np.arange(7, S, 1111)
     for sub in (False, True):
         nhi = np.broadcast_to(make_qmc_samples(sights[0], S, sub_dla=sub)[2], z.shape)
         ll = batch.eval(z, nhi)
-        assert ll.shape == (16, S) and np.all(np.isfinite(ll))
-        # the batch launch (one pixel split) agrees with a single-sightline launch (three splits)
+        assert ll.shape == (64, S) and np.all(np.isfinite(ll))
+        # the batch launch (one piece per block) agrees with a single-sightline launch (pieces + remainder)
         np.testing.assert_allclose(ll[5], devs[5].eval(z[5], nhi[5]), rtol=1e-13)
-        # spot check against the oracle
-        st = oracle_state(sights[11])
-        pick = np.arange(7, S, 1111)
-        want = np.array([R.sample_log_likelihood_k_dlas(st, [z[11, i]], [nhi[11, i]]) for i in pick])
-        np.testing.assert_allclose(ll[11, pick], want, rtol=RTOL_LL)
+        for b in (0, 11, 40, 63):  # spot checks against the oracle
+            np.testing.assert_allclose(ll[b, pick], oracle_spot(sights[b], z[b, pick], nhi[b, pick]), rtol=RTOL_LL)
     # sightlines with an injected absorber prefer the DLA model at the injected redshift
     nhi = np.broadcast_to(make_qmc_samples(sights[0], S)[2], z.shape)
     ll = batch.eval(z, nhi)
-    for b in (1, 4, 7):  # index % 3 == 1: one injected absorber
+    for b in range(1, 64, 3):  # index % 3 == 1: one injected absorber
         best = int(np.argmax(ll[b]))
         assert abs(z[b, best] - sights[b].injected_z[0]) < 0.02
+    batch.close()
+    for d in devs:
+        d.close()
+
+
+def test_config4_one_gpu_share_128_sightlines_through_shard_runner():
+    """BASELINE configs[3] (1024 spectra / 8 GPUs): one rank's 128 sightlines x [null, sub-DLA, DLA(1)] at S = 10 000"""
+    from gpy_dla_detection_amd import parallel
+    from oracle import ref_like as R
+
+    sights = full_size_sightlines(128)
+    S = 10000
+    runner = parallel.ShardRunner(sights, S, max_dlas=1)
+    table = runner.run()
+    assert table.shape == (128, 3) and np.all(np.isfinite(table))
+    z = runner.z
+    pick = np.arange(3, S, 997)
+    log_S = np.log(S)
+    for b in (2, 64, 127):
+        st = oracle_state(sights[b])
+        assert abs(table[b, 0] - R.null_log_model_evidence(st)) <= RTOL_LL * abs(table[b, 0])
+        # the evidence is a log-mean-exp over all S samples: recompute it from oracle-checked likelihoods
+        for col, nhi in ((1, runner.nhi_sub), (2, runner.nhi_dla)):
+            dev_ll = runner.batch.batch.sightlines[b].eval(z[b], nhi)
+            np.testing.assert_allclose(dev_ll[pick], oracle_spot(sights[b], z[b, pick], nhi[pick]), rtol=RTOL_LL)
+            top = dev_ll.max()
+            want = top + np.log(np.mean(np.exp(dev_ll - top))) - log_S  # the Occam term of dla_gp.py:157-159
+            assert abs(table[b, col] - want) <= 1e-11 * abs(want)
+    # argmax over [null, DLA(1)] = injected truth (synthetic.py: index % 3 absorbers injected)
+    for b in range(128):
+        assert (table[b, 2] > table[b, 0]) == (b % 3 != 0), b
+
+
+def test_config5_one_gpu_share_32_sightlines_four_levels():
+    """BASELINE configs[4] (256 spectra / 8 GPUs): one rank's 32 sightlines x DLA(1..4) at S = 10 000, levels on the device"""
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch, get_option
+
+    sights = full_size_sightlines(32)
+    devs = [device_sightline(s) for s in sights]
+    batch = DeviceBatch(devs)
+    S, max_dlas = 10000, 4
+    min_sep = 3000.0e3 / 299792458.0
+    z = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    ev, ll, base = parallel.sweep_batch_device(batch, z, nhi, max_dlas, min_sep)
+    assert get_option("last_sweep_cached") == 1 and get_option("last_launch_path") == 2
+    assert ev.shape == (32, 4) and ll.shape == (32, S, 4) and base.shape == (32, 3, S)
+    assert np.all(np.isfinite(ev))
+    # (1) oracle spot checks on every level: the parameter sets of a few samples, rebuilt through the base indices
+    pick = np.arange(11, S, 1999)
+    for b in (0, 13, 31):
+        for level in range(max_dlas):
+            idx = np.concatenate([pick[None, :], base[b, :level][:, pick]], axis=0)  # (level + 1, len(pick))
+            want = oracle_spot(sights[b], z[b][idx].T, nhi[idx].T) - np.log(S)
+            got = ll[b, pick, level]
+            ok = ~np.isnan(got)  # NaN = two absorbers closer than min_z_separation (dla_gp.py:164-177)
+            zs = np.sort(z[b][idx], axis=0)
+            assert np.array_equal(~ok, np.any(np.diff(zs, axis=0) < min_sep, axis=0))
+            np.testing.assert_allclose(got[ok], want[ok], rtol=RTOL_LL)
+    # (2) device levels == host levels (NumPy half of every level, reference RNG) on two sightlines
+    two = DeviceBatch([devs[4], devs[22]])
+    want_ev, want_ll, want_base = parallel.sweep_batch(two.eval, z[[4, 22]], nhi, max_dlas, min_sep, seed=0)
+    assert np.array_equal(base[[4, 22]], want_base)
+    np.testing.assert_allclose(ev[[4, 22]], want_ev, rtol=1e-11)
+    np.testing.assert_allclose(ll[[4, 22]], want_ll, rtol=1e-11, equal_nan=True)
+    two.close()
+    # (3) model selection over [null, DLA(1..4)] picks the number of injected absorbers
+    nulls = batch.nulls()
+    for b in range(32):
+        assert int(np.argmax(np.concatenate([[nulls[b]], ev[b]]))) == b % 3, (b, nulls[b], ev[b])
+    batch.close()
+    for d in devs:
+        d.close()
 
 
 # ------------------------------------------------------------------------------------------------
