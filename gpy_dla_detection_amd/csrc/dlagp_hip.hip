@@ -60,7 +60,7 @@ static int64_t g_opt_core_patch = 1;     // MFMA kernel: line cores repaired out
 static int64_t g_opt_profile_cache = 1;  // multi-level sweeps keep level-1 profiles in HBM (0 = recompute)
 // never more than this for the cache (MB), and never more than half of the free HBM
 static int64_t g_opt_profile_cache_max_mb = 196608;
-static int64_t g_opt_plan_item_cost = 50;   // fixed cost of a work item in the planner's model, tenths of a chunk
+static int64_t g_opt_plan_item_cost = 20;   // fixed cost of a work item in the planner's model, tenths of a chunk
 static int64_t g_opt_plan_rest_first = 0;   // dispatch the remainder pieces before the full ones (tuning)
 // read-only diagnostics of the most recent launch / sweep (dlagp_get_option): which kernel served it
 static int64_t g_last_launch_path = 0;    // 1 generic kernel, 2 MFMA kernel
@@ -375,10 +375,65 @@ static void plan_passes(const std::vector<int> &slot_pos, int ntaps, int c0, int
 // Items are dispatched in index order as slots free up: full pieces first, then the remainders; the order affects
 // only the balance, never the results.  Every block of 16 samples adds its pieces' partial sums in piece order
 // (finalize kernels, `counts`), so results are deterministic.  Option pixel_splits = h forces (A) with that h.
+// Modelled time of one work item, in units of one chunk's weights + MFMA work (measured with the per-wave trace of
+// tools/wave_timeline.py: 7.2 us per item + 6.6 us per pass + 1.3 us per chunk): the Voigt profiles, the convolution
+// and the set-up of a pass cost the same whether the pass holds 7 chunks or 1.
+static double item_cost(const std::vector<int> &slot_pos, int ntaps, int c0, int c1) {
+    if (c1 <= c0) return 0.0;
+    std::vector<PassDesc> passes;
+    plan_passes(slot_pos, ntaps, c0, c1, passes);
+    constexpr double per8 = 8.0 / DLAGP_CHUNK_PIXELS;  // the constants below were measured per 8 slots
+    return per8 * (0.1 * (double)g_opt_plan_item_cost + 5.1 * (double)passes.size()) + (double)(c1 - c0);
+}
+
+// Moves the cuts of one sightline (edge[0] = 0 < edge[1] < ... < edge[last] = chunks) by up to 24 chunks each so that
+// the busiest wave slot gets as little as possible: in practice onto pass boundaries, so that no piece pays the
+// fixed cost of a pass for a handful of chunks.  The last piece is the remainder when `remainder`; a left-over
+// slot works through `rest_per_slot` of those.
+static void refine_cuts(const std::vector<int> &slot_pos, int ntaps, std::vector<int> &edge, bool remainder,
+                        long rest_per_slot) {
+    const int npieces = (int)edge.size() - 1;
+    if (npieces < 2) return;
+    auto piece_cost = [&](int j) {
+        const double c = item_cost(slot_pos, ntaps, edge[j], edge[j + 1]);
+        return remainder && j == npieces - 1 ? c * (double)rest_per_slot : c;
+    };
+    std::vector<double> cost(npieces);
+    for (int j = 0; j < npieces; ++j) cost[j] = piece_cost(j);
+    for (int round = 0; round < 3; ++round) {
+        bool moved = false;
+        for (int j = 1; j < npieces; ++j) {  // cut between pieces j - 1 and j
+            const int at = edge[j];
+            int best_at = at;
+            double best = std::max(cost[j - 1], cost[j]), best_sum = cost[j - 1] + cost[j];
+            for (int d = -24; d <= 24; ++d) {
+                const int cand = at + d;
+                if (d == 0 || cand <= edge[j - 1] || cand >= edge[j + 1]) continue;
+                edge[j] = cand;
+                const double a = piece_cost(j - 1), bb = piece_cost(j);
+                const double worst = std::max(a, bb);
+                if (worst < best - 1e-9 || (worst < best + 1e-9 && a + bb < best_sum - 1e-9)) {
+                    best = worst;
+                    best_sum = a + bb;
+                    best_at = cand;
+                }
+            }
+            edge[j] = best_at;
+            if (best_at != at) {
+                moved = true;
+                cost[j - 1] = piece_cost(j - 1);
+                cost[j] = piece_cost(j);
+            }
+        }
+        if (!moved) break;
+    }
+}
+
 // the cut, as fractions of a sightline's chunks: `full` pieces of `frac` each, then a remainder if frac * full < 1
 static void choose_cut(long groups, double C, int64_t forced, int *full_out, double *frac_out) {
     const long slots = 2048;
-    const double o = 0.1 * (double)g_opt_plan_item_cost;  // prologue + epilogue of an item ~ 5 chunks of work
+    // prologue + epilogue of an item, and the pass it adds by starting a new one, in chunks' worth of work
+    const double o = 0.1 * (double)g_opt_plan_item_cost * 8.0 / DLAGP_CHUNK_PIXELS;
     int full = 1;
     double frac = 1.0, best = 1e300;
     const int h_max = (int)std::max(1.0, std::min(8.0, std::floor(C / DLAGP_MAX_PASS_CHUNKS)));
@@ -432,16 +487,20 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
     const bool remainder = frac * full < 1.0 - 1e-9;
     std::vector<unsigned char> counts((size_t)groups, 1);
     int max_parts = 1;
+    // remainder items a left-over wave slot works through (shape (B)); 1 otherwise
+    const long slots_total = 2048, left = slots_total - (long)full * groups;
+    const long rest_per_slot = remainder && left > 0 ? (groups + left - 1) / left : 1;
     for (int b = 0; b < nb; ++b) {
         // cut positions of sightline b (the same for all of its groups); empty pieces are dropped
+        const int npieces = full + (remainder ? 1 : 0);
+        std::vector<int> edge(npieces + 1, (int)chunks[b]);
+        edge[0] = 0;
+        for (int j = 1; j < npieces; ++j) edge[j] = (int)std::min<long>(chunks[b], std::llround(j * frac * chunks[b]));
+        refine_cuts(g.ctxs[b]->h_slot_pos, g.ctxs[b]->sl.ntaps, edge, remainder, rest_per_slot);
         std::vector<Piece> cuts;
-        int c0 = 0;
-        for (int j = 1; j <= full + (remainder ? 1 : 0); ++j) {
-            const bool last = j == full + (remainder ? 1 : 0);
-            const int c1 = last ? (int)chunks[b] : (int)std::min<long>(chunks[b], std::llround(j * frac * chunks[b]));
-            if (c1 > c0) cuts.push_back({b, 0, (int)cuts.size(), c0, c1, remainder && last});
-            c0 = c1;
-        }
+        for (int j = 0; j < npieces; ++j)
+            if (edge[j + 1] > edge[j])
+                cuts.push_back({b, 0, (int)cuts.size(), edge[j], edge[j + 1], remainder && j == npieces - 1});
         max_parts = std::max(max_parts, (int)cuts.size());
         for (long grp = 0; grp < ngroups; ++grp) {
             counts[b * ngroups + grp] = (unsigned char)cuts.size();
@@ -504,8 +563,14 @@ static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table
             else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, true, true);
             return;
         }
-        if (patch && !(g_opt_debug & 2)) {  // line cores repaired outside the sample loop (kd == 1, uniform grid)
+        if (lls) {  // Lyman-limit systems with several absorbers per sample, or on an irregular grid: in-loop core test
+            if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 1, false, true);
+            else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, false, true);
+            return;
+        }
+        if (patch) {  // line cores repaired outside the sample loop (kd == 1, uniform grid)
             if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 1, true);
+            else if (g_opt_debug & 2) DLAGP_LAUNCH_MFMA(3, BROADEN, true, 0, true);  // with per-phase cycle stamps
             else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, true);
             return;
         }
@@ -525,7 +590,7 @@ static bool patch_serves(const LaunchGroup &g, int kd) {
 static bool mfma_path_serves(const LaunchGroup &g, int kd, bool cached = false) {
     // the MFMA kernel keeps its 16 samples' per-absorber constants in dynamic LDS
     const size_t mfma_prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * std::max(kd, 1) * (g.num_lines + 1) * sizeof(double);
-    if (g.lls_break && !cached && !patch_serves(g, kd)) return false;  // the Lyman-limit term lives in that kernel only
+    if (g.lls_break && !cached && g.num_lines != 3) return false;  // the Lyman-limit term lives in the 3-line sample loop
     return g.mfma_ok && kd >= 1 && mfma_prep_lds <= 40 * 1024 && g_opt_path != 1;
 }
 
@@ -847,7 +912,7 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     const int k_eff = k <= DLAGP_MFMA_RANK ? DLAGP_MFMA_RANK : k;
     SightlineDev &sl = ctx->sl;
     sl.n = n;
-    sl.n_pad = (n + DLAGP_CHUNK_PIXELS - 1) / DLAGP_CHUNK_PIXELS * DLAGP_CHUNK_PIXELS;
+    sl.n_pad = (n + 7) / 8 * 8;
     sl.nsteps = sl.n_pad / DLAGP_STEP_PIXELS;
     sl.k = k_eff;
     sl.lls_break = lls_break;
@@ -1470,6 +1535,14 @@ int dlagp_debug_voigt(int form, int line, int64_t n, const double *velocity, dou
 }
 
 int dlagp_debug_read(uint64_t *out, int n, int reset) {
+#ifdef DLAGP_TRACE_BUILD
+    if (n > 8) {  // diagnostic build: the per-item trace of the last launches (kernels_mfma.h)
+        std::vector<unsigned long long> trace(4 * 8192);
+        HIP_TRY(hipMemcpyFromSymbol(trace.data(), HIP_SYMBOL(DLAGP_TRACE), trace.size() * sizeof(unsigned long long)));
+        for (int i = 0; i < n && i < (int)trace.size(); ++i) out[i] = trace[i];
+        return DLAGP_OK;
+    }
+#endif
     unsigned long long host[8] = {0};
     HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(DLAGP_STAMPS), sizeof(host)));
     for (int i = 0; i < n && i < 8; ++i)

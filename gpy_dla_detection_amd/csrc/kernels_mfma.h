@@ -46,16 +46,21 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define DLAGP_MFMA_THREADS 64
 #define DLAGP_PASS_ENTRIES 64
 #define DLAGP_RAW_STRIDE 67      // doubles per sample row in LDS; odd -> conflict-free ds_read2_b64 windows
-#define DLAGP_CHUNK_PIXELS 8     // planning granule = 2 steps
-#define DLAGP_MAX_PASS_CHUNKS 7  // 56 pixels
-#define DLAGP_MAX_PASS_STEPS (2 * DLAGP_MAX_PASS_CHUNKS)
+#ifndef DLAGP_CHUNK_PIXELS
+// planning granule ("chunk") = two steps.  One step (4) was tried: the same number of passes on the bench workload,
+// 1 % slower (profiles/r02_work_decomposition.txt)
+#define DLAGP_CHUNK_PIXELS 8
+#endif
+#define DLAGP_MAX_PASS_STEPS 14  // 56 pixels
+#define DLAGP_CHUNK_STEPS (DLAGP_CHUNK_PIXELS / DLAGP_STEP_PIXELS)
+#define DLAGP_MAX_PASS_CHUNKS (DLAGP_MAX_PASS_STEPS / DLAGP_CHUNK_STEPS)
 #define DLAGP_AUX_FIELDS 8       // per-pixel record: y, mu, omega2, v, window start, 3 spare
 #define DLAGP_BUFFER_FLAGS 0x00020000  // word 3 of a raw buffer resource on gfx9-family targets
 
 struct PassDesc {
     int entry_start;  // first entry computed by phase 1
-    int chunk_begin;  // first chunk (8 slots) consumed by phase 2
-    int nchunks;      // 1..7
+    int chunk_begin;  // first chunk (DLAGP_CHUNK_PIXELS slots) consumed by phase 2
+    int nchunks;      // 1..DLAGP_MAX_PASS_CHUNKS
     int pad;
 };
 
@@ -199,6 +204,10 @@ __device__ __forceinline__ G as_global(const T *p) {
 // dlagp_debug_read.  Slots: 0 Voigt sample loop, 1 convolution, 2 weights + MFMA loop, 3 epilogue,
 // 4 whole wave, 5 wave count.  Compiled only into the STAMPS instantiations of the kernel.
 __device__ unsigned long long DLAGP_STAMPS[8];
+#ifdef DLAGP_TRACE_BUILD
+// diagnostic build only (tools/wave_timeline.py): per work item {start, end (100 MHz real time), HW_ID | XCC_ID << 32, passes}
+__device__ unsigned long long DLAGP_TRACE[4 * 8192];
+#endif
 
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
@@ -236,7 +245,7 @@ __device__ __forceinline__ void lds_wave_sync() {
 // 2^(-N log2e tau) (core form for that line, wing form for the other two); every pass copies the values
 // that fall into its window over raw[].
 //
-// LLS (PATCH kernels only): every absorber also carries the Lyman-limit continuum opacity of reference
+// LLS (3-line kernels): every absorber also carries the Lyman-limit continuum opacity of reference
 // voigt_lls.py:258-284, N / 10^17.2 (lambda_rest / 911.7641)^3 where lambda_rest = fl(lambda / (1 + z)) is not
 // above the limit.  Per sample two more constants: the scaled reciprocal that turns lambda into
 // (lambda_rest / limit) 10^(-17.2/3), and the smallest grid wavelength T with fl(T / (1 + z)) > limit, found
@@ -260,10 +269,13 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     __shared__ int patch_hit[NPAIR_MAX];       // per pass: active pairs touching the pass
     extern __shared__ double prep_lds[];
     static_assert(!PATCH || (LINES == 3 && MODE != 2), "the core patch is written for the 3-line Voigt loop");
-    static_assert(!LLS || PATCH, "the Lyman-limit term is implemented in the single-absorber kernel");
+    static_assert(!LLS || LINES == 3, "the Lyman-limit term is implemented in the 3-line sample loop");
     typedef double v4d_a16 __attribute__((ext_vector_type(4), aligned(16)));
 
     if (blockIdx.x == 0 && threadIdx.x == 0) *status = 0;  // finalize raises it
+#ifdef DLAGP_TRACE_BUILD
+    const unsigned long long trace_start = __builtin_amdgcn_s_memrealtime();
+#endif
     // Wave priorities.  The two waves of a SIMD share the FP64 pipe; an MFMA holds it for 64 cycles, a vector
     // instruction for 4, so with equal priorities the wave that is in its MFMA loop starves the one that is in a
     // vector phase, which then reaches its own MFMA loop late and leaves latencies uncovered.  Measured best
@@ -432,11 +444,24 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     v2d frag[NPAIR];
     v2d rec_ym, rec_ov;
 
+#ifndef DLAGP_PREFETCH_PASS
+#define DLAGP_PREFETCH_PASS 1
+#endif
+    // The descriptor and the wavelengths of a pass are fetched during the pass before it: read at the head of
+    // their own pass they are two dependent trips to L2 before the Voigt loop can start.
+    PassDesc pd_next = passes[pass_begin];
+    double lam_next = 0.0;
+    if (DLAGP_PREFETCH_PASS && !CACHED) {
+        int e = __builtin_amdgcn_readfirstlane(pd_next.entry_start) + lane;
+        e = e < num_entries ? e : num_entries - 1;
+        lam_next = lam_ptr[e];
+    }
     for (int pass = pass_begin; pass < pass_end; ++pass) {
-        const PassDesc pd_v = passes[pass];
+        const PassDesc pd_v = DLAGP_PREFETCH_PASS ? pd_next : passes[pass];
         const int entry_start = __builtin_amdgcn_readfirstlane(pd_v.entry_start);
-        const int step0 = __builtin_amdgcn_readfirstlane(2 * pd_v.chunk_begin);
-        const int pass_steps = __builtin_amdgcn_readfirstlane(2 * pd_v.nchunks);
+        const int step0 = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd_v.chunk_begin);
+        const int pass_steps = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd_v.nchunks);
+        if (DLAGP_PREFETCH_PASS) pd_next = passes[pass + 1 < pass_end ? pass + 1 : pass];
 
         // window start of pixel (lane) of this pass, relative to the pass; consumed after the Voigt loop
         const int my_rel = lane < pass_steps * DLAGP_STEP_PIXELS ? lane : 0;
@@ -479,9 +504,17 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
             if (stamps) t_conv += stamp_now() - t_mark;
         } else {
         // ---------------- phase 1: raw profile and convolution, absorber by absorber ----------------
-            int e = entry_start + lane;
-            e = e < num_entries ? e : num_entries - 1;
-            const double lam = lam_ptr[e];
+            double lam;
+            if (DLAGP_PREFETCH_PASS) {
+                lam = lam_next;
+                int e = __builtin_amdgcn_readfirstlane(pd_next.entry_start) + lane;  // the next pass's (or, last, this one's)
+                e = e < num_entries ? e : num_entries - 1;
+                lam_next = lam_ptr[e];
+            } else {
+                int e = entry_start + lane;
+                e = e < num_entries ? e : num_entries - 1;
+                lam = lam_ptr[e];
+            }
             for (int jd = 0; jd < kd; ++jd) {
                 if (stamps) t_mark = stamp_now();
                 if (LINES == 3) {
@@ -491,12 +524,13 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                     // The three line multipliers of the next sample are read right after their last use in this
                     // one, into the same registers (no copies); the column density, needed until the end of the
                     // body, rotates through one extra register pair.
-                    const v4d first = LLS ? (v4d)*reinterpret_cast<const v4d_a16 *>(prep_lds) : sp4[0];
+                    const double *lls_row = prep_lds + jd * 6;  // LLS rows: 6 doubles per (sample, absorber)
+                    const v4d first = LLS ? (v4d)*reinterpret_cast<const v4d_a16 *>(lls_row) : sp4[0];
                     double m0 = first.x, m1 = first.y, m2 = first.z, ncol = first.w;
                     double lls_scale = 0.0, lls_edge = 0.0;
                     if constexpr (LLS) {
-                        lls_scale = prep_lds[4];
-                        lls_edge = prep_lds[5];
+                        lls_scale = lls_row[4];
+                        lls_edge = lls_row[5];
                     }
                     const double x_offset = -DLAGP_LINES.c * DLAGP_LINES.inv_sqrt2_sigma;
                     const double c8v = vgpr_constant(DLAGP_LINES.exp2c[8]);
@@ -511,7 +545,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                         const double xs[3] = {fma(lam, m0, x_offset), fma(lam, m1, x_offset), fma(lam, m2, x_offset)};
                         __builtin_amdgcn_sched_barrier(0);
                         // the last read lands in the spare 17th row
-                        const v4d nxt = LLS ? (v4d)*reinterpret_cast<const v4d_a16 *>(prep_lds + (ss + 1) * 6) : sp4[(ss + 1) * kd];
+                        const v4d nxt = LLS ? (v4d)*reinterpret_cast<const v4d_a16 *>(lls_row + (ss + 1) * kd * 6) : sp4[(ss + 1) * kd];
                         m0 = nxt.x;
                         m1 = nxt.y;
                         m2 = nxt.z;
@@ -520,8 +554,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                         if constexpr (LLS) {
                             const double rho = lam * lls_scale;
                             tau += lam >= lls_edge ? 0.0 : rho * rho * rho;  // voigt_lls.py:276-281
-                            lls_scale = prep_lds[(ss + 1) * 6 + 4];
-                            lls_edge = prep_lds[(ss + 1) * 6 + 5];
+                            lls_scale = lls_row[(ss + 1) * kd * 6 + 4];
+                            lls_edge = lls_row[(ss + 1) * kd * 6 + 5];
                         }
                         *raw_w = fast_exp2_table(-ncol * tau, DLAGP_LINES.exp2c, c8v);  // voigt.py:309
                         raw_w += DLAGP_RAW_STRIDE;
@@ -711,17 +745,36 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     constexpr int TR_STRIDE = 17;  // [16 columns][16 samples + 1]
     // row layout of the finalize kernels (kernels_common.h): vech columns 0..223, then u at 224..
     constexpr int QBASE = 14 * DLAGP_TILE_COLS;
+#ifndef DLAGP_EPILOGUE_TILES
+#define DLAGP_EPILOGUE_TILES 6  // tiles transposed per LDS round trip (3 fit raw[], 3 more a_lds[])
+#endif
+    constexpr int TILE_LDS = 16 * TR_STRIDE;
+    static_assert(3 * TILE_LDS <= 16 * DLAGP_RAW_STRIDE && 3 * TILE_LDS <= 16 * A_STRIDE, "transpose buffers");
+    static_assert(DLAGP_EPILOGUE_TILES >= 1 && DLAGP_EPILOGUE_TILES <= 6, "at most six tiles fit the two buffers");
 #pragma unroll
-    for (int t = 0; t < DLAGP_MFMA_NT; ++t) {
+    for (int t0 = 0; t0 < DLAGP_MFMA_NT; t0 += DLAGP_EPILOGUE_TILES) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) raw[s_loc * TR_STRIDE + slot + 4 * r] = acc[t][r];
+        for (int j = 0; j < DLAGP_EPILOGUE_TILES; ++j) {
+            if (t0 + j < DLAGP_MFMA_NT) {
+                double *buf = j < 3 ? raw + j * TILE_LDS : a_lds + (j - 3) * TILE_LDS;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) buf[s_loc * TR_STRIDE + slot + 4 * r] = acc[t0 + j][r];
+            }
+        }
         lds_wave_sync();
-        const int col0 = t < DLAGP_MFMA_NTW ? t * DLAGP_TILE_COLS : QBASE;
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const int col = cc * 4 + slot;  // lane -> (sample = s_loc, column = col)
-            const double val = raw[col * TR_STRIDE + s_loc];
-            if (s_loc < rows_left) base[(col0 + col) * 16 + s_loc] = val;  // 512 contiguous bytes
+        for (int j = 0; j < DLAGP_EPILOGUE_TILES; ++j) {
+            const int t = t0 + j;
+            if (t < DLAGP_MFMA_NT) {
+                const double *buf = j < 3 ? raw + j * TILE_LDS : a_lds + (j - 3) * TILE_LDS;
+                const int col0 = t < DLAGP_MFMA_NTW ? t * DLAGP_TILE_COLS : QBASE;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int col = cc * 4 + slot;  // lane -> (sample = s_loc, column = col)
+                    const double val = buf[col * TR_STRIDE + s_loc];
+                    if (s_loc < rows_left) base[(col0 + col) * 16 + s_loc] = val;  // 512 contiguous bytes
+                }
+            }
         }
         lds_wave_sync();
     }
@@ -744,6 +797,18 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         base[(SBASE + 1) * 16 + s_loc] = logd;
         base[(SBASE + 2) * 16 + s_loc] = split == 0 ? sl.n * DLAGP_LOG_2PI : 0.0;
     }
+#ifdef DLAGP_TRACE_BUILD
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        unsigned long long *t = DLAGP_TRACE + 4 * blockIdx.x;
+        t[0] = trace_start;
+        t[1] = __builtin_amdgcn_s_memrealtime();
+        t[2] = hw_id | ((unsigned long long)xcc_id << 32);
+        t[3] = (unsigned long long)(pass_end - pass_begin) | ((unsigned long long)split << 32);
+    }
+#endif
     if (stamps && lane == 0) {
         const unsigned long long now = stamp_now();
         atomicAdd(&DLAGP_STAMPS[0], t_voigt);

@@ -1025,8 +1025,15 @@ def test_lls_profile_matches_reference_golden_and_oracle():
         z2 = np.stack([g["z"][:6], g["z"][6:]], axis=1)
         n2 = 10.0 ** np.stack([g["log_nhi"][:6], g["log_nhi"][6:]], axis=1)
         got = dev.eval(z2, n2)
+        from gpy_dla_detection_amd.sightline import get_option
+
+        assert get_option("last_launch_path") == 2  # several Lyman-limit absorbers per sample: MFMA kernel too
         ref = np.array([R.sample_log_likelihood_k_dlas(st, z2[i], n2[i]) for i in range(6)])
         np.testing.assert_allclose(got, ref, rtol=RTOL_LL)
+        z3 = np.stack([g["z"][:4], g["z"][4:8], g["z"][8:12]], axis=1)
+        n3 = 10.0 ** np.stack([g["log_nhi"][:4], g["log_nhi"][4:8], g["log_nhi"][8:12]], axis=1)
+        ref3 = np.array([R.sample_log_likelihood_k_dlas(st, z3[i], n3[i]) for i in range(4)])
+        np.testing.assert_allclose(dev.eval(z3, n3), ref3, rtol=RTOL_LL)
         plain = DeviceSightline(y, mu, M, omega2, v, wl, keep, broadening=broadening).eval(z2, n2)
         assert np.max(np.abs(plain - got)) > 1.0  # the break matters on this grid
         # one absorber per sample on this log-uniform grid: the MFMA kernel with the continuum term
