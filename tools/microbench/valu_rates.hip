@@ -56,7 +56,12 @@ __global__ __launch_bounds__(512) void rate_kernel(int iters, double seed, doubl
     for (int i = 0; i < 16; ++i) s += v[i] + w[i];
     for (int i = 0; i < 8; ++i) s += acc[i][0];
     sink[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+    // every wave reports its own start and end: with two waves per SIMD the older wave can run its MFMAs back to back
+    // while the other one waits, so one wave's elapsed time says nothing about the SIMD's time per instruction
+    if ((threadIdx.x & 63) == 0) {
+        cycles[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 2] = t0;
+        cycles[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 2 + 1] = t1;
+    }
 }
 
 template <int OP>
@@ -73,22 +78,31 @@ static void run(const char *name, double *sink, unsigned long long *cyc, int thr
     CHECK(hipEventSynchronize(e1));
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
-    unsigned long long h[256];
+    static unsigned long long h[256 * 8 * 2];
     CHECK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
-    double mean = 0;
-    for (int i = 0; i < 256; ++i) mean += (double)h[i];
-    mean /= 256;
-    const double per_wave_instr = mean / (iters * 256.0);           // shader-clock ticks per instruction of one wave
-    const double waves_per_simd = threads / 256.0;                   // 4 SIMDs per CU
-    printf("%-28s %d waves/SIMD: %.3f ms, %.2f clk per wave-instruction, %.2f clk of SIMD time each\n", name,
-           (int)waves_per_simd, ms, per_wave_instr, per_wave_instr / waves_per_simd);
+    const int waves = threads / 64;
+    double mean_wave = 0, mean_span = 0;
+    for (int b = 0; b < 256; ++b) {
+        unsigned long long first = ~0ull, last = 0;
+        for (int w = 0; w < waves; ++w) {
+            const unsigned long long t0 = h[(b * 8 + w) * 2], t1 = h[(b * 8 + w) * 2 + 1];
+            mean_wave += (double)(t1 - t0) / (256.0 * waves);
+            first = t0 < first ? t0 : first;
+            last = t1 > last ? t1 : last;
+        }
+        mean_span += (double)(last - first) / 256.0;
+    }
+    const double waves_per_simd = threads / 256.0;  // 4 SIMDs per CU
+    // SIMD time per instruction: the workgroup's span (first start to last end) over the instructions one SIMD issued
+    printf("%-28s %d waves/SIMD: %.3f ms, %.2f clk elapsed per instruction of a wave (mean over waves), %.2f clk of SIMD time each\n",
+           name, (int)waves_per_simd, ms, mean_wave / (iters * 256.0), mean_span / (iters * 256.0 * waves_per_simd));
 }
 
 int main() {
     double *sink;
     unsigned long long *cyc;
     CHECK(hipMalloc(&sink, 256 * 512 * sizeof(double)));
-    CHECK(hipMalloc(&cyc, 256 * sizeof(unsigned long long)));
+    CHECK(hipMalloc(&cyc, 256 * 8 * 2 * sizeof(unsigned long long)));
     // warm the clocks
     for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((rate_kernel<0>), dim3(256), dim3(512), 0, 0, 200, 1.25, sink, cyc);
     CHECK(hipDeviceSynchronize());
