@@ -366,7 +366,7 @@ static void plan_passes(const std::vector<int> &slot_pos, int ntaps, int c0, int
 // at a different position and came out 10 % slower (profiles/r02_work_decomposition.txt).  Two shapes of cut are
 // priced with a simple model (time of the busiest wave slot, in chunks; `o` = fixed cost of an item) and the
 // cheaper one is taken:
-//   (A) h equal pieces per group, h = 1..8:            ceil(groups h / 2048) (C / h + o)
+//   (A) h equal pieces per group, h = 1..8:            ceil(groups h / 2048) (C / h + o)   [+ finalisation, ~ groups h]
 //   (B) f = floor(2048 / groups) full pieces of F chunks plus a remainder piece R = C - f F; the 2048 - f groups
 //       slots left over work through the remainder pieces, m = ceil(groups / slots left) each:
 //                                                        F + o = m (R + o)
@@ -434,12 +434,15 @@ static void choose_cut(long groups, double C, int64_t forced, int *full_out, dou
     const long slots = 2048;
     // prologue + epilogue of an item, and the pass it adds by starting a new one, in chunks' worth of work
     const double o = 0.1 * (double)g_opt_plan_item_cost * 8.0 / DLAGP_CHUNK_PIXELS;
+    // every piece of a block is one more set of partial sums the finalisation reads: ~25 ns per (block, piece) in a
+    // large launch, in units of a wave slot's time per chunk (4.9 us per 8 slots)
+    const double finalize_per_piece = 0.005 * 8.0 / DLAGP_CHUNK_PIXELS;
     int full = 1;
     double frac = 1.0, best = 1e300;
     const int h_max = (int)std::max(1.0, std::min(8.0, std::floor(C / DLAGP_MAX_PASS_CHUNKS)));
     for (int h = 1; h <= h_max; ++h) {
         if (forced > 0 && h != std::min<int64_t>(forced, h_max)) continue;
-        const double cost = (double)((groups * h + slots - 1) / slots) * (C / h + o);
+        const double cost = (double)((groups * h + slots - 1) / slots) * (C / h + o) + finalize_per_piece * groups * h;
         if (cost < best) {
             best = cost;
             full = h;
@@ -451,7 +454,7 @@ static void choose_cut(long groups, double C, int64_t forced, int *full_out, dou
         const long m = (groups + (slots - f * groups) - 1) / (slots - f * groups);
         const double F = (m * (C + o) - o) / (1.0 + (double)m * f);
         const double R = C - f * F;
-        if (R >= DLAGP_MAX_PASS_CHUNKS && F + o < best) {
+        if (R >= DLAGP_MAX_PASS_CHUNKS && F + o + finalize_per_piece * groups * (f + 1) < best) {
             full = (int)f;
             frac = F / C;
         }

@@ -26,6 +26,10 @@ def prepare_data(params: Parameters, X: np.ndarray, Y: np.ndarray, noise_varianc
     attributes `set_data` leaves on the instance, by name.
     """
     p = params
+    if p.width != 3:
+        # voigt.py:211-224: `width` = 3 is the half-width of the 7-tap SDSS instrument profile the device kernels
+        # are written for (DLAGP_NUM_TAPS); the reference's own profile table has no other width either
+        raise ValueError("Parameters.width = {} is not supported: the instrument profile has 2 * 3 + 1 taps".format(p.width))
     x, y, v = X, Y, noise_variance
     out = {"pixel_mask": pixel_mask}
     if normalize:
@@ -268,7 +272,9 @@ class NullGP:
         log N(y; mu, M M' + diag(d)) through the Woodbury identity, on the GPU.
 
         `scipy_lapack` is accepted for signature compatibility; both reference branches
-        compute the same quantity and there is a single device implementation.
+        compute the same quantity and there is a single device implementation.  Ranks up to
+        DLAGP_MAX_RANK = 64 (include/dlagp.h; the reference's learned models have k = 20); a larger k raises
+        ValueError.
         """
         return _sl.log_mvnpdf_low_rank(y, mu, M, d)
 

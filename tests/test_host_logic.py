@@ -412,3 +412,38 @@ def test_write_results_hdf5_branch_with_a_stand_in_h5py(tmp_path, monkeypatch):
     np.testing.assert_array_equal(created["base_sample_inds"], g["base_sample_inds"])
     # the only dataset beyond the reference's list: the sub-DLA sample likelihoods the driver keeps in memory (:124)
     assert set(created) - set(reference_datasets) == {"sample_log_likelihoods_lls"}
+
+
+def test_work_decomposition_model():
+    """
+    dlagp_plan_cut (pure host arithmetic of the MFMA path's planner): how the blocks of 16 samples are cut into
+    work items for the 2048 wave slots of the chip.
+    """
+    import ctypes
+
+    from gpy_dla_detection_amd import _lib
+
+    lib = _lib.load()
+
+    def cut(groups, chunks, forced=0):
+        full, frac = ctypes.c_int(), ctypes.c_double()
+        _lib.check(lib.dlagp_plan_cut(groups, float(chunks), forced, ctypes.byref(full), ctypes.byref(frac)))
+        return full.value, frac.value
+
+    # configs[1]: 625 blocks x 375 chunks -- three full pieces and a remainder that fills the 173 slots left over
+    full, frac = cut(625, 375)
+    assert full == 3 and 0.30 < frac < 0.32 and 375 * (1 - 3 * frac) >= 7
+    # busiest slot: a full piece, against 125 chunks with three equal pieces
+    assert frac * 375 < 118
+    # large launches: one item per block; forced equal pieces
+    assert cut(64 * 625, 375) == (1, 1.0)
+    assert cut(625, 375, forced=3) == (3, 1.0 / 3)
+    assert cut(625, 375, forced=1000)[0] == 8          # never more than 8 pieces, never less than a pass each
+    assert cut(3, 9) == (1, 1.0)
+    # every cut covers the block: full * frac <= 1
+    for groups in (1, 7, 300, 625, 1250, 1875, 2047, 2048, 2500, 5000, 10000):
+        for chunks in (1, 9, 60, 140, 375, 1000):
+            full, frac = cut(groups, chunks)
+            assert full >= 1 and 0.0 < frac <= 1.0 and full * frac <= 1.0 + 1e-12, (groups, chunks, full, frac)
+    with pytest.raises(ValueError):
+        cut(0, 10)
