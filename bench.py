@@ -136,9 +136,9 @@ def cpu_baseline(sight, evals, cpu_seconds: float = 18.0, single_seconds: float 
         while elapsed * workers < cpu_seconds:
             chunks = []
             for w in range(workers):
-                take = [evals[(cursor + w * 32 + i) % len(evals)] for i in range(32)]
+                take = [evals[(cursor + w * 128 + i) % len(evals)] for i in range(128)]
                 chunks.append(([t[0] for t in take], [t[1] for t in take]))
-            cursor += 32 * workers
+            cursor += 128 * workers
             t0 = time.perf_counter()
             done += sum(pool.map(_cpu_worker_eval, chunks))
             elapsed += time.perf_counter() - t0

@@ -483,10 +483,12 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
     double frac = 1.0;
     choose_cut(groups, mean_chunks, g_opt_pixel_splits, &full, &frac);
     struct Piece {
-        int b, group, part, c0, c1;
+        int b, group, part, pass_begin, pass_end;
         bool rest;
     };
     std::vector<Piece> pieces;
+    pieces.reserve((size_t)groups * (full + 1));
+    std::vector<PassDesc> passes;
     const bool remainder = frac * full < 1.0 - 1e-9;
     std::vector<unsigned char> counts((size_t)groups, 1);
     int max_parts = 1;
@@ -502,8 +504,11 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
         refine_cuts(g.ctxs[b]->h_slot_pos, g.ctxs[b]->sl.ntaps, edge, remainder, rest_per_slot);
         std::vector<Piece> cuts;
         for (int j = 0; j < npieces; ++j)
-            if (edge[j + 1] > edge[j])
-                cuts.push_back({b, 0, (int)cuts.size(), edge[j], edge[j + 1], remainder && j == npieces - 1});
+            if (edge[j + 1] > edge[j]) {
+                const int begin = (int)passes.size();  // the pass list of a piece is shared by all groups
+                plan_passes(g.ctxs[b]->h_slot_pos, g.ctxs[b]->sl.ntaps, edge[j], edge[j + 1], passes);
+                cuts.push_back({b, 0, (int)cuts.size(), begin, (int)passes.size(), remainder && j == npieces - 1});
+            }
         max_parts = std::max(max_parts, (int)cuts.size());
         for (long grp = 0; grp < ngroups; ++grp) {
             counts[b * ngroups + grp] = (unsigned char)cuts.size();
@@ -516,20 +521,9 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
     // dispatch order: the full pieces in (sightline, group, piece) order, then the remainders
     const bool rest_first = g_opt_plan_rest_first != 0;
     if (remainder) std::stable_partition(pieces.begin(), pieces.end(), [=](const Piece &x) { return x.rest == rest_first; });
-    std::vector<PassDesc> passes;
-    std::map<std::tuple<int, int, int>, std::pair<int, int>> ranges;  // (b, c0, c1) -> pass range
     std::vector<WorkItem> items;
     items.reserve(pieces.size());
-    for (const Piece &pc : pieces) {
-        const auto rkey = std::make_tuple(pc.b, pc.c0, pc.c1);
-        auto rit = ranges.find(rkey);
-        if (rit == ranges.end()) {
-            const int begin = (int)passes.size();
-            plan_passes(g.ctxs[pc.b]->h_slot_pos, g.ctxs[pc.b]->sl.ntaps, pc.c0, pc.c1, passes);
-            rit = ranges.emplace(rkey, std::make_pair(begin, (int)passes.size())).first;
-        }
-        items.push_back(WorkItem{pc.b, pc.group, pc.part, rit->second.first, rit->second.second, 0, 0, 0});
-    }
+    for (const Piece &pc : pieces) items.push_back(WorkItem{pc.b, pc.group, pc.part, pc.pass_begin, pc.pass_end, 0, 0, 0});
     std::unique_ptr<LaunchPlan> plan(new LaunchPlan());
     int rc = plan->passes.reserve(std::max<size_t>(1, passes.size()) * sizeof(PassDesc));
     if (!rc) rc = plan->items.reserve(std::max<size_t>(1, items.size()) * sizeof(WorkItem));

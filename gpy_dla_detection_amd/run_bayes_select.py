@@ -206,12 +206,12 @@ def process_qso(
             local["p_no_dlas"][i] = 1 - local["p_dlas"][i]
         engine.release(batch, sightlines)
 
-    # A worker thread prepares batch i + 1 (NumPy index logic, context creation on its own HIP stream) and
+    # Two worker threads: one prepares batch i + 1 (NumPy index logic, context creation on its own HIP stream) and
     # finishes batch i - 1 (priors, posteriors, MAP, freeing contexts) while this thread is inside the sweeps of
     # batch i (ctypes releases the GIL): the device never waits for the host.  `prefetch=False` runs everything in
     # this thread, in order.
     bounds = [(start, min(start + batch_size, hi)) for start in range(lo, hi, batch_size)]
-    pool = ThreadPoolExecutor(max_workers=1) if prefetch and len(bounds) > 1 else None
+    pool = ThreadPoolExecutor(max_workers=2) if prefetch and len(bounds) > 1 else None
     pending = pool.submit(prepare, *bounds[0]) if pool else None
     finishing = []
     try:

@@ -1,0 +1,19 @@
+#!/bin/bash
+# On the GPU box: everything profiles/rNN_* is made of, into gpurun_out/collect_<tag>/.  usage: tools/collect_profiles.sh r02
+tag=${1:-run}
+out=gpurun_out/collect_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python3 bench.py > $out/bench.json 2> $out/bench.err
+for c in 3 4 5; do python3 bench.py --config $c > $out/bench_config$c.json 2>> $out/bench.err; done
+python3 bench.py --strong --no-cpu-baseline > $out/bench_strong_n1.json 2>> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2>&1
+cp $out/prof/*/*_kernel_stats.csv $out/kernel_stats.csv
+for c in 3 5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_c$c -- python3 bench.py --no-cpu-baseline --config $c --steps 3 > $out/bench_config${c}_under_rocprof.json 2>&1
+  cp $out/prof_c$c/*/*_kernel_stats.csv $out/kernel_stats_config$c.csv
+done
+python3 tools/measure_configs.py 2>/dev/null | tail -1 > $out/other_configs.json
+python3 tools/measure_catalogue.py 2>/dev/null | tail -1 > $out/catalogue_pipeline.json
+rm -rf $out/prof $out/prof_c3 $out/prof_c5
+ls -la $out
