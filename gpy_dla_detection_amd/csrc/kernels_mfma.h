@@ -444,6 +444,9 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     v2d frag[NPAIR];
     v2d rec_ym, rec_ov;
 
+#ifndef DLAGP_CACHE_STORE_NT
+#define DLAGP_CACHE_STORE_NT 1
+#endif
 #ifndef DLAGP_PREFETCH_PASS
 #define DLAGP_PREFETCH_PASS 1
 #endif
@@ -487,7 +490,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
 #pragma unroll
             for (int ss = 0; ss < 16; ++ss) {
                 const long rel = ss < last ? ss : last;
-                own[ss] = run_col[rel * src.cache_stride];
+                // the running product is read once: streamed past the L2 that serves the sightline's operand
+                own[ss] = DLAGP_CACHE_STORE_NT ? __builtin_nontemporal_load(run_col + rel * src.cache_stride) : run_col[rel * src.cache_stride];
                 other[ss] = cache_col[(row0 + row_lds[ss]) * src.cache_stride];
             }
             __attribute__((address_space(1))) double *out_col =
@@ -497,7 +501,10 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 const double prod = own[ss] * other[ss];
                 if (lane < npx) {
                     a_lds[ss * A_STRIDE + lane] = prod;
-                    if (src.cache_write && ss <= last) out_col[ss * src.cache_stride] = prod;
+                    if (src.cache_write && ss <= last) {
+                        if (DLAGP_CACHE_STORE_NT) __builtin_nontemporal_store(prod, out_col + ss * src.cache_stride);
+                        else out_col[ss * src.cache_stride] = prod;
+                    }
                 }
             }
             lds_wave_sync();
@@ -651,8 +658,13 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                     (__attribute__((address_space(1))) double *)src.cache +
                     ((long)b * S + sample0) * src.cache_stride + (long)step0 * DLAGP_STEP_PIXELS + lane;
                 const long valid = S - sample0 < 16 ? S - sample0 : 16;
+                // streaming stores: 24 KB per sample written once and read a level later -- kept out of the L2 that
+                // serves the sightline's operand
                 if (lane < npx)
-                    for (int ss = 0; ss < valid; ++ss) dst[ss * src.cache_stride] = a_lds[ss * A_STRIDE + lane];
+                    for (int ss = 0; ss < valid; ++ss) {
+                        if (DLAGP_CACHE_STORE_NT) __builtin_nontemporal_store(a_lds[ss * A_STRIDE + lane], dst + ss * src.cache_stride);
+                        else dst[ss * src.cache_stride] = a_lds[ss * A_STRIDE + lane];
+                    }
             }
         }
         if (stamps) t_mark = stamp_now();
