@@ -67,6 +67,7 @@ static int64_t g_last_launch_path = 0;    // 1 generic kernel, 2 MFMA kernel
 static int64_t g_last_launch_items = 0;   // work items (waves) of the last MFMA launch
 static int64_t g_last_launch_parts = 0;   // most pieces a block of 16 samples was cut into
 static int64_t g_last_sweep_cached = 0;   // the last multi-level sweep used the profile cache
+static int64_t g_last_launch_patch = 0;   // core handling of the last MFMA launch (patch_mode: 0 in loop, 1, 2)
 
 struct EventPair {
     hipEvent_t start, stop;
@@ -548,27 +549,38 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
                        plan->passes.as<const PassDesc>(), plan->items.as<const WorkItem>(), nb, S, kd, src, part, \
                        status, (int)g_opt_debug)
 
+// how the line cores are handled (kernels_mfma.h): 0 tested for inside the sample loop; 1 one absorber per sample,
+// repaired once per wave; 2 several absorbers per sample, repaired pass by pass.  1 and 2 need three lines and a
+// log-uniform wavelength grid.
+static int patch_mode(const LaunchGroup &g, int kd) {
+    if (g.num_lines != 3 || !g.grid_uniform || g_opt_core_patch == 0 || kd < 1) return 0;
+    return kd == 1 ? 1 : 2;
+}
+
 template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, const LaunchPlan *plan, int nb,
                         long S, int kd, int num_lines, const SampleSource &src, double *part, int *status,
-                        bool patch, bool lls) {
-    // 16 samples + one spare row that the look-ahead of the sample loop may read
-    const size_t prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * kd * (lls ? 6 : (LINES > 0 ? LINES : num_lines) + 1) * sizeof(double);
+                        int patch, bool lls) {
+    // 16 samples + one spare row that the look-ahead of the sample loop may read; PATCH 2: 3 ints per (sample, absorber)
+    const size_t prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * kd * (lls ? 6 : (LINES > 0 ? LINES : num_lines) + 1) * sizeof(double) +
+                            (patch == 2 ? (size_t)DLAGP_MFMA_GROUP * kd * 3 * sizeof(int) : 0);
     if constexpr (LINES == 3) {
-        if (patch && lls) {  // Lyman-limit systems: single-absorber kernel with the continuum term
-            if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 1, true, true);
-            else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, true, true);
+        if (lls) {  // Lyman-limit systems (voigt_lls.py): the continuum term rides in the 3-line sample loop
+            if (patch == 1 && src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 1, 1, true);
+            else if (patch == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, 1, true);
+            else if (patch == 2) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, 2, true);
+            else if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 1, 0, true);
+            else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, 0, true);
             return;
         }
-        if (lls) {  // Lyman-limit systems with several absorbers per sample, or on an irregular grid: in-loop core test
-            if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 1, false, true);
-            else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, false, true);
+        if (patch == 1) {  // line cores repaired outside the sample loop (kd == 1, uniform grid)
+            if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 1, 1);
+            else if (g_opt_debug & 2) DLAGP_LAUNCH_MFMA(3, BROADEN, true, 0, 1);  // with per-phase cycle stamps
+            else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, 1);
             return;
         }
-        if (patch) {  // line cores repaired outside the sample loop (kd == 1, uniform grid)
-            if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 1, true);
-            else if (g_opt_debug & 2) DLAGP_LAUNCH_MFMA(3, BROADEN, true, 0, true);  // with per-phase cycle stamps
-            else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, true);
+        if (patch == 2 && !(g_opt_debug & 2)) {  // several absorbers per sample, cores repaired pass by pass
+            DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, 2);
             return;
         }
     }
@@ -577,16 +589,11 @@ static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table
     else DLAGP_LAUNCH_MFMA(LINES, BROADEN, false);
 }
 
-// the single-absorber kernel with the cores repaired outside the sample loop (and, with it, the LLS term)
-static bool patch_serves(const LaunchGroup &g, int kd) {
-    return g.num_lines == 3 && kd == 1 && g.grid_uniform && g_opt_core_patch != 0;
-}
-
 // whether a launch with kd absorbers per sample runs the MFMA kernel (else the generic one); `cached`:
 // the launch multiplies cached profiles (levels > 1 of a sweep) and evaluates no Voigt profile itself
 static bool mfma_path_serves(const LaunchGroup &g, int kd, bool cached = false) {
     // the MFMA kernel keeps its 16 samples' per-absorber constants in dynamic LDS
-    const size_t mfma_prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * std::max(kd, 1) * (g.num_lines + 1) * sizeof(double);
+    const size_t mfma_prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * std::max(kd, 1) * ((g.lls_break ? 5 : g.num_lines) + 1 + 2) * sizeof(double);
     if (g.lls_break && !cached && g.num_lines != 3) return false;  // the Lyman-limit term lives in the 3-line sample loop
     return g.mfma_ok && kd >= 1 && mfma_prep_lds <= 40 * 1024 && g_opt_path != 1;
 }
@@ -638,7 +645,8 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
         g_last_launch_parts = plan->max_parts;
         dim3 grid((unsigned)plan->nitems);
         const bool lines3 = g.num_lines == 3;
-        const bool patch = patch_serves(g, kd);
+        const int patch = src.cache_mode == 2 ? 0 : patch_mode(g, kd);
+        g_last_launch_patch = patch;
         const bool lls = g.lls_break;
         double *part = ws.part.as<double>();
         int *status = ws.status.as<int>();
@@ -1598,6 +1606,7 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "last_launch_items")) *value = g_last_launch_items;
     else if (!strcmp(name, "last_launch_parts")) *value = g_last_launch_parts;
     else if (!strcmp(name, "last_sweep_cached")) *value = g_last_sweep_cached;
+    else if (!strcmp(name, "last_launch_patch")) *value = g_last_launch_patch;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 }

@@ -251,7 +251,7 @@ __device__ __forceinline__ void lds_wave_sync() {
 // (lambda_rest / limit) 10^(-17.2/3), and the smallest grid wavelength T with fl(T / (1 + z)) > limit, found
 // by stepping ulps around limit (1 + z), so that the in-loop test `lambda >= T` reproduces the reference's
 // `rest_wavelengths > lambda_Lyman_limit` (:280) exactly without a division per entry.
-template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, bool PATCH = false, bool LLS = false>
+template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, int PATCH = 0, bool LLS = false>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *__restrict__ passes,
     const WorkItem *__restrict__ items, int nb, long S, int kd,
@@ -261,14 +261,15 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     __shared__ double raw[16 * DLAGP_RAW_STRIDE];
     __shared__ double a_lds[16 * A_STRIDE];
     __shared__ int pos_lds[64];
-    constexpr int NPAIR_MAX = PATCH ? 48 : 1;  // (sample, line) pairs of a wave
+    constexpr int NPAIR_MAX = PATCH ? 48 : 1;  // (sample, line) pairs of a wave and absorber
     constexpr int NCAND = 7;                   // candidate entries per pair, see below
-    __shared__ double patch_factor[NPAIR_MAX * NCAND];  // exact profile value of a core entry, -1 elsewhere
+    __shared__ double patch_factor[(PATCH == 1 ? NPAIR_MAX : 1) * NCAND];  // exact profile value of a core entry, -1 elsewhere
     __shared__ int patch_first[NPAIR_MAX];     // first candidate entry of an active pair
     __shared__ int patch_sample[NPAIR_MAX];    // its sample (0..15)
     __shared__ int patch_hit[NPAIR_MAX];       // per pass: active pairs touching the pass
     extern __shared__ double prep_lds[];
     static_assert(!PATCH || (LINES == 3 && MODE != 2), "the core patch is written for the 3-line Voigt loop");
+    static_assert(PATCH != 2 || MODE == 0, "several absorbers per sample never meet the profile cache's level 1");
     static_assert(!LLS || LINES == 3, "the Lyman-limit term is implemented in the 3-line sample loop");
     typedef double v4d_a16 __attribute__((ext_vector_type(4), aligned(16)));
 
@@ -352,7 +353,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         // a NaN redshift makes every line NaN, np.nansum drops them all and the profile is 1 (voigt.py:309):
         // without the in-loop NaN test that is a zero column density
         // (and a finite multiplier, so that the optical depth the zero multiplies is finite)
-        if (PATCH && !(zj == zj)) value = 0.0;
+        // (with the Lyman-limit term the reference's profile is NaN instead: rest wavelength NaN, voigt_lls.py:273-281)
+        if (PATCH && !(zj == zj)) value = LLS && which == L ? __builtin_nan("") : 0.0;
         prep_lds[i] = value;
     }
 
@@ -361,7 +363,20 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
 
     // ---------------- core patch factors of this wave (PATCH) ----------------
     int npatch = 0;  // active (sample, line) pairs, wave-uniform
-    if constexpr (PATCH) {
+    // PATCH == 2 (several absorbers per sample): the first candidate entry of every (sample, absorber, line), behind
+    // the per-sample constants in dynamic LDS; the cores are repaired pass by pass, absorber by absorber (below)
+    int *centre_lds = reinterpret_cast<int *>(prep_lds + (DLAGP_MFMA_GROUP + 1) * kd * prep_stride);
+    if constexpr (PATCH == 2) {
+        lds_wave_sync();  // per-sample constants visible
+        const double x_offset = -DLAGP_LINES.c * DLAGP_LINES.inv_sqrt2_sigma;
+        for (int i = lane; i < 16 * kd * 3; i += 64) {
+            const double m = prep_lds[(i / 3) * prep_stride + i % 3];
+            const double e_c = (log10(-x_offset / m) - sl.grid_log0) * sl.grid_inv_dlog;
+            centre_lds[i] = e_c > -16.0 && e_c < 1.0e9 ? (int)floor(e_c - 3.5) + 1 : -(1 << 30);
+        }
+        lds_wave_sync();
+    }
+    if constexpr (PATCH == 1) {
         lds_wave_sync();  // per-sample constants visible
         const double x_offset = -DLAGP_LINES.c * DLAGP_LINES.inv_sqrt2_sigma;
         const int first_entry = passes[pass_begin].entry_start;
@@ -557,7 +572,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                         m1 = nxt.y;
                         m2 = nxt.z;
                         __builtin_amdgcn_sched_barrier(0);
-                        double tau = optical_depth<LINES, !PATCH>(lam, nullptr, 3, w3v, xs);
+                        double tau = optical_depth<LINES, PATCH == 0>(lam, nullptr, 3, w3v, xs);
                         if constexpr (LLS) {
                             const double rho = lam * lls_scale;
                             tau += lam >= lls_edge ? 0.0 : rho * rho * rho;  // voigt_lls.py:276-281
@@ -583,7 +598,50 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 }
                 if (jd == 0) pos_lds[lane] = (int)my_pos_f - entry_start;
                 lds_wave_sync();
-                if constexpr (PATCH) {
+                if constexpr (PATCH == 2) {
+                    // line cores of absorber jd inside this pass: lane p < 48 owns (sample p / 3, line p % 3); the
+                    // few pairs whose 7 candidate entries touch the pass get their core entries' exact profile
+                    // value -- core form for that line, wing form for the other two -- written over raw[]
+                    const int mine = lane < 48 ? centre_lds[((lane / 3) * kd + jd) * 3 + lane % 3] : -(1 << 30);
+                    const bool hit = mine + NCAND - 1 >= entry_start && mine < entry_start + DLAGP_PASS_ENTRIES;
+                    const unsigned long long hmask = __builtin_amdgcn_ballot_w64(hit);
+                    if (hmask) {
+                        if (hit) patch_hit[__builtin_popcountll(hmask & ((1ull << lane) - 1))] = lane;
+                        lds_wave_sync();
+                        const double x_offset = -DLAGP_LINES.c * DLAGP_LINES.inv_sqrt2_sigma;
+                        const int nitems = __builtin_popcountll(hmask) * NCAND;
+                        for (int base = 0; base < nitems; base += 64) {
+                            const int item = base + lane;
+                            const bool live = item < nitems;
+                            const int pair = patch_hit[live ? item / NCAND : 0], j = item % NCAND;
+                            const int ss = pair / 3, l = pair % 3;
+                            const int rel = centre_lds[(ss * kd + jd) * 3 + l] + j - entry_start;
+                            const bool inside = live && rel >= 0 && rel < DLAGP_PASS_ENTRIES;
+                            const double lam_e = __shfl(lam, inside ? rel : 0);  // lane rel holds this entry's wavelength
+                            if (inside && entry_start + rel < num_entries) {
+                                const double *mrow = prep_lds + (ss * kd + jd) * prep_stride;
+                                const double x = fma(lam_e, mrow[l], x_offset);  // the loop's expression, bit for bit
+                                if (!(x * x >= DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT)) {
+                                    const double core = DLAGP_LINES.k_core[l] * core_taylor(x, DLAGP_LINES.y[l]);
+                                    double tau = core == core ? core : 0.0;  // a NaN term is dropped (np.nansum, voigt.py:309)
+#pragma unroll
+                                    for (int k = 0; k < 3; ++k) {
+                                        const double xk = fma(lam_e, mrow[k], x_offset);
+                                        const double wing = wing_term(xk * xk, DLAGP_LINES.wing[k]);
+                                        if (k != l) tau += wing;  // Lyman lines are > 40 A apart: never two cores at one entry
+                                    }
+                                    if constexpr (LLS) {
+                                        const double rho = lam_e * mrow[4];
+                                        if (!(lam_e >= mrow[5])) tau += rho * rho * rho;  // voigt_lls.py:276-281
+                                    }
+                                    raw[ss * DLAGP_RAW_STRIDE + rel] = fast_exp2(-mrow[3] * tau);
+                                }
+                            }
+                        }
+                        lds_wave_sync();
+                    }
+                }
+                if constexpr (PATCH == 1) {
                     // copy the core values that fall into this pass's 64 entries over raw[] (see the kernel header)
                     const int mine = patch_first[lane < npatch ? lane : 0];
                     const bool hit = lane < npatch && mine + NCAND - 1 >= entry_start && mine < entry_start + DLAGP_PASS_ENTRIES;
@@ -613,7 +671,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 // serialising them one ds_read + wait at a time), then the arithmetic runs on them.
                 const double *raw_row = raw + s_loc * DLAGP_RAW_STRIDE;
                 double *a_dst = &a_lds[s_loc * A_STRIDE + slot];
-                constexpr int CONV_GROUP = PATCH && MODE == 0 ? 7 : 4;  // reads of that many steps in flight; the single-absorber kernel has the registers for 7
+                // (7 with several absorbers per sample -- their running product is one more register pair per step -- spills)
+                constexpr int CONV_GROUP = PATCH == 1 && MODE == 0 ? 7 : 4;  // reads of that many steps in flight; the single-absorber kernel has the registers for 7
                 constexpr int NW = BROADEN ? DLAGP_NUM_TAPS : 1;
 #pragma unroll
                 for (int g0 = 0; g0 < DLAGP_MAX_PASS_STEPS; g0 += CONV_GROUP) {
@@ -626,7 +685,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                             const double *win = raw_row + pos_lds[st * DLAGP_STEP_PIXELS + slot];
 #pragma unroll
                             for (int t = 0; t < NW; ++t) wv[u][t] = win[t];
-                            if (!PATCH) prev[u] = a_dst[st * DLAGP_STEP_PIXELS];  // PATCH implies one absorber
+                            if (PATCH != 1) prev[u] = a_dst[st * DLAGP_STEP_PIXELS];  // PATCH == 1 implies one absorber
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -642,7 +701,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                                 conv = fma(wv[u][2] + wv[u][4], tap[2], conv);
                                 conv = fma(wv[u][3], tap[3], conv);
                             }
-                            if constexpr (PATCH) a_dst[st * DLAGP_STEP_PIXELS] = conv;
+                            if constexpr (PATCH == 1) a_dst[st * DLAGP_STEP_PIXELS] = conv;
                             else a_dst[st * DLAGP_STEP_PIXELS] = jd == 0 ? conv : prev[u] * conv;
                         }
                     }

@@ -268,7 +268,8 @@ int dlagp_set_option(const char *name, int64_t value);
 /* Reads an option back, or one of the read-only diagnostics of the most recent launch on this process:
  * "last_launch_path" (1 = generic kernel, 2 = MFMA kernel), "last_launch_items" (waves of the last MFMA
  * launch), "last_launch_parts" (most pieces a block of 16 samples was cut into), "last_sweep_cached"
- * (1 = the last dlagp_batch_sweep* used the profile cache). */
+ * (1 = the last dlagp_batch_sweep* used the profile cache), "last_launch_patch" (how the last MFMA launch handled
+ * the line cores: 0 tested inside the sample loop, 1 repaired once per wave, 2 repaired pass by pass). */
 int dlagp_get_option(const char *name, int64_t *value);
 /* The work decomposition the MFMA path would choose for `groups` blocks of 16 samples of sightlines with `chunks`
  * chunks of 8 pixel slots each (pure host arithmetic, no device needed): every block is cut into `full` pieces of

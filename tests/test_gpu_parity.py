@@ -114,8 +114,13 @@ def test_sample_log_likelihoods_match_reference_golden():
     assert checksum(sight.y, sight.this_M, sight.padded_wavelengths, sight.keep) == int(g["sight_crc"])
     dev = device_sightline(sight)
     assert abs(dev.null() - g["null_evidence"]) <= RTOL_LL * abs(g["null_evidence"])
+    from gpy_dla_detection_amd.sightline import get_option
+
     for kd in (1, 2, 3, 4):
         got = dev.eval(g["z_kd%d" % kd], g["nhi_kd%d" % kd])
+        # the MFMA kernel with the line cores repaired outside the sample loop: once per wave (1 absorber per
+        # sample) or pass by pass (several)
+        assert get_option("last_launch_path") == 2 and get_option("last_launch_patch") == (1 if kd == 1 else 2)
         np.testing.assert_allclose(got, g["out_kd%d" % kd], rtol=RTOL_LL)
     got = device_sightline(sight, broadening=False).eval(g["z_kd1"], g["nhi_kd1"])
     np.testing.assert_allclose(got, g["out_nobroad_kd1"], rtol=RTOL_LL)
@@ -1120,6 +1125,25 @@ def test_core_patch_equals_in_loop_core_test(restore_options):
     pick = np.r_[0:8, len(z) - len(special):len(z) - 2]
     ref = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in pick])
     np.testing.assert_allclose(got[pick], ref, rtol=RTOL_LL)
+    # several absorbers per sample: the cores are repaired pass by pass and absorber by absorber -- same numbers as
+    # the in-loop test, with the special redshifts (edges of the grid, NaN, infinite) in every absorber position
+    rng = np.random.default_rng(11)
+    n_all = len(z)
+    for kd in (2, 3, 4):
+        idx = np.stack([np.arange(n_all)] + [rng.permutation(n_all) for _ in range(kd - 1)], axis=1)
+        idx[-len(special):, 1] = np.arange(n_all - len(special), n_all)[::-1]  # special with special
+        zz, nn = z[idx], nhi[idx]
+        set_option("core_patch", 1)
+        got = dev.eval(zz, nn)
+        set_option("core_patch", 0)
+        want = dev.eval(zz, nn)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        finite = np.isfinite(want)
+        np.testing.assert_allclose(got[finite], want[finite], rtol=2e-11, err_msg="kd=%d" % kd)
+        pick = np.r_[0:4, n_all - 6:n_all - 2]
+        ref = np.array([R.sample_log_likelihood_k_dlas(st, zz[i], nn[i]) for i in pick])
+        ok = np.isfinite(ref)
+        np.testing.assert_allclose(got[pick][ok], ref[ok], rtol=RTOL_LL)
     # a grid that is not log-uniform silently takes the in-loop kernel
     set_option("core_patch", 1)
     warped = lam * (1 + 3e-4 * np.sin(np.arange(lam.shape[0]) / 90.0))
