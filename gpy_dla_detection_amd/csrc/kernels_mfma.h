@@ -462,6 +462,18 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
 #ifndef DLAGP_CACHE_STORE_NT
 #define DLAGP_CACHE_STORE_NT 1
 #endif
+#ifndef DLAGP_PRIO_VOIGT
+#define DLAGP_PRIO_VOIGT 2
+#endif
+#ifndef DLAGP_PRIO_CONV
+#define DLAGP_PRIO_CONV 1
+#endif
+#ifndef DLAGP_PRIO_HEAD
+#define DLAGP_PRIO_HEAD 3
+#endif
+#ifndef DLAGP_PRIO_MFMA
+#define DLAGP_PRIO_MFMA 0
+#endif
 #ifndef DLAGP_PREFETCH_PASS
 #define DLAGP_PREFETCH_PASS 1
 #endif
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                     const double c8v = vgpr_constant(DLAGP_LINES.exp2c[8]);
                     const double w3v[3] = {vgpr_constant(DLAGP_LINES.wing[0][3]), vgpr_constant(DLAGP_LINES.wing[1][3]),
                                            vgpr_constant(DLAGP_LINES.wing[2][3])};
-                    __builtin_amdgcn_s_setprio(2);
+                    __builtin_amdgcn_s_setprio(DLAGP_PRIO_VOIGT);
                     // one running LDS address (hipcc otherwise rebuilds lane * 8 + offset for every sample)
                     __attribute__((address_space(3))) double *raw_w = (__attribute__((address_space(3))) double *)raw + lane;
                     asm volatile("" : "+v"(raw_w));
@@ -663,7 +675,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                         lds_wave_sync();
                     }
                 }
-                __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_s_setprio(DLAGP_PRIO_CONV);
                 // convolution (voigt.py:319) on the kept pixels (dla_gp.py:388), product over absorbers.
                 // Always all 14 steps, branch-free, so that the LDS reads of different steps overlap:
                 // lanes beyond the pass's pixels re-read a valid window and write unused slots.
@@ -749,7 +761,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         const double *a_row = &a_lds[s_loc * A_STRIDE + slot];
         double a = a_row[0];
         for (int st = 0; st < pass_steps; ++st) {
-            __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_s_setprio(DLAGP_PRIO_HEAD);
             const double a2 = a * a;
             const double d = fma(rec_ov.x, a2, rec_ov.y);
             const double h = fast_rcp1(d);
@@ -769,7 +781,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
             // keep the prefetches above in front of the MFMAs: their results are not needed before
             // the next step, 16 MFMAs (>= 1024 cycles) from here
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(DLAGP_PRIO_MFMA);
             __builtin_amdgcn_sched_barrier(0);
             const int soff = nxt * STEP_BYTES;
 #pragma unroll
@@ -795,7 +807,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
             }
         }
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(DLAGP_PRIO_CONV);
         // the next pass overwrites raw[] / a_lds[]: order the LDS reads above before those writes
         lds_wave_sync();
         if (stamps) t_mfma += stamp_now() - t_mark;
