@@ -7,16 +7,21 @@
 // stall: every wave is independent -- no workgroup barriers, no shared staging -- and streams
 // its operands from L2 one step ahead of use.
 //
-// Work decomposition (DESIGN.md "accumulate_mfma"):
-//   one wave (= one 64-thread workgroup) owns 16 QMC samples of one sightline and one pixel split.
-//   The Gram/projection contraction is the FP64 GEMM  [samples x pixels] . [pixels x 256 cols]:
-//     A operand (16 samples x 4 pixels per v_mfma_f64_16x16x4_f64) = the per-pixel weights
-//       w = a^2/d (14 w-tiles, vech(M_i M_i')) and q = a r/d (2 q-tiles, M_i), generated in
-//       registers by the same lane that feeds them to the MFMA -- they never touch memory;
-//     B operand = the sightline's shared operand P (kernels_common.h), read straight from L2 into
-//       registers as 8 double2 per lane and step; each register pair is reloaded for the next
-//       step right after its two MFMAs have issued (a rolling one-step-ahead prefetch).
-//   Accumulators: 16 tiles x 4 doubles per lane (128 VGPRs) -> 2 waves per SIMD.
+// Work decomposition (DESIGN.md "accumulate_mfma", "Work decomposition"):
+//   one wave (= one 64-thread workgroup) is one work item of the launch plan: 16 QMC samples of one
+//   sightline over a range of its chunks (dlagp_hip.hip build_plan).
+//   The Gram/projection contraction is the FP64 GEMM  [samples x pixels] . [pixels x 230 cols]:
+//     A operand (16 samples x 4 pixels per MFMA) = the per-pixel weights w = a^2/d (vech(M_i M_i'),
+//       210 columns) and q = a r/d (M_i, 20 columns), generated in registers by the same lane that
+//       feeds them to the MFMA -- they never touch memory;
+//     per step 14 v_mfma_f64_16x16x4_f64 (13 w-tiles: vech columns 0..207, one q-tile: M columns 0..15)
+//       and two v_mfma_f64_4x4x4_4b_f64 (vech columns 208, 209 with w; M columns 16..19 with q): the
+//       4-block form takes 16 cycles, its A-operand lane layout is the 16x16x4 form's, and it spares
+//       the two mostly empty 64-cycle tiles (profiles/r02_microbench_mfma_f64_4x4.txt);
+//     B operand = the sightline's MFMA operand Pm (kernels_common.h build_mfma_operand), read straight
+//       from L2 into registers as 8 double2 per lane and step; each register pair is reloaded for the
+//       next step right after its two MFMAs have issued (a rolling one-step-ahead prefetch).
+//   Accumulators: 14 tiles x 4 doubles + 2 doubles per lane (116 VGPRs) -> 2 waves per SIMD.
 //
 // Per pass (<= 56 kept pixels whose 7-tap windows fit in 64 consecutive entries):
 //   phase 1  lane = entry, loop over the wave's 16 samples: optical depth of every absorber and
@@ -25,8 +30,8 @@
 //   phase 2  lane = (sample = lane & 15, pixel slot = lane >> 4), per step of 4 pixels:
 //            a = sum_t taps_t raw[pos + t] (voigt.py:319, dla_gp.py:388), d = omega2 a^2 + v,
 //            r = y - mu a, w = a^2/d, q = a r/d, running sum r^2/d and product of d
-//            (dla_gp.py:392-394, null_gp.py:329-333,356), then 16 MFMAs   (null_gp.py:339-354)
-// Output: partial sums part[split][block][column][16] (partial_index) for the finalize kernel.
+//            (dla_gp.py:392-394, null_gp.py:329-333,356), then the 16 MFMAs   (null_gp.py:339-354)
+// Output: partial sums part[piece][block][column][16] (partial_index) for the finalize kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -233,7 +238,8 @@ __device__ __forceinline__ void lds_wave_sync() {
 // convolved profiles; 2 = deeper levels, phase 1 multiplies cached rows instead of evaluating Voigt profiles
 // (LINES / BROADEN are then irrelevant: instantiated once, as <3, true, false, 2>).
 //
-// PATCH (LINES == 3, kd == 1, SightlineDev::grid_uniform): the line cores are taken out of the sample loop.
+// PATCH (LINES == 3, SightlineDev::grid_uniform; 1: one absorber per sample, 2: several): the line cores are
+// taken out of the sample loop.
 // Within 16 Doppler widths of a line centre -- at most 6 consecutive entries per (sample, line) -- the far-
 // wing form does not hold and the Taylor/table evaluation (core_taylor) is needed.  Testing for that in
 // the loop costs three compares per sample and entry plus a wave-wide branch that is taken for ~7 % of the
@@ -243,7 +249,9 @@ __device__ __forceinline__ void lds_wave_sync() {
 // centre lies in the wave's pixel range, the 7 candidate entries around the centre (located through the
 // log-uniform grid) are examined 64 at a time and those inside the core get their exact profile value
 // 2^(-N log2e tau) (core form for that line, wing form for the other two); every pass copies the values
-// that fall into its window over raw[].
+// that fall into its window over raw[].  With several absorbers per sample (PATCH == 2) a table of that size per
+// absorber does not fit the wave's LDS: only the first candidate entry of every (sample, absorber, line) is kept,
+// and each pass repairs the cores of the absorber it has just evaluated on the spot.
 //
 // LLS (3-line kernels): every absorber also carries the Lyman-limit continuum opacity of reference
 // voigt_lls.py:258-284, N / 10^17.2 (lambda_rest / 911.7641)^3 where lambda_rest = fl(lambda / (1 + z)) is not
