@@ -1250,6 +1250,40 @@ def test_randomised_sightlines_against_oracle():
     assert worst < RTOL_LL
 
 
+def test_async_launches_survive_scratch_growth_and_destroy():
+    """
+    Stream rules of the *_device entry points (include/dlagp.h): a launch that needs larger scratch drains the stream
+    of the launches before it, and destroy drains the last launch's stream before device memory goes back to the pool --
+    results of back-to-back asynchronous launches with a growing sample count on a non-blocking stream stay right, and
+    a context destroyed straight after an asynchronous launch does not corrupt a context created next.
+    """
+    import torch
+
+    torch.cuda.init()
+    dev = torch.device("cuda", 0)
+    sight = make_sightline(3, n_unmasked=900, n_masked=17)
+    z, _, nhi = make_qmc_samples(sight, 6000)
+    want = device_sightline(sight).eval(z, nhi)
+    stream = torch.cuda.Stream(device=dev)  # non-blocking with respect to the null stream
+    d_z, d_n = torch.from_numpy(z).to(dev), torch.from_numpy(nhi).to(dev)
+    torch.cuda.synchronize()
+    ds = device_sightline(sight)
+    outs = []
+    with torch.cuda.stream(stream):
+        for S in (64, 700, 6000, 300, 6000):  # the third launch regrows the partial-sum buffer while two are queued
+            out = torch.full((S,), float("nan"), dtype=torch.float64, device=dev)
+            ds.eval_device(S, 1, d_z.data_ptr(), d_n.data_ptr(), out.data_ptr(), stream.cuda_stream)
+            outs.append((S, out))
+    ds.close()  # straight after the last asynchronous launch
+    other = device_sightline(make_sightline(4, n_unmasked=900, n_masked=17))  # draws the same pooled buffer sizes
+    other_ll = other.eval(z[:500], nhi[:500])
+    stream.synchronize()
+    for S, out in outs:
+        np.testing.assert_allclose(out.cpu().numpy(), want[:S], rtol=1e-13)
+    again = device_sightline(make_sightline(4, n_unmasked=900, n_masked=17)).eval(z[:500], nhi[:500])
+    np.testing.assert_array_equal(other_ll, again)
+
+
 def test_device_entry_points_are_graph_capturable():
     """
     dlagp_eval_device + dlagp_level_evidence_device only enqueue work on the caller's stream once the workspace
