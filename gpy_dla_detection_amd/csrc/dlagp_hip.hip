@@ -62,6 +62,7 @@ static int64_t g_opt_profile_cache = 1;  // multi-level sweeps keep level-1 prof
 static int64_t g_opt_profile_cache_max_mb = 196608;
 static int64_t g_opt_plan_item_cost = 20;   // fixed cost of a work item in the planner's model, tenths of a chunk
 static int64_t g_opt_plan_rest_first = 0;   // dispatch the remainder pieces before the full ones (tuning)
+static int64_t g_opt_plan_slots = 2048;     // wave slots the planner fills: 256 CUs x 4 SIMDs x 2 waves (tuning)
 // read-only diagnostics of the most recent launch / sweep (dlagp_get_option): which kernel served it
 static int64_t g_last_launch_path = 0;    // 1 generic kernel, 2 MFMA kernel
 static int64_t g_last_launch_items = 0;   // work items (waves) of the last MFMA launch
@@ -432,7 +433,7 @@ static void refine_cuts(const std::vector<int> &slot_pos, int ntaps, std::vector
 
 // the cut, as fractions of a sightline's chunks: `full` pieces of `frac` each, then a remainder if frac * full < 1
 static void choose_cut(long groups, double C, int64_t forced, int *full_out, double *frac_out) {
-    const long slots = 2048;
+    const long slots = g_opt_plan_slots;
     // prologue + epilogue of an item, and the pass it adds by starting a new one, in chunks' worth of work
     const double o = 0.1 * (double)g_opt_plan_item_cost * 8.0 / DLAGP_CHUNK_PIXELS;
     // every piece of a block is one more set of partial sums the finalisation reads: ~25 ns per (block, piece) in a
@@ -465,7 +466,8 @@ static void choose_cut(long groups, double C, int64_t forced, int *full_out, dou
 }
 
 static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
-    const std::pair<int64_t, int64_t> key(S, g_opt_pixel_splits + 1000 * g_opt_plan_item_cost + 1000000 * g_opt_plan_rest_first);
+    const std::pair<int64_t, int64_t> key(S, g_opt_pixel_splits + 1000 * g_opt_plan_item_cost + 1000000 * g_opt_plan_rest_first +
+                                                 10000000 * g_opt_plan_slots);
     auto it = g.plans.find(key);
     if (it != g.plans.end()) {
         *out = it->second.get();
@@ -494,7 +496,7 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
     std::vector<unsigned char> counts((size_t)groups, 1);
     int max_parts = 1;
     // remainder items a left-over wave slot works through (shape (B)); 1 otherwise
-    const long slots_total = 2048, left = slots_total - (long)full * groups;
+    const long slots_total = g_opt_plan_slots, left = slots_total - (long)full * groups;
     const long rest_per_slot = remainder && left > 0 ? (groups + left - 1) / left : 1;
     for (int b = 0; b < nb; ++b) {
         // cut positions of sightline b (the same for all of its groups); empty pieces are dropped
@@ -1582,6 +1584,7 @@ int dlagp_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "profile_cache_max_mb")) g_opt_profile_cache_max_mb = value;
     else if (!strcmp(name, "plan_item_cost")) g_opt_plan_item_cost = value;
     else if (!strcmp(name, "plan_rest_first")) g_opt_plan_rest_first = value;
+    else if (!strcmp(name, "plan_slots")) g_opt_plan_slots = value > 0 ? value : 2048;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 }

@@ -261,6 +261,9 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     of all QMC points in HBM, 8 S n_pad bytes per sightline, and multiplies cached
  *                     rows at the deeper levels instead of re-evaluating Voigt profiles; 0 = recompute),
  *                     "profile_cache_max_mb" (upper bound of that allocation, default 196608; never more than half of the free HBM)
+ *                     "plan_item_cost" (fixed cost of a work item in the planner's model, tenths of a chunk, default
+ *                     20), "plan_slots" (wave slots the planner fills, default 2048 = 256 CUs x 4 SIMDs x 2 waves),
+ *                     "plan_rest_first" (dispatch remainder pieces first; tuning experiments only)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.
  */
