@@ -1207,13 +1207,16 @@ def test_class_api_device_levels_consume_the_rng_like_the_reference():
         dla.dla_samples._nhi_samples = good
 
 
-def test_randomised_sightlines_against_oracle():
+def test_randomised_sightlines_against_oracle(restore_options):
     """
-    60 sightlines of random length, mask pattern, rank and redshift range, a few samples each, automatic
-    kernel selection (core-patch kernel where the mask allows the MFMA path, generic kernel otherwise).
+    60 sightlines of random length, mask pattern (random single pixels, masked runs of 2..300 pixels), rank and
+    redshift range, a few samples each with one or two absorbers; every sightline of rank <= 20 is required to run
+    on the MFMA kernel (path = 2), whatever its mask.
     """
+    from gpy_dla_detection_amd.sightline import get_option
     from oracle import ref_like as R
 
+    set_option = restore_options
     rng = np.random.default_rng(2024)
     worst = 0.0
     for trial in range(60):
@@ -1223,8 +1226,8 @@ def test_randomised_sightlines_against_oracle():
         sight = make_sightline(1000 + trial, n_unmasked=n_u, n_masked=n_masked, k=k)
         if trial % 7 == 3 and n_u > 200:  # a masked run inside the spectrum
             keep = sight.keep.copy()
-            lo = int(rng.integers(10, n_u - 60))
-            run = int(rng.integers(2, 50))
+            run = int(rng.integers(2, min(300, n_u // 2)))
+            lo = int(rng.integers(10, max(11, n_u - run - 10)))
             sel = np.ones(int(keep.sum()), dtype=bool)
             idx = np.cumsum(keep) - 1
             gone = keep.copy()
@@ -1239,11 +1242,19 @@ def test_randomised_sightlines_against_oracle():
         S = 24
         z, _, nhi = make_qmc_samples(sight, S)
         z = z + 1e-3 * rng.standard_normal(S)
+        set_option("path", 2 if k <= 20 else 0)  # rank <= 20: the MFMA kernel must serve it (raises otherwise)
         got = dev.eval(z, nhi)
+        assert get_option("last_launch_path") == (2 if k <= 20 else 1)
         st = oracle_state(sight)
         pick = rng.choice(S, 6, replace=False)
         want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in pick])
         rel = np.max(np.abs(got[pick] - want) / np.abs(want))
+        if trial % 3 == 0:  # two absorbers per sample
+            z2, n2 = np.stack([z, z[::-1]], axis=1), np.stack([nhi, nhi[::-1]], axis=1)
+            got2 = dev.eval(z2, n2)
+            want2 = np.array([R.sample_log_likelihood_k_dlas(st, z2[i], n2[i]) for i in pick[:3]])
+            rel = max(rel, np.max(np.abs(got2[pick[:3]] - want2) / np.abs(want2)))
+        set_option("path", 0)
         worst = max(worst, rel)
         assert rel <= RTOL_LL, "trial %d (n_u=%d, masked=%d, k=%d): %.2e" % (trial, n_u, n_masked, k, rel)
         assert abs(dev.null() - R.null_log_model_evidence(st)) <= RTOL_LL * abs(R.null_log_model_evidence(st))
