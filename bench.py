@@ -23,6 +23,9 @@ are all-gathered over RCCL once, at the end of the timed region.  `--strong` (co
 10 000 samples of ONE sightline over the ranks: per step every rank evaluates its slice, one all-gather of S / N
 log-likelihoods, and the evidence on every rank (the by-sample partition of SURVEY.md §8e).
 
+`vs_baseline` is null: BASELINE.md holds no published number for this metric on this configuration (the reference's only
+statement, "~4 mins for a single spectrum", is another size on unnamed hardware).
+
 Prints ONE JSON line on rank 0: the driver's contract keys plus
   roofline      the accumulate kernels only: algorithmic FLOP of the timed launches / their summed HIP-event
                 durations, against the dense FP64 MFMA peak; `frac_cold`: the same from 25 steps on an idle device

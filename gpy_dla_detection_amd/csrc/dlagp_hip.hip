@@ -280,7 +280,9 @@ struct LaunchGroup {
     bool lls_break = false;     // members carry the Lyman-limit term (all or none, else no MFMA path)
     Workspace ws;
     int max_slots = 0;  // largest n_slots of a member (row stride of the profile cache)
-    std::map<std::pair<int64_t, int64_t>, std::unique_ptr<LaunchPlan>> plans;  // key: (S, forced split count)
+    // key: (S, and the planner options in force: forced split count, item cost, dispatch order, slot count)
+    typedef std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t> PlanKey;
+    std::map<PlanKey, std::unique_ptr<LaunchPlan>> plans;
     void release() {
         // asynchronous entry points may have left kernels in flight that still use these buffers, and released
         // buffers go back to a pool other contexts draw from
@@ -466,8 +468,7 @@ static void choose_cut(long groups, double C, int64_t forced, int *full_out, dou
 }
 
 static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
-    const std::pair<int64_t, int64_t> key(S, g_opt_pixel_splits + 1000 * g_opt_plan_item_cost + 1000000 * g_opt_plan_rest_first +
-                                                 10000000 * g_opt_plan_slots);
+    const LaunchGroup::PlanKey key(S, g_opt_pixel_splits, g_opt_plan_item_cost, g_opt_plan_rest_first, g_opt_plan_slots);
     auto it = g.plans.find(key);
     if (it != g.plans.end()) {
         *out = it->second.get();
