@@ -81,3 +81,31 @@ def mcmc_thetas(z_lo, z_hi):
     outside = np.array([[z_lo - 0.01, 21.0], [z_hi + 0.01, 21.0], [0.5 * (z_lo + z_hi), 19.9],
                         [0.5 * (z_lo + z_hi), 23.1], [z_hi, 21.0]])
     return np.concatenate([inside, outside])
+
+
+GAPPED_CASES = [  # (index, n_unmasked, masked runs, comb) of golden set G11: masks with long masked runs
+    dict(index=4, n_unmasked=600, gaps=((203, 333),), comb=(400, 420, 2)),
+    dict(index=5, n_unmasked=600, gaps=((10, 75), (76, 140), (300, 520)), comb=(400, 420, 2)),
+    dict(index=6, n_unmasked=900, gaps=((0, 64), (500, 597), (700, 880)), comb=None),
+]
+
+
+def gapped_sightline(index=4, n_unmasked=600, gaps=((203, 333),), comb=(400, 420, 2), k=20):
+    """
+    A synthetic sightline whose mask has long masked runs (longer than one 64-entry pass of the MFMA kernel) and a
+    comb of single pixels -- the shapes real SDSS masks have (reference read_spec.py:38-71: runs of ivar == 0;
+    null_gp.py:139-152).
+    """
+    from gpy_dla_detection_amd.synthetic import make_sightline
+
+    sight = make_sightline(index, n_unmasked=n_unmasked, n_masked=0, k=k)
+    keep = sight.keep.copy()
+    for lo, hi in gaps:
+        keep[lo:hi] = False
+    if comb:
+        keep[comb[0]:comb[1]:comb[2]] = False
+    sel = keep[sight.keep]  # all kept originally: the index map is the identity
+    sight.keep = keep
+    sight.y, sight.v = sight.y[sel], sight.v[sel]
+    sight.this_mu, sight.this_M, sight.this_omega2 = sight.this_mu[sel], sight.this_M[sel], sight.this_omega2[sel]
+    return sight

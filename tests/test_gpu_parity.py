@@ -478,20 +478,7 @@ def test_sharded_driver_on_device_matches_oracle_driver():
     assert np.array_equal(np.argmax(got, axis=1), np.argmax(want, axis=1))  # identical model selection
 
 
-def gapped_sightline(index=4, n_unmasked=600, gaps=((203, 333),), comb=(400, 420, 2), k=20):
-    """a synthetic sightline whose mask has long masked runs (> one 64-entry pass) and a comb of single pixels,
-    the shapes real SDSS masks have (reference read_spec.py:38-71: runs of ivar == 0; null_gp.py:139-152)"""
-    sight = make_sightline(index, n_unmasked=n_unmasked, n_masked=0, k=k)
-    keep = sight.keep.copy()
-    for lo, hi in gaps:
-        keep[lo:hi] = False
-    if comb:
-        keep[comb[0]:comb[1]:comb[2]] = False
-    sel = keep[sight.keep]  # all kept originally: the index map is the identity
-    sight.keep = keep
-    sight.y, sight.v = sight.y[sel], sight.v[sel]
-    sight.this_mu, sight.this_M, sight.this_omega2 = sight.this_mu[sel], sight.this_M[sel], sight.this_omega2[sel]
-    return sight
+from tests.golden_inputs import GAPPED_CASES, gapped_sightline  # noqa: E402
 
 
 def test_ragged_mask_runs_on_the_mfma_path(restore_options):
@@ -515,6 +502,34 @@ def test_ragged_mask_runs_on_the_mfma_path(restore_options):
         np.testing.assert_allclose(dev.eval(z2, n2)[::5], want2, rtol=RTOL_LL)
         set_option("path", 0)
         assert abs(dev.null() - R.null_log_model_evidence(st)) <= RTOL_LL * abs(R.null_log_model_evidence(st))
+
+
+def test_gapped_masks_match_reference_golden(restore_options):
+    """golden set G11: the reference itself on sightlines with long masked runs -- per-sample likelihoods with one and
+    two absorbers, the null evidence and a seeded three-level sweep -- against the MFMA kernel (path = 2)"""
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    set_option = restore_options
+    g = load_golden("gapped.npz")
+    for c, case in enumerate(GAPPED_CASES):
+        sight = gapped_sightline(**case)
+        assert checksum(sight.y, sight.this_M, sight.padded_wavelengths, sight.keep) == int(g["crc_%d" % c])
+        dev = device_sightline(sight)
+        set_option("path", 2)
+        np.testing.assert_allclose(dev.eval(g["z1_%d" % c], g["n1_%d" % c]), g["out1_%d" % c], rtol=RTOL_LL)
+        np.testing.assert_allclose(dev.eval(g["z2_%d" % c], g["n2_%d" % c]), g["out2_%d" % c], rtol=RTOL_LL)
+        set_option("path", 0)
+        assert abs(dev.null() - g["null_%d" % c]) <= RTOL_LL * abs(g["null_%d" % c])
+        S = g["sweep_z_%d" % c].shape[0]
+        batch = DeviceBatch([dev])
+        set_option("path", 2)
+        ev, ll, base = batch.sweep(g["sweep_z_%d" % c][None, :], g["sweep_nhi_%d" % c], 3, float(g["min_z_separation"]),
+                                   parallel.resampling_uniforms(1, 3, S, seed=0))
+        set_option("path", 0)
+        np.testing.assert_array_equal(base[0], g["sweep_base_%d" % c])
+        np.testing.assert_allclose(ev[0], g["sweep_ev_%d" % c], rtol=RTOL_LL)
+        np.testing.assert_allclose(ll[0], g["sweep_ll_%d" % c], rtol=RTOL_LL, equal_nan=True)
 
 
 def test_one_gapped_sightline_does_not_slow_the_batch_down(restore_options):

@@ -150,3 +150,19 @@ def test_oracle_reproduces_reference_voigt_lls():
                                      lls_break=True)
             np.testing.assert_allclose(got, want[i], rtol=1e-13, atol=1e-300)
     assert (g["absorption_b0"] < 1e-3).any() and (g["absorption_b0"] > 0.5).any()  # the break is on the grid
+
+
+def test_oracle_reproduces_reference_on_gapped_masks():
+    """G11: sightlines whose masks have long masked runs (reference dla_gp.py:360-388 keeps `~pixel_mask[ind_unmasked]`)"""
+    from tests.golden_inputs import GAPPED_CASES, checksum, gapped_sightline
+
+    g = load_golden("gapped.npz")
+    for c, case in enumerate(GAPPED_CASES):
+        sight = gapped_sightline(**case)
+        assert checksum(sight.y, sight.this_M, sight.padded_wavelengths, sight.keep) == int(g["crc_%d" % c])
+        st = oracle_state(sight)
+        got = np.array([R.sample_log_likelihood_k_dlas(st, [z], [n]) for z, n in zip(g["z1_%d" % c], g["n1_%d" % c])])
+        np.testing.assert_allclose(got, g["out1_%d" % c], rtol=1e-12)
+        got2 = np.array([R.sample_log_likelihood_k_dlas(st, z, n) for z, n in zip(g["z2_%d" % c], g["n2_%d" % c])])
+        np.testing.assert_allclose(got2, g["out2_%d" % c], rtol=1e-12)
+        assert abs(R.null_log_model_evidence(st) - g["null_%d" % c]) <= 1e-12 * abs(g["null_%d" % c])

@@ -23,6 +23,8 @@ Fixtures (all float64):
   G9 log_posterior.npz     log_posterior_mcmc.log_posterior (MCMC target density) for a set of thetas
   G8 catalogue.npz         the per-spectrum body of run_bayes_select.process_qso on three raw spectra:
                            every array the reference writes to processed_qsos_multi_meanflux.h5
+  G11 gapped.npz           sightlines whose masks have long masked runs: per-sample likelihoods (1, 2 absorbers), null
+                           evidence, a seeded DLAGP.log_model_evidences(3)
 """
 import os
 import sys
@@ -50,7 +52,8 @@ from gpy_dla_detection import voigt_lls as ref_voigt_lls  # noqa: E402
 from gpy_dla_detection_amd.synthetic import make_sightline, make_qmc_samples  # noqa: E402
 from gpy_dla_detection_amd.samples import halton  # noqa: E402
 from tests.golden_inputs import (  # noqa: E402
-    MVNPDF_SHAPES, checksum, mcmc_pdf, mcmc_thetas, mvnpdf_inputs, raw_catalogue, raw_spectrum_and_model,
+    GAPPED_CASES, MVNPDF_SHAPES, checksum, gapped_sightline, mcmc_pdf, mcmc_thetas, mvnpdf_inputs, raw_catalogue,
+    raw_spectrum_and_model,
 )
 
 OUT = os.path.join(REPO, "tests", "golden")
@@ -226,6 +229,33 @@ def g4_sample_ll():
     np.savez_compressed(os.path.join(OUT, "sample_ll.npz"), **store)
 
 
+def g11_gapped():
+    store = {}
+    for c, case in enumerate(GAPPED_CASES):
+        sight = gapped_sightline(**case)
+        store["crc_%d" % c] = checksum(sight.y, sight.this_M, sight.padded_wavelengths, sight.keep)
+        S = 40
+        z, log_nhi, nhi = make_qmc_samples(sight, S)
+        gp = ref_gp(RefDLAGP, sight, S, halton(S, 2), log_nhi)
+        store["z1_%d" % c], store["n1_%d" % c] = z, nhi
+        store["out1_%d" % c] = np.array([gp.sample_log_likelihood_k_dlas(z[i:i + 1], nhi[i:i + 1]) for i in range(S)])
+        z2, n2 = np.stack([z[:16], z[::-1][:16]], axis=1), np.stack([nhi[:16], nhi[::-1][:16]], axis=1)
+        store["z2_%d" % c], store["n2_%d" % c] = z2, n2
+        store["out2_%d" % c] = np.array([gp.sample_log_likelihood_k_dlas(z2[i], n2[i]) for i in range(16)])
+        store["null_%d" % c] = ref_gp(RefNullGP, sight, S).log_model_evidence()
+        S = 64
+        off, u = halton(S, 2), halton(S, 3)
+        dla = ref_gp(RefDLAGP, sight, S, off, 20.0 + 3.0 * u, min_z_separation=3000.0)
+        np.random.seed(0)
+        store["sweep_ev_%d" % c] = dla.log_model_evidences(3)
+        store["sweep_ll_%d" % c] = dla.sample_log_likelihoods
+        store["sweep_base_%d" % c] = dla.base_sample_inds
+        store["sweep_z_%d" % c] = dla.dla_samples.sample_z_dlas(dla.this_wavelengths, dla.z_qso)
+        store["sweep_nhi_%d" % c] = dla.dla_samples.nhi_samples
+        store["min_z_separation"] = dla.min_z_separation
+    np.savez_compressed(os.path.join(OUT, "gapped.npz"), **store)
+
+
 def g5_evidences():
     for tag, sight_kwargs, S in (
         ("small", dict(index=1, n_unmasked=400, n_masked=9, k=20), 256),
@@ -393,9 +423,9 @@ def g10_voigt_lls():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     table = dict(g1=g1_voigt_profile, g2=g2_voigt_absorption, g3=g3_mvnpdf, g4=g4_sample_ll,
-                 g5=g5_evidences, g6=g6_model_selection, g7=g7_set_data, g8=g8_catalogue, g9=g9_log_posterior, g10=g10_voigt_lls)
+                 g5=g5_evidences, g6=g6_model_selection, g7=g7_set_data, g8=g8_catalogue, g9=g9_log_posterior, g10=g10_voigt_lls, g11=g11_gapped)
     for name in which:
         print("generating", name, flush=True)
         table[name]()
