@@ -314,11 +314,15 @@ struct dlagp_ctx {
     std::vector<int> h_slot_pos;  // window start of every slot (padding slots repeat their chunk's last pixel), for planning
     bool mfma_ok = false;      // rank padded to 20
     LaunchGroup self;          // the group {this}
+    std::vector<dlagp_batch *> batches;  // live batches this context is a member of (g_membership_mutex)
 };
 
 struct dlagp_batch {
     LaunchGroup group;
 };
+
+// which batches a context belongs to: a context destroyed before its batches drains their streams first
+static std::mutex g_membership_mutex;
 
 // ------------------------------------------------------------------------------------------------
 // planning (MFMA path)
@@ -1207,7 +1211,16 @@ int dlagp_ctx_read_model(dlagp_ctx *ctx, double *this_mu, double *this_M, double
 void dlagp_destroy(dlagp_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    ctx->self.release();  // first: drains the stream of the last asynchronous launch
+    {
+        // batches are meant to be destroyed before their members; if one is still alive, its launches may be using
+        // this context's arrays
+        std::lock_guard<std::mutex> lock(g_membership_mutex);
+        for (dlagp_batch *batch : ctx->batches)
+            if (batch->group.launched) (void)hipStreamSynchronize(batch->group.last_stream);
+        for (dlagp_batch *batch : ctx->batches)  // and it must not touch the context again
+            std::replace(batch->group.ctxs.begin(), batch->group.ctxs.end(), ctx, (dlagp_ctx *)nullptr);
+    }
+    ctx->self.release();  // drains the stream of the last asynchronous launch
     ctx->y.release();
     ctx->mu.release();
     ctx->omega2.release();
@@ -1226,6 +1239,14 @@ void dlagp_destroy(dlagp_ctx *ctx) {
 int dlagp_ctx_n(const dlagp_ctx *ctx) { return ctx ? ctx->sl.n : DLAGP_EINVAL; }
 int dlagp_ctx_k(const dlagp_ctx *ctx) { return ctx ? ctx->user_k : DLAGP_EINVAL; }
 int dlagp_ctx_device(const dlagp_ctx *ctx) { return ctx ? ctx->device : DLAGP_EINVAL; }
+
+// a batch one of whose members has been destroyed can no longer launch
+static int batch_alive(const dlagp_batch *batch) {
+    if (!batch) return fail(DLAGP_EINVAL, "NULL batch");
+    for (const dlagp_ctx *ctx : batch->group.ctxs)
+        if (!ctx) return fail(DLAGP_EINVAL, "a member context of this batch has been destroyed");
+    return DLAGP_OK;
+}
 
 static int check_eval_args(const void *ctx, int64_t S, int kd, const void *z, const void *nhi, const void *out) {
     if (!ctx) return fail(DLAGP_EINVAL, "context is NULL");
@@ -1323,6 +1344,10 @@ int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
             g_spare_workspace.erase(it);
         }
     }
+    {
+        std::lock_guard<std::mutex> lock(g_membership_mutex);
+        for (dlagp_ctx *ctx : batch->group.ctxs) ctx->batches.push_back(batch);
+    }
     int rc = finish_group(batch->group);
     if (rc) {
         dlagp_batch_destroy(batch);
@@ -1337,6 +1362,11 @@ void dlagp_batch_destroy(dlagp_batch *batch) {
     (void)hipSetDevice(batch->group.device);
     // the workspace goes to the next batch, which may launch on another stream
     if (batch->group.launched) (void)hipStreamSynchronize(batch->group.last_stream);
+    {
+        std::lock_guard<std::mutex> lock(g_membership_mutex);
+        for (dlagp_ctx *ctx : batch->group.ctxs)
+            if (ctx) ctx->batches.erase(std::remove(ctx->batches.begin(), ctx->batches.end(), batch), ctx->batches.end());
+    }
     // A catalogue run builds one batch after the other: the sweep workspace (partial sums, profile cache --
     // gigabytes) is handed to the next batch of this device instead of being freed and allocated again.
     // One workspace per device is kept; option "pool_mb" = 0 turns this off as well.
@@ -1362,7 +1392,7 @@ void dlagp_batch_destroy(dlagp_batch *batch) {
 int dlagp_batch_eval_device(dlagp_batch *batch, int64_t S, int kd, const double *d_z, const double *d_nhi,
                             double *d_out, void *stream) {
     int rc = check_eval_args(batch, S, kd, d_z, d_nhi, d_out);
-    if (rc) return rc;
+    if (rc || (rc = batch_alive(batch))) return rc;
     HIP_TRY(hipSetDevice(batch->group.device));
     return launch_sweep(batch->group, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0}, d_out,
                         static_cast<hipStream_t>(stream));
@@ -1370,7 +1400,7 @@ int dlagp_batch_eval_device(dlagp_batch *batch, int64_t S, int kd, const double 
 
 int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, const double *nhi, double *out) {
     int rc = check_eval_args(batch, S, kd, z, nhi, out);
-    if (rc) return rc;
+    if (rc || (rc = batch_alive(batch))) return rc;
     if (S == 0) return DLAGP_OK;
     HIP_TRY(hipSetDevice(batch->group.device));
     return sweep_from_host(batch->group, S, kd, z, nhi, out);
@@ -1378,13 +1408,16 @@ int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, con
 
 int dlagp_batch_null(dlagp_batch *batch, double *out) {
     if (!batch || !out) return fail(DLAGP_EINVAL, "NULL argument");
+    int rc = batch_alive(batch);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(batch->group.device));
     return sweep_from_host(batch->group, 1, 0, nullptr, nullptr, out);
 }
 
 static int check_sweep_args(const dlagp_batch *batch, int64_t S, int max_dlas, const void *sample_z,
                             const void *sample_nhi, int64_t nhi_stride, const void *uniforms, const void *evidences) {
-    if (!batch) return fail(DLAGP_EINVAL, "NULL batch");
+    int alive = batch_alive(batch);
+    if (alive) return alive;
     if (S <= 0) return fail(DLAGP_EINVAL, "S = %lld, need S > 0", (long long)S);
     if (S > INT32_MAX) return fail(DLAGP_EINVAL, "S = %lld does not fit the int32 base indices", (long long)S);
     if (max_dlas < 1 || max_dlas > DLAGP_MAX_ABSORBERS)
@@ -1451,7 +1484,8 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
 int dlagp_batch_level_eval_device(dlagp_batch *batch, int64_t S_total, int64_t s_begin, int64_t s_count, int level,
                                   const double *d_sample_z, const double *d_sample_nhi, int64_t nhi_stride,
                                   const int32_t *d_base_inds, int base_levels, double *d_out, void *stream) {
-    if (!batch) return fail(DLAGP_EINVAL, "NULL batch");
+    int alive = batch_alive(batch);
+    if (alive) return alive;
     if (S_total <= 0 || s_begin < 0 || s_count < 0 || s_begin + s_count > S_total)
         return fail(DLAGP_EINVAL, "sample slice [%lld, %lld) outside [0, %lld)", (long long)s_begin,
                     (long long)(s_begin + s_count), (long long)S_total);

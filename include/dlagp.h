@@ -168,7 +168,8 @@ int dlagp_eval_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, cons
 
 /*
  * Batch of sightlines evaluated by one launch sequence.  All contexts must live on the same
- * device.  Sample arrays are laid out [nb][S][kd], outputs [nb][S].
+ * device.  Sample arrays are laid out [nb][S][kd], outputs [nb][S].  Destroy a batch before its member contexts;
+ * a context destroyed first drains the batch's launches, and the batch then refuses further calls (DLAGP_EINVAL).
  */
 int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb);
 void dlagp_batch_destroy(dlagp_batch *batch);

@@ -1308,6 +1308,24 @@ def test_async_launches_survive_scratch_growth_and_destroy():
         np.testing.assert_allclose(out.cpu().numpy(), want[:S], rtol=1e-13)
     again = device_sightline(make_sightline(4, n_unmasked=900, n_masked=17)).eval(z[:500], nhi[:500])
     np.testing.assert_array_equal(other_ll, again)
+    # a member context destroyed before its batch: the batch's launches are drained first, later calls are refused
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    members = [device_sightline(sight), device_sightline(make_sightline(4, n_unmasked=900, n_masked=17))]
+    batch = DeviceBatch(members)
+    out2 = torch.full((2, 6000), float("nan"), dtype=torch.float64, device=dev)
+    zz = torch.from_numpy(np.stack([z, z])).to(dev)
+    nn = torch.from_numpy(np.stack([nhi, nhi])).to(dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        batch.eval_device(6000, 1, zz.data_ptr(), nn.data_ptr(), out2.data_ptr(), stream.cuda_stream)
+    members[0].close()
+    stream.synchronize()
+    np.testing.assert_allclose(out2[0].cpu().numpy(), want, rtol=1e-13)
+    with pytest.raises(ValueError):
+        batch.eval_device(6000, 1, zz.data_ptr(), nn.data_ptr(), out2.data_ptr(), stream.cuda_stream)
+    batch.close()
+    members[1].close()
 
 
 def test_device_entry_points_are_graph_capturable():
