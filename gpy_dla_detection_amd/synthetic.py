@@ -113,7 +113,7 @@ def make_sightline(
 
     scale = n_unmasked / 3061.0
     mu = 1 + 0.3 * np.sin(2 * np.pi * jj / (700 * scale)) + 0.5 * np.exp(-(((jj - 2600 * scale) / (60 * scale)) ** 2))
-    box = np.ones(25) / 25.0
+    box = np.ones(min(25, n)) / min(25, n)  # 25-pixel boxcar (shorter only for toy sightlines of fewer pixels)
     M = np.empty((k, n))
     for col in range(k):
         M[col] = 0.15 * np.convolve(rng.standard_normal(n), box, "same") * 0.9 ** col
