@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -52,23 +53,34 @@ static int fail(int code, const char *fmt, ...) {
 // ------------------------------------------------------------------------------------------------
 // options and timing
 // ------------------------------------------------------------------------------------------------
-static int64_t g_opt_pixel_splits = 0;
-static int64_t g_opt_path = 0;
-static int64_t g_opt_timing = 0;
-static int64_t g_opt_debug = 0;  // bit 1: stamped instantiation of the MFMA kernel (diagnostics)
-static int64_t g_opt_core_patch = 1;     // MFMA kernel: line cores repaired outside the sample loop when eligible
-static int64_t g_opt_profile_cache = 1;  // multi-level sweeps keep level-1 profiles in HBM (0 = recompute)
+// Options and last-launch diagnostics are process-wide and may be read by a worker thread (context creation,
+// batch bookkeeping) while another thread sets them: relaxed atomics, each read a plain int64_t.
+struct Option {
+    std::atomic<int64_t> v;
+    constexpr Option(int64_t init) : v(init) {}
+    operator int64_t() const { return v.load(std::memory_order_relaxed); }
+    Option &operator=(int64_t x) {
+        v.store(x, std::memory_order_relaxed);
+        return *this;
+    }
+};
+static Option g_opt_pixel_splits = 0;
+static Option g_opt_path = 0;
+static Option g_opt_timing = 0;
+static Option g_opt_debug = 0;  // bit 1: stamped instantiation of the MFMA kernel (diagnostics)
+static Option g_opt_core_patch = 1;     // MFMA kernel: line cores repaired outside the sample loop when eligible
+static Option g_opt_profile_cache = 1;  // multi-level sweeps keep level-1 profiles in HBM (0 = recompute)
 // never more than this for the cache (MB), and never more than half of the free HBM
-static int64_t g_opt_profile_cache_max_mb = 196608;
-static int64_t g_opt_plan_item_cost = 20;   // fixed cost of a work item in the planner's model, tenths of a chunk
-static int64_t g_opt_plan_rest_first = 0;   // dispatch the remainder pieces before the full ones (tuning)
-static int64_t g_opt_plan_slots = 2048;     // wave slots the planner fills: 256 CUs x 4 SIMDs x 2 waves (tuning)
+static Option g_opt_profile_cache_max_mb = 196608;
+static Option g_opt_plan_item_cost = 20;   // fixed cost of a work item in the planner's model, tenths of a chunk
+static Option g_opt_plan_rest_first = 0;   // dispatch the remainder pieces before the full ones (tuning)
+static Option g_opt_plan_slots = 2048;     // wave slots the planner fills: 256 CUs x 4 SIMDs x 2 waves (tuning)
 // read-only diagnostics of the most recent launch / sweep (dlagp_get_option): which kernel served it
-static int64_t g_last_launch_path = 0;    // 1 generic kernel, 2 MFMA kernel
-static int64_t g_last_launch_items = 0;   // work items (waves) of the last MFMA launch
-static int64_t g_last_launch_parts = 0;   // most pieces a block of 16 samples was cut into
-static int64_t g_last_sweep_cached = 0;   // the last multi-level sweep used the profile cache
-static int64_t g_last_launch_patch = 0;   // core handling of the last MFMA launch (patch_mode: 0 in loop, 1, 2)
+static Option g_last_launch_path = 0;    // 1 generic kernel, 2 MFMA kernel
+static Option g_last_launch_items = 0;   // work items (waves) of the last MFMA launch
+static Option g_last_launch_parts = 0;   // most pieces a block of 16 samples was cut into
+static Option g_last_sweep_cached = 0;   // the last multi-level sweep used the profile cache
+static Option g_last_launch_patch = 0;   // core handling of the last MFMA launch (patch_mode: 0 in loop, 1, 2)
 
 struct EventPair {
     hipEvent_t start, stop;
@@ -133,7 +145,7 @@ static int ensure_device(int device) {
 static std::mutex g_pool_mutex;
 static std::map<std::pair<int, size_t>, std::vector<void *>> g_pool;
 static size_t g_pool_bytes = 0;
-static int64_t g_opt_pool_mb = 2048;
+static Option g_opt_pool_mb = 2048;
 
 static void pool_flush() {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
