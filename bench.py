@@ -213,6 +213,9 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    # launched through torch.distributed.run: the process group and every collective below run even with one rank
+    # (a one-GPU box then exercises the RCCL calls of the N > 1 path); plain `python bench.py` has no group
+    dist_on = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
 
     from gpy_dla_detection_amd import sightline as sl
     from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline
@@ -241,7 +244,7 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
@@ -268,7 +271,7 @@ def main() -> None:
     per_step = {2: 1, 3: 2 * nb, 4: 3 * nb, 5: 4 * nb}[config]
     slots = max(steps, warmup, 1)
     evidences = torch.zeros(slots * per_step, **f64)
-    gathered = torch.zeros(world * slots * per_step, **f64) if world > 1 else None
+    gathered = torch.zeros(world * slots * per_step, **f64) if dist_on else None
     counter = [0]
 
     if config == 2:
@@ -290,9 +293,9 @@ def main() -> None:
                 target = out
             else:  # this rank's slice, then all S log-likelihoods on every rank (S / N doubles per rank over RCCL)
                 devs[0].eval_device(hi - lo, 1, z.data_ptr() + 8 * lo, nhi_col.data_ptr() + 8 * lo, local.data_ptr(), stream)
-                if world > 1 and args.rehearse_on_one_gpu:
+                if dist_on and args.rehearse_on_one_gpu:
                     dist.all_gather(list(everything.view(world, -1).unbind(0)), local)
-                elif world > 1:
+                elif dist_on:
                     dist.all_gather_into_tensor(everything, local)
                 else:
                     everything.copy_(local)
@@ -323,14 +326,14 @@ def main() -> None:
                 evidences[slot * per_step + 2 * nb: slot * per_step + 3 * nb] = torch.from_numpy(batch.nulls()).to(device)
 
     def exchange():
-        if world > 1 and args.rehearse_on_one_gpu:  # gloo has no all_gather_into_tensor for device tensors
+        if dist_on and args.rehearse_on_one_gpu:  # gloo has no all_gather_into_tensor for device tensors
             dist.all_gather(list(gathered.view(world, -1).unbind(0)), evidences)
-        elif world > 1:
+        elif dist_on:
             dist.all_gather_into_tensor(gathered, evidences)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -366,7 +369,7 @@ def main() -> None:
     # Untimed steps until the device has been busy for --ramp-ms, then the W warmup steps the contract asks for, then
     # exactly K timed steps.  (local work only when not --strong -- the loop is time-based, so ranks may run different
     # numbers of iterations; --strong communicates per step, so there the ramp is a fixed number of steps)
-    if args.strong and world > 1:
+    if args.strong and dist_on:
         for _ in range(60):
             step()
         torch.cuda.synchronize()
@@ -397,10 +400,14 @@ def main() -> None:
             names = ["voigt", "conv", "mfma_loop", "epilogue", "wave_total"]
             print("stamps: waves=%d  " % st[5] + "  ".join("%s=%.0f" % (n, st[i] / st[5]) for i, n in enumerate(names)) + "  (cycles per wave)", file=sys.stderr)
 
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank holds every rank's evidences after the exchange: rank r's slots must equal its own
+        mine = gathered.view(world, -1)[rank]
+        if not torch.equal(torch.nan_to_num(mine), torch.nan_to_num(evidences)):
+            raise SystemExit("rank %d: the gathered evidences differ from the local ones" % rank)
 
     if rank == 0:
         total_evals = (float(S) if args.strong else evals_per_step * world) * steps
@@ -456,7 +463,7 @@ def main() -> None:
             line["cpu_baseline"] = baseline
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -66,6 +66,33 @@ SIGNATURES = {
 }
 
 _lib = None
+_hip = None
+
+
+def _preload_torch_hip_runtime() -> None:
+    """
+    One HIP runtime per process.  libdlagp_hip.so needs `libamdhip64.so.7`; PyTorch-ROCm bundles a runtime of its own
+    with that same SONAME (torch/lib/libamdhip64.so).  The dynamic loader binds the library to whichever copy is
+    already in the process: torch's when torch was imported first -- one runtime, torch streams and tensors can be
+    handed to the `*_device` entry points, RCCL and our kernels are ordered on the same streams -- but the system's
+    when the library was loaded first, after which `import torch` brings in a SECOND runtime (separate streams, no
+    ordering between them, and on this stack the second runtime to initialise does not see the GPU).  So whenever
+    torch is installed its runtime is mapped first, without importing torch.  DLAGP_HIP_RUNTIME=system opts out
+    (a process that never touches torch).
+    """
+    if os.environ.get("DLAGP_HIP_RUNTIME", "").lower() == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:  # no torch, a CPU-only torch, an unreadable install: the system runtime serves
+        pass
 
 
 def load():
@@ -77,15 +104,7 @@ def load():
                 "libdlagp_hip.so not found at {} -- build it with `make -C gpy_dla_detection_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback".format(LIB_PATH)
             )
-        # Two HIP runtimes can live in one process (torch bundles its own); the second one to initialise does not
-        # see the GPU.  RCCL runs inside torch's, so when torch is already imported its runtime goes first.
-        torch = sys.modules.get("torch")
-        if torch is not None and hasattr(torch, "cuda"):
-            try:
-                if torch.cuda.is_available() and not torch.cuda.is_initialized():
-                    torch.cuda.init()
-            except Exception:  # a CPU-only torch build, or no device: nothing to order
-                pass
+        _preload_torch_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)
@@ -93,6 +112,29 @@ def load():
             fn.argtypes = argtypes
         _lib = lib
     return _lib
+
+
+def hip_runtime():
+    """ctypes handle of the HIP runtime the library is bound to (tests allocate device memory through it)"""
+    global _hip
+    if _hip is None:
+        load()
+        _hip = ctypes.CDLL("libamdhip64.so.7")  # SONAME lookup: the copy already mapped, never a second one
+    return _hip
+
+
+def hip_runtime_copies():
+    """paths of the libamdhip64 copies mapped into this process (diagnostic: more than one is a set-up error)"""
+    seen = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.split()[-1]
+                if "libamdhip64" in path and path not in seen:
+                    seen.append(path)
+    except OSError:
+        pass
+    return seen
 
 
 def last_error() -> str:

@@ -307,6 +307,19 @@ struct LaunchGroup {
     }
 };
 
+// Every growth of a launch group's scratch goes through here.  The asynchronous entry points leave kernels in flight
+// on the caller's stream, and a buffer that is replaced goes back to a pool other contexts (other host threads) draw
+// from: the stream of the group's most recent launch is drained before a live buffer is let go (the stream rule of
+// include/dlagp.h: "a call that needs larger scratch drains that stream first").
+static int grow(LaunchGroup &g, DeviceBuffer &buf, size_t want) {
+    if (want <= buf.bytes) return DLAGP_OK;
+    if (buf.ptr && g.launched) {
+        HIP_TRY(hipStreamSynchronize(g.last_stream));
+        g.launched = false;  // nothing of this group is in flight any more
+    }
+    return buf.reserve(want);
+}
+
 // learned GP model resident on one device (state of NullGP.__init__, reference null_gp.py:35-71)
 struct dlagp_model {
     int device = 0;
@@ -469,7 +482,8 @@ static void choose_cut(long groups, double C, int64_t forced, int *full_out, dou
             frac = 1.0 / h;
         }
     }
-    const long f = slots / std::max<long>(groups, 1);
+    // at most 254 full pieces + the remainder: the finalize kernels count a block's pieces in a byte (`counts`)
+    const long f = std::min<long>(slots / std::max<long>(groups, 1), 254);
     if (forced <= 0 && f >= 1 && slots - f * groups > 0) {
         const long m = (groups + (slots - f * groups) - 1) / (slots - f * groups);
         const double F = (m * (C + o) - o) / (1.0 + (double)m * f);
@@ -529,6 +543,7 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
                 plan_passes(g.ctxs[b]->h_slot_pos, g.ctxs[b]->sl.ntaps, edge[j], edge[j + 1], passes);
                 cuts.push_back({b, 0, (int)cuts.size(), begin, (int)passes.size(), remainder && j == npieces - 1});
             }
+        if (cuts.size() > 255) return fail(DLAGP_EINVAL, "internal: %zu pieces per block exceed the byte-sized piece count", cuts.size());
         max_parts = std::max(max_parts, (int)cuts.size());
         for (long grp = 0; grp < ngroups; ++grp) {
             counts[b * ngroups + grp] = (unsigned char)cuts.size();
@@ -544,6 +559,18 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
     std::vector<WorkItem> items;
     items.reserve(pieces.size());
     for (const Piece &pc : pieces) items.push_back(WorkItem{pc.b, pc.group, pc.part, pc.pass_begin, pc.pass_end, 0, 0, 0});
+    // One plan per distinct (S, planner options): a by-sample run adds one per slice size, a tuning session one per
+    // option set.  Beyond kMaxPlans the cache starts over -- after draining the group's stream, since a launch in
+    // flight still reads its plan.
+    constexpr size_t kMaxPlans = 16;
+    if (g.plans.size() >= kMaxPlans) {
+        if (g.launched) {
+            HIP_TRY(hipStreamSynchronize(g.last_stream));
+            g.launched = false;
+        }
+        for (auto &kv : g.plans) kv.second->release();
+        g.plans.clear();
+    }
     std::unique_ptr<LaunchPlan> plan(new LaunchPlan());
     int rc = plan->passes.reserve(std::max<size_t>(1, passes.size()) * sizeof(PassDesc));
     if (!rc) rc = plan->items.reserve(std::max<size_t>(1, items.size()) * sizeof(WorkItem));
@@ -638,24 +665,32 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
     // partial sums: [piece][sightline x ceil(S/16) blocks][row_width columns][16 samples]
     const size_t nblocks = (size_t)nb * ((S + 15) / 16);
     const size_t part_bytes = (size_t)nparts * nblocks * g.row_width * 16 * sizeof(double);
-    // kernels enqueued earlier on this stream may still be using the buffer that a larger request replaces
-    if (ws.part.ptr && part_bytes > ws.part.bytes) HIP_TRY(hipStreamSynchronize(stream));
-    if ((rc = ws.part.reserve(part_bytes))) return rc;
-    if ((rc = ws.status.reserve(sizeof(int)))) return rc;
+    // kernels enqueued earlier may still be using the buffer that a larger request replaces: grow() drains them
+    if ((rc = grow(g, ws.part, part_bytes))) return rc;
+    if ((rc = grow(g, ws.status, sizeof(int)))) return rc;
     g.last_stream = stream;
     g.launched = true;
 
-    EventPair ev{};
+    // timing (option "timing"): a pair of events around the accumulate launch.  The pair joins the list that
+    // dlagp_timing_read reads only once both events have been recorded; any earlier exit destroys it.
+    struct TimingGuard {
+        EventPair ev{};
+        bool armed = false;
+        ~TimingGuard() {
+            if (!armed) return;
+            (void)hipEventDestroy(ev.start);
+            (void)hipEventDestroy(ev.stop);
+        }
+    } tg;
     const bool timing = g_opt_timing != 0;
     if (timing) {
-        HIP_TRY(hipEventCreate(&ev.start));
-        if (hipEventCreate(&ev.stop) != hipSuccess) {
-            (void)hipEventDestroy(ev.start);
+        HIP_TRY(hipEventCreate(&tg.ev.start));
+        if (hipEventCreate(&tg.ev.stop) != hipSuccess) {
+            (void)hipEventDestroy(tg.ev.start);
             return fail(DLAGP_EDEVICE, "hipEventCreate failed");
         }
-        std::lock_guard<std::mutex> lock(g_timing_mutex);
-        g_timing_events.push_back(ev);  // owned by the list from here on: dlagp_timing_read destroys them
-        HIP_TRY(hipEventRecord(ev.start, stream));
+        tg.armed = true;
+        HIP_TRY(hipEventRecord(tg.ev.start, stream));
     }
 
     g_last_launch_path = use_mfma ? 2 : 1;
@@ -696,7 +731,12 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
         HIP_TRY(hipGetLastError());
     }
 
-    if (timing) HIP_TRY(hipEventRecord(ev.stop, stream));
+    if (timing) {
+        HIP_TRY(hipEventRecord(tg.ev.stop, stream));
+        std::lock_guard<std::mutex> lock(g_timing_mutex);
+        g_timing_events.push_back(tg.ev);  // owned by the list from here on: dlagp_timing_read destroys them
+        tg.armed = false;
+    }
 
     if (g.k == DLAGP_FIN_K) {
         const size_t lds_bytes = DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double);
@@ -776,9 +816,9 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
     const long rows = (long)g.ctxs.size() * S;
     const size_t nsamp = (size_t)rows * (kd > 0 ? kd : 1);
     int rc;
-    if ((rc = ws.z.reserve(nsamp * sizeof(double)))) return rc;
-    if ((rc = ws.nhi.reserve(nsamp * sizeof(double)))) return rc;
-    if ((rc = ws.out.reserve((size_t)rows * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.z, nsamp * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.nhi, nsamp * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.out, (size_t)rows * sizeof(double)))) return rc;
     Transfers tr(ws.stage);
     if (kd > 0) {
         tr.upload(ws.z.ptr, z, nsamp * sizeof(double));
@@ -806,11 +846,13 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     const int nb = (int)g.ctxs.size();
     const size_t rows = (size_t)nb * S;
     int rc;
-    if ((rc = ws.level_ll.reserve(rows * sizeof(double)))) return rc;
-    if ((rc = ws.cdf.reserve(rows * sizeof(double)))) return rc;
-    if ((rc = ws.alive.reserve((size_t)(nb + 1) * sizeof(int)))) return rc;  // [nb] = sticky non-PD flag
+    if ((rc = grow(g, ws.level_ll, rows * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.cdf, rows * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.alive, (size_t)(nb + 1) * sizeof(int)))) return rc;  // [nb] = sticky non-PD flag
     const double nan = std::numeric_limits<double>::quiet_NaN();
     const long n_ll = (long)rows * max_dlas, n_base = (long)rows * (max_dlas - 1);
+    g.last_stream = stream;  // the fills below already use the group's scratch
+    g.launched = true;
     hipLaunchKernelGGL(fill_f64, dim3((unsigned)std::min<long>((n_ll + 255) / 256, 2048)), dim3(256), 0, stream,
                        d_sample_ll, n_ll, nan);
     hipLaunchKernelGGL(fill_f64, dim3(1), dim3(256), 0, stream, d_evidences, (long)nb * max_dlas, nan);
@@ -835,8 +877,8 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
             HIP_TRY(hipMemGetInfo(&free_b, &total_b));
             use_cache = want_bytes <= (size_t)g_opt_profile_cache_max_mb << 20 && want_bytes <= (free_b + have) / 2;
         }
-        if (use_cache && (rc = ws.cache.reserve(cache_bytes))) return rc;
-        if (use_cache && max_dlas > 2 && (rc = ws.running.reserve(cache_bytes))) return rc;
+        if (use_cache && (rc = grow(g, ws.cache, cache_bytes))) return rc;
+        if (use_cache && max_dlas > 2 && (rc = grow(g, ws.running, cache_bytes))) return rc;
     }
     g_last_sweep_cached = use_cache ? 1 : 0;
     if (use_cache) {
@@ -1304,10 +1346,11 @@ int dlagp_absorption(dlagp_ctx *ctx, int kd, const double *z, const double *nhi,
     int rc = check_eval_args(ctx, 1, kd, z, nhi, out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    Workspace &ws = ctx->self.ws;
-    if ((rc = ws.z.reserve(kd * sizeof(double)))) return rc;
-    if ((rc = ws.nhi.reserve(kd * sizeof(double)))) return rc;
-    if ((rc = ws.out.reserve((size_t)ctx->sl.n_pad * sizeof(double)))) return rc;
+    LaunchGroup &g = ctx->self;
+    Workspace &ws = g.ws;
+    if ((rc = grow(g, ws.z, kd * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.nhi, kd * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.out, (size_t)ctx->sl.n_pad * sizeof(double)))) return rc;
     HIP_TRY(hipMemcpy(ws.z.ptr, z, kd * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ws.nhi.ptr, nhi, kd * sizeof(double), hipMemcpyHostToDevice));
     const int lds_entries = std::max(ctx->sl.num_entries, ctx->sl.n_pad);
@@ -1465,12 +1508,12 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
     const size_t rows = nb * (size_t)S;
     const size_t n_nhi = nhi_stride ? (size_t)nhi_stride * (nb - 1) + S : (size_t)S;
     const size_t n_base = rows * (max_dlas - 1);
-    if ((rc = ws.z.reserve(rows * sizeof(double)))) return rc;
-    if ((rc = ws.nhi.reserve(n_nhi * sizeof(double)))) return rc;
-    if ((rc = ws.uniforms.reserve(std::max<size_t>(n_base, 1) * sizeof(double)))) return rc;
-    if ((rc = ws.evidences.reserve(nb * max_dlas * sizeof(double)))) return rc;
-    if ((rc = ws.sample_ll.reserve(rows * max_dlas * sizeof(double)))) return rc;
-    if ((rc = ws.base.reserve(std::max<size_t>(n_base, 1) * sizeof(int32_t)))) return rc;
+    if ((rc = grow(g, ws.z, rows * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.nhi, n_nhi * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.uniforms, std::max<size_t>(n_base, 1) * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.evidences, nb * max_dlas * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.sample_ll, rows * max_dlas * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.base, std::max<size_t>(n_base, 1) * sizeof(int32_t)))) return rc;
     Transfers tr(ws.stage);
     tr.upload(ws.z.ptr, sample_z, rows * sizeof(double));
     tr.upload(ws.nhi.ptr, sample_nhi, n_nhi * sizeof(double));
@@ -1652,6 +1695,9 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "pool_mb")) *value = g_opt_pool_mb;
     else if (!strcmp(name, "profile_cache")) *value = g_opt_profile_cache;
     else if (!strcmp(name, "profile_cache_max_mb")) *value = g_opt_profile_cache_max_mb;
+    else if (!strcmp(name, "plan_item_cost")) *value = g_opt_plan_item_cost;
+    else if (!strcmp(name, "plan_rest_first")) *value = g_opt_plan_rest_first;
+    else if (!strcmp(name, "plan_slots")) *value = g_opt_plan_slots;
     else if (!strcmp(name, "last_launch_path")) *value = g_last_launch_path;
     else if (!strcmp(name, "last_launch_items")) *value = g_last_launch_items;
     else if (!strcmp(name, "last_launch_parts")) *value = g_last_launch_parts;
@@ -1664,14 +1710,20 @@ int dlagp_get_option(const char *name, int64_t *value) {
 int dlagp_timing_read(double *total_ms, int64_t *launches, int reset) {
     std::lock_guard<std::mutex> lock(g_timing_mutex);
     double total = 0.0;
+    int64_t counted = 0;
     for (const EventPair &ev : g_timing_events) {
-        HIP_TRY(hipEventSynchronize(ev.stop));
+        // a pair that cannot be read (its stream was destroyed, a sticky device error) is skipped, never fatal:
+        // the list is still cleared below, so one bad pair cannot wedge every later read
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, ev.start, ev.stop));
+        if (hipEventSynchronize(ev.stop) != hipSuccess || hipEventElapsedTime(&ms, ev.start, ev.stop) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
         total += ms;
+        ++counted;
     }
     if (total_ms) *total_ms = total;
-    if (launches) *launches = (int64_t)g_timing_events.size();
+    if (launches) *launches = counted;
     if (reset) {
         for (const EventPair &ev : g_timing_events) {
             (void)hipEventDestroy(ev.start);

@@ -69,12 +69,17 @@ def gather_rows(local_rows: np.ndarray, total_rows: int, group=None, device=None
 
 
 def _require_torch_gpu(torch) -> None:
-    """RCCL needs torch's HIP runtime to own the GPU: it must have initialised before libdlagp_hip's"""
+    """RCCL runs inside torch's HIP runtime, which must be the one libdlagp_hip.so is bound to (`_lib.load`)"""
+    from . import _lib
+
     if not torch.cuda.is_available():
+        raise RuntimeError("the process group is `nccl` but torch sees no GPU")
+    copies = _lib.hip_runtime_copies()
+    if len(copies) > 1:
         raise RuntimeError(
-            "the process group is `nccl` but torch sees no GPU: initialise torch's HIP runtime (torch.cuda.init()) "
-            "before the first call into libdlagp_hip.so -- the second HIP runtime to start in a process does not see "
-            "the device (gpy_dla_detection_amd._lib.load() does this by itself when torch is already imported)")
+            "two HIP runtimes are mapped into this process (%s): launches of libdlagp_hip.so and RCCL collectives "
+            "would run on unrelated streams.  Load the library through gpy_dla_detection_amd._lib.load() without "
+            "DLAGP_HIP_RUNTIME=system so that it binds to torch's runtime" % ", ".join(copies))
 
 
 def sweep_sharded_samples(level_eval: Callable[[np.ndarray, np.ndarray], np.ndarray], sample_z: np.ndarray,
@@ -132,9 +137,17 @@ def sweep_sharded_samples_device(batch, sample_z: np.ndarray, sample_nhi: np.nda
     nb, S = sample_z.shape
     if max_dlas > 1 and (uniforms is None or uniforms.shape != (nb, max_dlas - 1, S)):
         raise ValueError("uniforms must be (nb, max_dlas - 1, S)")
-    distributed = world_size > 1 and slices is None
-    if distributed and dist.get_backend(group) == "nccl":
-        _require_torch_gpu(torch)
+    # with an initialised process group the collective runs even for a single rank (a one-GPU rehearsal of the
+    # RCCL calls); without one this is the single-process sweep
+    group_up = dist.is_available() and dist.is_initialized()
+    if world_size > 1 and not group_up and slices is None:
+        raise RuntimeError("world_size = %d needs an initialised torch.distributed process group" % world_size)
+    distributed = group_up and slices is None
+    if distributed:
+        if dist.get_world_size(group) != world_size or dist.get_rank(group) != rank:
+            raise ValueError("rank / world_size do not match the process group")
+        if dist.get_backend(group) == "nccl":
+            _require_torch_gpu(torch)
     dev = torch.device("cuda", batch.sightlines[0].device)
     f64 = dict(dtype=torch.float64, device=dev)
     d_z = torch.from_numpy(np.ascontiguousarray(sample_z, dtype=np.float64)).to(dev)

@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def free_port() -> int:
+    """a TCP port nobody listens on right now (two test runs on one host must not share a rendezvous port)"""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
@@ -45,16 +54,17 @@ def oracle_state(sight, num_lines=3, broadening=True):
 class HipBuffers:
     """
     Minimal device-memory helper for tests that pass HBM pointers through the C ABI: hipMalloc /
-    hipMemcpy from the HIP runtime the library itself is linked against (a second runtime in the
-    process -- e.g. the one bundled with torch, if torch were initialised after the library --
-    does not see the GPU).
+    hipMemcpy from the HIP runtime the library itself is bound to (`_lib.hip_runtime()`: one runtime
+    per process, see `_lib._preload_torch_hip_runtime`).
     """
 
     def __init__(self):
         import ctypes
 
+        from gpy_dla_detection_amd import _lib
+
         self.ct = ctypes
-        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip = _lib.hip_runtime()
         self.ptrs = []
 
     def to_device(self, array):

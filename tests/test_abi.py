@@ -61,3 +61,21 @@ def test_argument_errors_do_not_need_a_gpu():
         _lib.check(_lib.DLAGP_ELINALG)
     with pytest.raises(RuntimeError):
         _lib.check(_lib.DLAGP_EDEVICE)
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """
+    torch bundles a HIP runtime with the SONAME the library needs.  Whichever of the two is imported first, the process
+    must end up with ONE copy mapped (`_lib._preload_torch_hip_runtime`): with two, streams and RCCL collectives of
+    torch's runtime and the launches of libdlagp_hip.so are unordered with respect to each other.
+    """
+    import subprocess
+    import sys
+
+    pytest.importorskip("torch")
+    for order in ("from gpy_dla_detection_amd import _lib; _lib.load(); import torch",
+                  "import torch; from gpy_dla_detection_amd import _lib; _lib.load()"):
+        code = order + "; print(len(_lib.hip_runtime_copies())); print(_lib.hip_runtime()._name)"
+        res = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert res.stdout.split()[:2] == ["1", "libamdhip64.so.7"], (order, res.stdout)

@@ -1328,6 +1328,53 @@ def test_async_launches_survive_scratch_growth_and_destroy():
     members[1].close()
 
 
+def test_async_device_sweeps_survive_growth_of_every_scratch_buffer():
+    """
+    The same stream rule for the multi-level device sweep (dlagp_batch_sweep_device): its per-level likelihoods, cdf
+    scratch, alive flags, profile cache and running products all grow with S, and every growth drains the launches
+    queued before it (one helper, `grow`, dlagp_hip.hip) -- back-to-back asynchronous sweeps with a growing sample
+    count on a non-blocking stream give the results of synchronous sweeps on fresh batches.
+    """
+    import torch
+
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    dev = torch.device("cuda", 0)
+    sights = [make_sightline(3, n_unmasked=700, n_masked=13), make_sightline(5, n_unmasked=640, n_masked=40)]
+    sizes = (96, 1500, 400, 5000, 5000)
+    max_dlas, min_sep = 3, 0.01
+    nhi_all = make_qmc_samples(sights[0], max(sizes))[2]
+    z_all = np.stack([make_qmc_samples(s, max(sizes))[0] for s in sights])
+    want = {}
+    for S in set(sizes):
+        fresh = DeviceBatch([device_sightline(s) for s in sights])
+        want[S] = fresh.sweep(z_all[:, :S], nhi_all[:S], max_dlas, min_sep, parallel.resampling_uniforms(2, max_dlas, S, seed=0))
+        fresh.close()
+    batch = DeviceBatch([device_sightline(s) for s in sights])
+    stream = torch.cuda.Stream(device=dev)
+    held = []
+    for S in sizes:  # inputs first: the sweeps below are then enqueued back to back
+        f64 = dict(dtype=torch.float64, device=dev)
+        held.append(dict(
+            S=S, z=torch.from_numpy(np.ascontiguousarray(z_all[:, :S])).to(dev), nhi=torch.from_numpy(nhi_all[:S].copy()).to(dev),
+            u=torch.from_numpy(parallel.resampling_uniforms(2, max_dlas, S, seed=0)).to(dev),
+            ev=torch.full((2, max_dlas), float("nan"), **f64), ll=torch.full((2, max_dlas, S), float("nan"), **f64),
+            base=torch.zeros((2, max_dlas - 1, S), dtype=torch.int32, device=dev)))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        for h in held:
+            batch.sweep_device(h["S"], max_dlas, h["z"].data_ptr(), h["nhi"].data_ptr(), 0, min_sep, h["u"].data_ptr(),
+                               h["ev"].data_ptr(), h["ll"].data_ptr(), h["base"].data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    for h in held:
+        ev, ll, base = want[h["S"]]
+        np.testing.assert_array_equal(h["base"].cpu().numpy(), base)
+        np.testing.assert_allclose(h["ev"].cpu().numpy(), ev, rtol=1e-12)
+        np.testing.assert_allclose(h["ll"].cpu().numpy().transpose(0, 2, 1), ll, rtol=1e-12, equal_nan=True)
+    batch.close()
+
+
 def test_device_entry_points_are_graph_capturable():
     """
     dlagp_eval_device + dlagp_level_evidence_device only enqueue work on the caller's stream once the workspace

@@ -16,7 +16,7 @@ from gpy_dla_detection_amd.dla_gp import occupation_sweep
 from gpy_dla_detection_amd.samples import halton
 from gpy_dla_detection_amd.set_parameters import Parameters
 from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline
-from tests.conftest import REPO, load_golden, oracle_state
+from tests.conftest import REPO, free_port, load_golden, oracle_state
 from tests.golden_inputs import checksum, raw_spectrum_and_model
 
 
@@ -184,7 +184,7 @@ def test_sharded_evidences_gloo_world_size_2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)]
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)]
     res = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     got0 = np.load(tmp_path / "rank0.npy")
@@ -447,3 +447,18 @@ def test_work_decomposition_model():
             assert full >= 1 and 0.0 < frac <= 1.0 and full * frac <= 1.0 + 1e-12, (groups, chunks, full, frac)
     with pytest.raises(ValueError):
         cut(0, 10)
+    # A block's piece count travels to the finalisation in a byte: however many wave slots the planner is told to
+    # fill and however long the sightline, at most 254 full pieces + a remainder.  The planner options read back.
+    value = ctypes.c_int64()
+    try:
+        _lib.check(lib.dlagp_set_option(b"plan_slots", 1 << 20))
+        _lib.check(lib.dlagp_get_option(b"plan_slots", ctypes.byref(value)))
+        assert value.value == 1 << 20
+        for groups, chunks in ((3, 400000), (1, 1 << 20), (17, 90000), (625, 375)):
+            full, frac = cut(groups, chunks)
+            assert 1 <= full <= 254 and full * frac <= 1.0 + 1e-12, (groups, chunks, full, frac)
+    finally:
+        _lib.check(lib.dlagp_set_option(b"plan_slots", 2048))
+    for name, default in ((b"plan_slots", 2048), (b"plan_item_cost", 20), (b"plan_rest_first", 0)):
+        _lib.check(lib.dlagp_get_option(name, ctypes.byref(value)))
+        assert value.value == default, name

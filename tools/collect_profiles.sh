@@ -1,9 +1,11 @@
 #!/bin/bash
 # On the GPU box: everything profiles/rNN_* is made of, into gpurun_out/collect_<tag>/.  usage: tools/collect_profiles.sh r02
+set -u
 tag=${1:-run}
-out=gpurun_out/collect_$tag
-mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+root=${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun exports GRAFT_REPO_ROOT)}
+out=$root/gpurun_out/collect_$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp && cd "$root"
 python3 bench.py > $out/bench.json 2> $out/bench.err
 for c in 3 4 5; do python3 bench.py --config $c > $out/bench_config$c.json 2>> $out/bench.err; done
 python3 bench.py --strong --no-cpu-baseline > $out/bench_strong_n1.json 2>> $out/bench.err

@@ -3,7 +3,7 @@
 # One rocprofv3 counter pass (own run, kernel trace only), then a per-kernel mean of every counter.
 set -e
 out=$1; counters=$2; shift 3
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?run this on the GPU box}"
 mkdir -p "$out"
 rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$out" -- "$@" > "$out/run.log" 2>&1
 python3 - "$out" <<'PY'
