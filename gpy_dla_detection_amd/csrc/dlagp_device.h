@@ -54,6 +54,10 @@ struct SightlineDev {
     const double *Pm;      // [nsteps_m][8 pairs][64][2] MFMA operand, see build_mfma_operand
     const double *aux;     // [n_slots][8] per-slot records {y, mu, omega2, v, pos, 0, 0, 0}
     double taps[DLAGP_NUM_TAPS];  // instrument profile (or {1, 0, ...})
+    // Position of this sightline in the CALLER's arrays (samples in, log-likelihoods out).  Equal to its position in
+    // the launch's descriptor table except when a batch that mixes line counts / broadening / Lyman-limit flags
+    // runs as several homogeneous launches, each over a subset of the members (dlagp_hip.hip, LaunchGroup::parts).
+    int batch_index;
 };
 
 // Where a launch finds the absorber parameters of sample (sightline b, sample s, absorber j).

@@ -81,6 +81,7 @@ static Option g_last_launch_items = 0;   // work items (waves) of the last MFMA 
 static Option g_last_launch_parts = 0;   // most pieces a block of 16 samples was cut into
 static Option g_last_sweep_cached = 0;   // the last multi-level sweep used the profile cache
 static Option g_last_launch_patch = 0;   // core handling of the last MFMA launch (patch_mode: 0 in loop, 1, 2)
+static Option g_last_launch_groups = 1;  // homogeneous launch groups the last call ran as (> 1: a batch of mixed flavours)
 
 struct EventPair {
     hipEvent_t start, stop;
@@ -295,11 +296,25 @@ struct LaunchGroup {
     // key: (S, and the planner options in force: forced split count, item cost, dispatch order, slot count)
     typedef std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t> PlanKey;
     std::map<PlanKey, std::unique_ptr<LaunchPlan>> plans;
+    // A batch whose members differ in line count, broadening or Lyman-limit flag cannot share one instantiation of
+    // the MFMA kernel.  Instead of sending all of them to the generic kernel (21x slower) it runs as several
+    // homogeneous launch groups over subsets of its members, every kernel reading samples and writing results at
+    // the member's position in the caller's arrays (SightlineDev::batch_index).  Empty for a homogeneous batch.
+    // This group then keeps the scratch that spans all members (staging, per-level likelihoods, the shared non-PD
+    // flag); the parts keep their own partial sums, launch plans and profile caches.
+    std::vector<std::unique_ptr<LaunchGroup>> parts;
+    // kernels in flight on the group's (and its parts') most recent stream are done on return
+    void drain() {
+        if (launched) (void)hipStreamSynchronize(last_stream);
+        launched = false;
+        for (auto &p : parts) p->drain();
+    }
     void release() {
         // asynchronous entry points may have left kernels in flight that still use these buffers, and released
         // buffers go back to a pool other contexts draw from
-        if (launched) (void)hipStreamSynchronize(last_stream);
-        launched = false;
+        drain();
+        for (auto &p : parts) p->release();
+        parts.clear();
         d_table.release();
         ws.release();
         for (auto &kv : plans) kv.second->release();
@@ -593,7 +608,7 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
 #define DLAGP_LAUNCH_MFMA(...)                                                                                     \
     hipLaunchKernelGGL((accumulate_mfma<__VA_ARGS__>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream, table,     \
                        plan->passes.as<const PassDesc>(), plan->items.as<const WorkItem>(), nb, S, kd, src, part, \
-                       status, (int)g_opt_debug)
+                       status, launch_flags)
 
 // how the line cores are handled (kernels_mfma.h): 0 tested for inside the sample loop; 1 one absorber per sample,
 // repaired once per wave; 2 several absorbers per sample, repaired pass by pass.  1 and 2 need three lines and a
@@ -606,7 +621,7 @@ static int patch_mode(const LaunchGroup &g, int kd) {
 template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, const LaunchPlan *plan, int nb,
                         long S, int kd, int num_lines, const SampleSource &src, double *part, int *status,
-                        int patch, bool lls) {
+                        int patch, bool lls, int launch_flags) {
     // 16 samples + one spare row that the look-ahead of the sample loop may read; PATCH 2: 3 ints per (sample, absorber)
     const size_t prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * kd * (lls ? 6 : (LINES > 0 ? LINES : num_lines) + 1) * sizeof(double) +
                             (patch == 2 ? (size_t)DLAGP_MFMA_GROUP * kd * 3 * sizeof(int) : 0);
@@ -644,8 +659,11 @@ static bool mfma_path_serves(const LaunchGroup &g, int kd, bool cached = false) 
     return g.mfma_ok && kd >= 1 && mfma_prep_lds <= 40 * 1024 && g_opt_path != 1;
 }
 
-static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &src, double *d_out,
-                        hipStream_t stream) {
+// One homogeneous launch group: accumulate + finalize.  `status`: the non-PD flag the finalisation raises (the
+// group's own unless the caller shares one between the parts of a heterogeneous batch); `keep_status`: this launch
+// must not clear it (an earlier part of the same level may have raised it).
+static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src, double *d_out, hipStream_t stream,
+                      int *status_shared = nullptr, bool keep_status = false) {
     if (S <= 0) return DLAGP_OK;
     Workspace &ws = g.ws;
     const int nb = (int)g.ctxs.size();
@@ -693,6 +711,7 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
         HIP_TRY(hipEventRecord(tg.ev.start, stream));
     }
 
+    int *status = status_shared ? status_shared : ws.status.as<int>();
     g_last_launch_path = use_mfma ? 2 : 1;
     if (use_mfma) {
         g_last_launch_items = plan->nitems;
@@ -703,16 +722,16 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
         g_last_launch_patch = patch;
         const bool lls = g.lls_break;
         double *part = ws.part.as<double>();
-        int *status = ws.status.as<int>();
+        const int launch_flags = keep_status ? DLAGP_LAUNCH_KEEP_STATUS : 0;
         if (src.cache_mode == 2) {
             const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * sizeof(double);
             DLAGP_LAUNCH_MFMA(3, true, false, 2);
         } else if (g.broadening) {
-            if (lines3) launch_mfma<3, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls);
-            else launch_mfma<0, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false);
+            if (lines3) launch_mfma<3, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags);
+            else launch_mfma<0, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags);
         } else {
-            if (lines3) launch_mfma<3, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls);
-            else launch_mfma<0, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false);
+            if (lines3) launch_mfma<3, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags);
+            else launch_mfma<0, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags);
         }
         HIP_TRY(hipGetLastError());
     } else {
@@ -727,7 +746,7 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         dim3 grid((unsigned)S, (unsigned)nb);
         hipLaunchKernelGGL(accumulate_generic, grid, dim3(DLAGP_GENERIC_THREADS), lds_bytes, stream, table, (long)S,
-                           kd, src, ws.part.as<double>(), ws.status.as<int>(), lds_entries, lds_pixels);
+                           kd, src, ws.part.as<double>(), status, lds_entries, lds_pixels, keep_status ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
 
@@ -742,15 +761,33 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
         const size_t lds_bytes = DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double);
         hipLaunchKernelGGL(finalize_rank20, dim3((unsigned)nblocks),
                            dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
-                           ws.part.as<double>(), nparts, rows, (long)S, table, d_out, ws.status.as<int>(),
+                           ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
                            plan ? plan->counts.as<const unsigned char>() : nullptr);
     } else {
         const int threads = DLAGP_FINALIZE_THREADS;
         hipLaunchKernelGGL(finalize_samples<0>, dim3((unsigned)((rows + threads - 1) / threads)), dim3(threads), 0,
-                           stream, ws.part.as<double>(), nparts, rows, (long)S, table, d_out, ws.status.as<int>(),
+                           stream, ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
                            plan ? plan->counts.as<const unsigned char>() : nullptr);
     }
     HIP_TRY(hipGetLastError());
+    return DLAGP_OK;
+}
+
+// The launch group itself, or -- for a batch that mixes kernel flavours -- its homogeneous parts one after the other
+// on the same stream, all raising the one non-PD flag of `g`.
+static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &src, double *d_out,
+                        hipStream_t stream) {
+    g_last_launch_groups = g.parts.empty() ? 1 : (int64_t)g.parts.size();
+    if (g.parts.empty() || kd == 0 || S <= 0) return launch_one(g, S, kd, src, d_out, stream);  // kd == 0: null model, generic kernel anyway
+    int rc = grow(g, g.ws.status, sizeof(int));
+    if (rc) return rc;
+    g.last_stream = stream;
+    g.launched = true;
+    bool first = true;
+    for (auto &p : g.parts) {
+        if ((rc = launch_one(*p, S, kd, src, d_out, stream, g.ws.status.as<int>(), !first))) return rc;
+        first = false;
+    }
     return DLAGP_OK;
 }
 
@@ -862,36 +899,60 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
         hipLaunchKernelGGL(fill_i32, dim3((unsigned)std::min<long>((n_base + 255) / 256, 2048)), dim3(256), 0, stream,
                            d_base, n_base, 0);
     HIP_TRY(hipGetLastError());
-    SampleSource src{d_sample_z, d_sample_nhi, d_base, 1, (long)nhi_stride, max_dlas - 1, nullptr, nullptr, 0, 0, 0, 0, 0};
+    const SampleSource src0{d_sample_z, d_sample_nhi, d_base, 1, (long)nhi_stride, max_dlas - 1, nullptr, nullptr, 0, 0, 0, 0, 0};
+    // the homogeneous launch groups of this sweep: the batch itself, or the parts of a batch of mixed flavours
+    struct Target {
+        LaunchGroup *g;
+        SampleSource src;
+        bool use_cache;
+    };
+    std::vector<Target> targets;
+    if (g.parts.empty()) targets.push_back({&g, src0, false});
+    else for (auto &p : g.parts) targets.push_back({p.get(), src0, false});
+    g_last_launch_groups = (int64_t)targets.size();
+    if (!g.parts.empty() && (rc = grow(g, ws.status, sizeof(int)))) return rc;  // the parts share this group's flag
     // Profile cache: every absorber of every level is one of the sightline's S QMC points, whose convolved
     // profile level 1 computes anyway.  Keeping them (8 S n_pad bytes per sightline) turns the Voigt work of
     // levels 2..max_dlas into HBM reads -- capacity traded for time on the shared FP64 pipe.
-    bool use_cache = g_opt_profile_cache != 0 && max_dlas > 1;
-    for (int level = 0; level < max_dlas; ++level) use_cache = use_cache && mfma_path_serves(g, level + 1, level > 0);
-    const size_t cache_bytes = rows * (size_t)g.max_slots * sizeof(double);
-    const size_t want_bytes = cache_bytes * (max_dlas > 2 ? 2 : 1);  // profiles + running products
-    if (use_cache) {
-        const size_t have = ws.cache.bytes + ws.running.bytes;
-        if (have < want_bytes) {
-            size_t free_b = 0, total_b = 0;
-            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            use_cache = want_bytes <= (size_t)g_opt_profile_cache_max_mb << 20 && want_bytes <= (free_b + have) / 2;
+    bool all_cached = true;
+    for (Target &t : targets) {
+        LaunchGroup &tg = *t.g;
+        Workspace &tws = tg.ws;
+        bool use_cache = g_opt_profile_cache != 0 && max_dlas > 1;
+        for (int level = 0; level < max_dlas; ++level) use_cache = use_cache && mfma_path_serves(tg, level + 1, level > 0);
+        const size_t cache_bytes = tg.ctxs.size() * (size_t)S * (size_t)tg.max_slots * sizeof(double);
+        const size_t want_bytes = cache_bytes * (max_dlas > 2 ? 2 : 1);  // profiles + running products
+        if (use_cache) {
+            const size_t have = tws.cache.bytes + tws.running.bytes;
+            if (have < want_bytes) {
+                size_t free_b = 0, total_b = 0;
+                HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+                use_cache = want_bytes <= (size_t)g_opt_profile_cache_max_mb << 20 && want_bytes <= (free_b + have) / 2;
+            }
+            if (use_cache && (rc = grow(tg, tws.cache, cache_bytes))) return rc;
+            if (use_cache && max_dlas > 2 && (rc = grow(tg, tws.running, cache_bytes))) return rc;
         }
-        if (use_cache && (rc = grow(g, ws.cache, cache_bytes))) return rc;
-        if (use_cache && max_dlas > 2 && (rc = grow(g, ws.running, cache_bytes))) return rc;
+        t.use_cache = use_cache;
+        all_cached = all_cached && use_cache;
+        if (use_cache) {
+            t.src.cache = tws.cache.as<double>();
+            t.src.running = tws.running.as<double>();
+            t.src.cache_stride = tg.max_slots;
+        }
     }
-    g_last_sweep_cached = use_cache ? 1 : 0;
-    if (use_cache) {
-        src.cache = ws.cache.as<double>();
-        src.running = ws.running.as<double>();
-        src.cache_stride = g.max_slots;
-    }
+    g_last_sweep_cached = all_cached ? 1 : 0;
     for (int level = 0; level < max_dlas; ++level) {
-        src.cache_mode = use_cache ? (level == 0 ? 1 : 2) : 0;
-        src.cache_write = use_cache && level >= 1 && level + 1 < max_dlas;
-        if ((rc = launch_sweep(g, S, level + 1, src, ws.level_ll.as<double>(), stream))) return rc;
+        bool first = true;
+        for (Target &t : targets) {
+            t.src.cache_mode = t.use_cache ? (level == 0 ? 1 : 2) : 0;
+            t.src.cache_write = t.use_cache && level >= 1 && level + 1 < max_dlas;
+            if (g.parts.empty()) rc = launch_one(g, S, level + 1, t.src, ws.level_ll.as<double>(), stream);
+            else rc = launch_one(*t.g, S, level + 1, t.src, ws.level_ll.as<double>(), stream, ws.status.as<int>(), !first);
+            if (rc) return rc;
+            first = false;
+        }
         hipLaunchKernelGGL(level_finish, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS), 0, stream,
-                           ws.level_ll.as<const double>(), (long)S, level, max_dlas, src, min_z_separation, d_uniforms,
+                           ws.level_ll.as<const double>(), (long)S, level, max_dlas, src0, min_z_separation, d_uniforms,
                            d_sample_ll, d_evidences, d_base, ws.cdf.as<double>(), ws.alive.as<int>(), ws.status.as<const int>(),
                            ws.alive.as<int>() + nb);
         HIP_TRY(hipGetLastError());
@@ -920,8 +981,9 @@ static int upload_now(void *dst, const void *src, size_t bytes, hipStream_t stre
     return DLAGP_OK;
 }
 
-// fill the group-level summary from its members and upload the descriptor table
-static int finish_group(LaunchGroup &g) {
+// fill the group-level summary from its members and upload the descriptor table; `positions`: where each member
+// sits in the caller's arrays (a part of a heterogeneous batch), default 0, 1, 2, ...
+static int finish_group(LaunchGroup &g, const std::vector<int> *positions = nullptr) {
     std::vector<SightlineDev> table;
     g.k = g.ctxs[0]->sl.k;
     g.row_width = g.ctxs[0]->sl.row_width;
@@ -935,6 +997,7 @@ static int finish_group(LaunchGroup &g) {
         lls_mixed = lls_mixed || (ctx->sl.lls_break != 0) != g.lls_break;
         g.grid_uniform = g.grid_uniform && ctx->sl.grid_uniform;
         table.push_back(ctx->sl);
+        table.back().batch_index = positions ? (*positions)[table.size() - 1] : (int)table.size() - 1;
         g.max_entries = std::max(g.max_entries, ctx->sl.num_entries);
         g.max_npad = std::max(g.max_npad, ctx->sl.n_pad);
         g.max_slots = std::max(g.max_slots, ctx->sl.n_slots);
@@ -945,6 +1008,30 @@ static int finish_group(LaunchGroup &g) {
     int rc = g.d_table.reserve(table.size() * sizeof(SightlineDev));
     if (rc) return rc;
     return upload_now(g.d_table.ptr, table.data(), table.size() * sizeof(SightlineDev), setup_stream(g.device));
+}
+
+// A batch whose members could each run the MFMA kernel but differ in line count, broadening or Lyman-limit flag:
+// one homogeneous launch group per flavour (LaunchGroup::parts), members in the caller's order within each.
+static int split_mixed_batch(LaunchGroup &g) {
+    if (g.mfma_ok) return DLAGP_OK;
+    for (const dlagp_ctx *ctx : g.ctxs)
+        if (!ctx->mfma_ok) return DLAGP_OK;  // rank above 20: the generic kernel serves the whole batch
+    typedef std::tuple<int, int, int> Flavour;  // line count, taps, Lyman-limit flag
+    std::map<Flavour, std::vector<int>> members;
+    for (size_t b = 0; b < g.ctxs.size(); ++b) {
+        const SightlineDev &sl = g.ctxs[b]->sl;
+        members[Flavour(sl.num_lines, sl.ntaps, sl.lls_break)].push_back((int)b);
+    }
+    if (members.size() < 2) return DLAGP_OK;
+    for (const auto &kv : members) {
+        std::unique_ptr<LaunchGroup> part(new LaunchGroup());
+        part->device = g.device;
+        for (int b : kv.second) part->ctxs.push_back(g.ctxs[b]);
+        int rc = finish_group(*part, &kv.second);
+        if (rc) return rc;
+        g.parts.push_back(std::move(part));
+    }
+    return DLAGP_OK;
 }
 
 // Everything of context creation that does not depend on where the model arrays come from:
@@ -1269,10 +1356,12 @@ void dlagp_destroy(dlagp_ctx *ctx) {
         // batches are meant to be destroyed before their members; if one is still alive, its launches may be using
         // this context's arrays
         std::lock_guard<std::mutex> lock(g_membership_mutex);
-        for (dlagp_batch *batch : ctx->batches)
-            if (batch->group.launched) (void)hipStreamSynchronize(batch->group.last_stream);
-        for (dlagp_batch *batch : ctx->batches)  // and it must not touch the context again
+        for (dlagp_batch *batch : ctx->batches) batch->group.drain();
+        for (dlagp_batch *batch : ctx->batches) {  // and it must not touch the context again
             std::replace(batch->group.ctxs.begin(), batch->group.ctxs.end(), ctx, (dlagp_ctx *)nullptr);
+            for (auto &part : batch->group.parts)
+                std::replace(part->ctxs.begin(), part->ctxs.end(), ctx, (dlagp_ctx *)nullptr);
+        }
     }
     ctx->self.release();  // drains the stream of the last asynchronous launch
     ctx->y.release();
@@ -1404,6 +1493,7 @@ int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
         for (dlagp_ctx *ctx : batch->group.ctxs) ctx->batches.push_back(batch);
     }
     int rc = finish_group(batch->group);
+    if (!rc) rc = split_mixed_batch(batch->group);
     if (rc) {
         dlagp_batch_destroy(batch);
         return rc;
@@ -1416,7 +1506,7 @@ void dlagp_batch_destroy(dlagp_batch *batch) {
     if (!batch) return;
     (void)hipSetDevice(batch->group.device);
     // the workspace goes to the next batch, which may launch on another stream
-    if (batch->group.launched) (void)hipStreamSynchronize(batch->group.last_stream);
+    batch->group.drain();
     {
         std::lock_guard<std::mutex> lock(g_membership_mutex);
         for (dlagp_ctx *ctx : batch->group.ctxs)
@@ -1703,6 +1793,7 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "last_launch_parts")) *value = g_last_launch_parts;
     else if (!strcmp(name, "last_sweep_cached")) *value = g_last_sweep_cached;
     else if (!strcmp(name, "last_launch_patch")) *value = g_last_launch_patch;
+    else if (!strcmp(name, "last_launch_groups")) *value = g_last_launch_groups;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 }

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
         result = __builtin_nan("");
         atomicOr(status, 1);
     }
-    out[row] = result;
+    out[sl.batch_index * S + smp] = result;  // the caller's row of this sightline
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     const long block = blockIdx.x;
     if (part_counts) nsplit = part_counts[block];  // pieces this block's pixels were cut into (work items, dlagp_hip.hip)
     const long b = block / ngroups, g = block % ngroups;
-    const long row0 = b * S + g * NS;          // first output row of this workgroup
+    const long row0 = sightlines[b].batch_index * S + g * NS;  // first output row of this workgroup (the caller's arrays)
     const int valid = (int)((S - g * NS) < NS ? (S - g * NS) : NS);
     const SightlineDev &sl = sightlines[b];
     const int rw = sl.row_width;

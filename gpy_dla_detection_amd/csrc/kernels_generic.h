@@ -74,18 +74,18 @@ __device__ __forceinline__ double block_sum(double x, double *red) {
 // grid: (S, nb).  Dynamic LDS: (num_entries + n_pad + MAX_LINES + 8) doubles (max over sightlines).
 __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
     const SightlineDev *__restrict__ sightlines, long S, int kd, SampleSource src, double *__restrict__ part,
-    int *__restrict__ status, int lds_entries, int lds_pixels) {
+    int *__restrict__ status, int lds_entries, int lds_pixels, int keep_status) {
     extern __shared__ double lds[];
     double *raw = lds;
     double *a = raw + lds_entries;
     double *mult = a + lds_pixels;
     double *red = mult + DLAGP_MAX_LINES + 1;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *status = 0;  // finalize raises it
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && !keep_status) *status = 0;  // finalize raises it
 
     const SightlineDev &sl = sightlines[blockIdx.y];
     const int tid = threadIdx.x;
 
-    sample_absorption(sl, kd, src, blockIdx.y, blockIdx.x, S, raw, a, mult);
+    sample_absorption(sl, kd, src, sl.batch_index, blockIdx.x, S, raw, a, mult);
 
     // phase B: per-pixel weights; w overwrites raw[], q overwrites a[]
     double *w = raw;

@@ -61,6 +61,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define DLAGP_MAX_PASS_CHUNKS (DLAGP_MAX_PASS_STEPS / DLAGP_CHUNK_STEPS)
 #define DLAGP_AUX_FIELDS 8       // per-pixel record: y, mu, omega2, v, window start, 3 spare
 #define DLAGP_BUFFER_FLAGS 0x00020000  // word 3 of a raw buffer resource on gfx9-family targets
+#define DLAGP_LAUNCH_KEEP_STATUS 0x10000  // launch_flags: do not clear the non-PD flag (see accumulate_mfma)
 
 struct PassDesc {
     int entry_start;  // first entry computed by phase 1
@@ -263,7 +264,7 @@ template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, int PATCH = 0, boo
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *__restrict__ passes,
     const WorkItem *__restrict__ items, int nb, long S, int kd,
-    SampleSource src, double *__restrict__ part, int *__restrict__ status, int debug_flags) {
+    SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags) {
     constexpr bool CACHED = MODE == 2;
     constexpr int A_STRIDE = 4 * DLAGP_MAX_PASS_STEPS + 2;  // 58: stride/2 odd -> conflict-free b64 reads
     __shared__ double raw[16 * DLAGP_RAW_STRIDE];
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     static_assert(!LLS || LINES == 3, "the Lyman-limit term is implemented in the 3-line sample loop");
     typedef double v4d_a16 __attribute__((ext_vector_type(4), aligned(16)));
 
-    if (blockIdx.x == 0 && threadIdx.x == 0) *status = 0;  // finalize raises it
+    // finalize raises it; a later launch of a heterogeneous batch's level leaves the flag of the earlier ones alone
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !(launch_flags & DLAGP_LAUNCH_KEEP_STATUS)) *status = 0;
 #ifdef DLAGP_TRACE_BUILD
     const unsigned long long trace_start = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const WorkItem &item = items[blockIdx.x];
     const int b = __builtin_amdgcn_readfirstlane(item.b);
     const SightlineDev &sl = sightlines[b];
+    const long gb = sl.batch_index;  // this sightline's position in the caller's sample arrays
     const int split = __builtin_amdgcn_readfirstlane(item.part);
     const long group = __builtin_amdgcn_readfirstlane(item.group);
     const int lane = threadIdx.x;
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         if (lane < 16) {
             long smp = sample0 + lane;
             smp = smp < S ? smp : S - 1;
-            row_lds[lane] = (int)sample_point(src, b, smp, kd - 1, S, kd);
+            row_lds[lane] = (int)sample_point(src, gb, smp, kd - 1, S, kd);
         }
         lds_wave_sync();
     }
@@ -337,12 +340,12 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         long smp = sample0 + sample_abs / kd;
         smp = smp < S ? smp : S - 1;
         const int j = sample_abs % kd;
-        const double zj = sample_z(src, b, smp, j, S, kd);
+        const double zj = sample_z(src, gb, smp, j, S, kd);
         double value;
         if (which < L) {
             value = line_multiplier(which, zj) * DLAGP_LINES.inv_sqrt2_sigma;
         } else if (which == L) {
-            value = sample_nhi(src, b, smp, j, S, kd) * 1.44269504088896338700e+00;
+            value = sample_nhi(src, gb, smp, j, S, kd) * 1.44269504088896338700e+00;
         } else if (which == L + 1) {
             // (lambda / (1 + z) / limit)^3 / 10^17.2 = (lambda * value)^3
             value = 1.8478497974222906e-06 /* 10^(-17.2/3) */ / ((1.0 + zj) * DLAGP_LYMAN_LIMIT_ANGSTROM);
@@ -453,7 +456,6 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
 
     // compile-time switch: the stamp accumulators would otherwise hold ~12 SGPRs in production too
     constexpr bool stamps = STAMPS;
-    (void)debug_flags;
     unsigned long long t_voigt = 0, t_conv = 0, t_mfma = 0, t_mark = 0, t_start = 0;
     if (stamps) t_start = stamp_now();
 

@@ -296,6 +296,78 @@ def test_batch_equals_single_sightline_launches():
         np.testing.assert_allclose(got[b], dev.eval(zs[b], ns[b]), rtol=1e-13)
 
 
+def test_batch_of_mixed_flavours_runs_as_homogeneous_mfma_groups(restore_options):
+    """
+    A batch whose members differ in line count, broadening or Lyman-limit flag used to send ALL of them to the
+    generic kernel (4.7 % of peak).  It now runs as one MFMA launch group per flavour, every kernel reading samples
+    and writing results at the member's position in the caller's arrays: same numbers as member-by-member launches
+    (per-sample likelihoods with one and two absorbers, the multi-level device sweep with and without the profile
+    cache, the by-sample slices), MFMA kernel throughout, and a non-PD member of ANY group still surfaces as LinAlgError.
+    """
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch, DeviceSightline, get_option, set_option
+
+    sights = [make_sightline(i, n_unmasked=n_u, n_masked=m) for i, (n_u, m) in
+              enumerate([(300, 5), (411, 0), (257, 30), (333, 7), (290, 3), (350, 11)])]
+    flavours = [dict(), dict(broadening=False), dict(num_lines=5), dict(lls_break=True), dict(), dict(broadening=False)]
+    devs = [device_sightline(s, **f) for s, f in zip(sights, flavours)]
+    S = 150
+    zs, ns = [], []
+    for s in sights:
+        z, _, nhi = make_qmc_samples(s, S)
+        zs.append(z)
+        ns.append(nhi)
+    zs, ns = np.stack(zs), np.stack(ns)
+    batch = DeviceBatch(devs)
+    set_option("path", 2)  # refuse the generic kernel
+    got1 = batch.eval(zs, ns)
+    assert get_option("last_launch_groups") == 4 and get_option("last_launch_path") == 2
+    z2, n2 = np.stack([zs, zs[:, ::-1]], axis=2), np.stack([ns, ns[:, ::-1]], axis=2)
+    got2 = batch.eval(z2, n2)
+    set_option("path", 0)
+    np.testing.assert_allclose(batch.nulls(), [d.null() for d in devs], rtol=1e-14)
+    for b, dev in enumerate(devs):
+        np.testing.assert_allclose(got1[b], dev.eval(zs[b], ns[b]), rtol=1e-13)
+        np.testing.assert_allclose(got2[b], dev.eval(z2[b], n2[b]), rtol=1e-13)
+    # the generic kernel agrees (independent evaluation of every flavour)
+    set_option("path", 1)
+    np.testing.assert_allclose(batch.eval(zs, ns), got1, rtol=1e-10)
+    set_option("path", 0)
+    # multi-level sweep on the device: equal to each member swept alone, cache on and off
+    max_dlas, min_sep = 3, 0.01
+    uniforms = parallel.resampling_uniforms(len(devs), max_dlas, S, seed=0)
+    for cache in (1, 0):
+        set_option("profile_cache", cache)
+        ev, ll, base = batch.sweep(zs, ns, max_dlas, min_sep, uniforms)
+        assert get_option("last_launch_groups") == 4
+        # the two 3-line flavours and the Lyman-limit one keep level-1 profiles; 5 lines x 3 absorbers recomputes
+        for b, dev in enumerate(devs):
+            alone = DeviceBatch([dev])
+            ev1, ll1, base1 = alone.sweep(zs[b:b + 1], ns[b:b + 1], max_dlas, min_sep, uniforms[b:b + 1])
+            alone.close()
+            np.testing.assert_array_equal(base[b], base1[0])
+            np.testing.assert_allclose(ev[b], ev1[0], rtol=1e-12)
+            np.testing.assert_allclose(ll[b], ll1[0], rtol=1e-12, equal_nan=True)
+    set_option("profile_cache", 1)
+    # by-sample slices of the mixed batch (one rank's share of every level)
+    got = parallel.sweep_sharded_samples_device(batch, zs, ns, max_dlas, min_sep, uniforms,
+                                                slices=[(0, 64), (64, 71), (71, S)])
+    np.testing.assert_array_equal(got[2], base)
+    np.testing.assert_allclose(got[0], ev, rtol=1e-12)
+    batch.close()
+    # a member whose B = I + M' D^-1 M is indefinite, in a launch group that is not the last: the later ones must not clear the flag
+    bad = sights[4]
+    neg = DeviceSightline(bad.y, bad.this_mu, 10.0 * bad.this_M, bad.this_omega2, -np.abs(bad.v), bad.padded_wavelengths,
+                          bad.keep)
+    mixed = DeviceBatch([neg, devs[1], devs[2]])
+    with pytest.raises(np.linalg.LinAlgError):
+        mixed.eval(zs[[4, 1, 2]], ns[[4, 1, 2]])
+    assert get_option("last_launch_groups") == 3
+    with pytest.raises(np.linalg.LinAlgError):
+        mixed.sweep(zs[[4, 1, 2]], ns[[4, 1, 2]], 2, min_sep, uniforms[:3, :1])
+    mixed.close()
+
+
 def test_full_size_properties():
     """BASELINE config 2 (n = 3000, k = 20, S = 10 000): size-independent properties"""
     sight = make_sightline(1)
