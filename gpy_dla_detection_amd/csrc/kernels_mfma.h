@@ -469,6 +469,9 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     v2d frag[NPAIR];
     v2d rec_ym, rec_ov;
 
+#ifndef DLAGP_M1_STORE_LATE
+#define DLAGP_M1_STORE_LATE 1
+#endif
 #ifndef DLAGP_CACHE_STORE_NT
 #define DLAGP_CACHE_STORE_NT 1
 #endif
@@ -496,6 +499,32 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         e = e < num_entries ? e : num_entries - 1;
         lam_next = lam_ptr[e];
     }
+    // cached levels (MODE 2): the row of the running product and the cached row of the new absorber, per sample, for
+    // the 64 pixel slots of a pass (lane = slot); loaded a pass ahead, see the step loop
+    constexpr int NROW = CACHED ? 16 : 1;
+    double own[NROW], other[NROW];
+    auto issue_rows = [&](const PassDesc &pd) __attribute__((always_inline)) {
+        if constexpr (CACHED) {
+            typedef const __attribute__((address_space(1))) double *gcd;
+            const int *row_lds = reinterpret_cast<const int *>(prep_lds);
+            const int st0 = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd.chunk_begin);
+            const int npx = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd.nchunks) * DLAGP_STEP_PIXELS;
+            const int px = lane < npx ? lane : npx - 1;
+            const long col = (long)st0 * DLAGP_STEP_PIXELS + px;
+            const long row0 = (long)b * S;
+            const long last = S - 1 - sample0;  // rows beyond S repeat the last sample (never stored)
+            gcd cache_col = (gcd)src.cache + col;
+            gcd run_col = (gcd)(kd == 2 ? src.cache : src.running) + (row0 + sample0) * src.cache_stride + col;
+#pragma unroll
+            for (int ss = 0; ss < 16; ++ss) {
+                const long rel = ss < last ? ss : last;
+                // the running product is read once: streamed past the L2 that serves the sightline's operand
+                own[ss] = DLAGP_CACHE_STORE_NT ? __builtin_nontemporal_load(run_col + rel * src.cache_stride) : run_col[rel * src.cache_stride];
+                other[ss] = cache_col[(row0 + row_lds[ss]) * src.cache_stride];
+            }
+        }
+    };
+    if constexpr (CACHED) issue_rows(pd_next);  // the first pass's rows
     for (int pass = pass_begin; pass < pass_end; ++pass) {
         const PassDesc pd_v = DLAGP_PREFETCH_PASS ? pd_next : passes[pass];
         const int entry_start = __builtin_amdgcn_readfirstlane(pd_v.entry_start);
@@ -511,38 +540,15 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
 
         if constexpr (CACHED) {
             // ---------------- phase 1 (cached): running product x the new absorber's cached profile ----------------
-            // all 32 row reads of the pass are issued before the first use: one memory round trip per pass,
-            // hidden behind the other resident wave's MFMAs
+            // The 32 row reads of this pass were issued during the last two steps of the pass before it (below), so
+            // their trip to HBM ran beside those steps' MFMAs; what is left of it is hidden behind the other resident
+            // wave.  The products are written back (cache_write) from a_lds[] at the same point of THIS pass.
             if (stamps) t_mark = stamp_now();
-            typedef const __attribute__((address_space(1))) double *gcd;
-            const int *row_lds = reinterpret_cast<const int *>(prep_lds);
             const int npx = pass_steps * DLAGP_STEP_PIXELS;
-            const int px = lane < npx ? lane : npx - 1;
-            const long col = (long)step0 * DLAGP_STEP_PIXELS + px;
-            const long row0 = (long)b * S;
-            const long last = S - 1 - sample0;  // rows beyond S repeat the last sample (never stored)
-            gcd cache_col = (gcd)src.cache + col;
-            gcd run_col = (gcd)(kd == 2 ? src.cache : src.running) + (row0 + sample0) * src.cache_stride + col;
-            double own[16], other[16];
-#pragma unroll
-            for (int ss = 0; ss < 16; ++ss) {
-                const long rel = ss < last ? ss : last;
-                // the running product is read once: streamed past the L2 that serves the sightline's operand
-                own[ss] = DLAGP_CACHE_STORE_NT ? __builtin_nontemporal_load(run_col + rel * src.cache_stride) : run_col[rel * src.cache_stride];
-                other[ss] = cache_col[(row0 + row_lds[ss]) * src.cache_stride];
-            }
-            __attribute__((address_space(1))) double *out_col =
-                (__attribute__((address_space(1))) double *)src.running + (row0 + sample0) * src.cache_stride + col;
 #pragma unroll
             for (int ss = 0; ss < 16; ++ss) {
                 const double prod = own[ss] * other[ss];
-                if (lane < npx) {
-                    a_lds[ss * A_STRIDE + lane] = prod;
-                    if (src.cache_write && ss <= last) {
-                        if (DLAGP_CACHE_STORE_NT) __builtin_nontemporal_store(prod, out_col + ss * src.cache_stride);
-                        else out_col[ss * src.cache_stride] = prod;
-                    }
-                }
+                if (lane < npx) a_lds[ss * A_STRIDE + lane] = prod;
             }
             lds_wave_sync();
             if (stamps) t_conv += stamp_now() - t_mark;
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 if (stamps) t_conv += stamp_now() - t_mark;
             }
             // level 1 of a multi-level sweep: keep the convolved profiles for the deeper levels
-            if constexpr (MODE == 1) {
+            if constexpr (MODE == 1 && !DLAGP_M1_STORE_LATE) {
                 const int npx = pass_steps * DLAGP_STEP_PIXELS;
                 __attribute__((address_space(1))) double *dst =
                     (__attribute__((address_space(1))) double *)src.cache +
@@ -770,52 +776,107 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         // ---------------- phase 2: weights and MFMAs, step by step ----------------
         const double *a_row = &a_lds[s_loc * A_STRIDE + slot];
         double a = a_row[0];
-        for (int st = 0; st < pass_steps; ++st) {
-            __builtin_amdgcn_s_setprio(DLAGP_PRIO_HEAD);
-            const double a2 = a * a;
-            const double d = fma(rec_ov.x, a2, rec_ov.y);
-            const double h = fast_rcp1(d);
-            const double r = fma(-rec_ym.y, a, rec_ym.x);
-            const double rh = r * h;
-            const double w = a2 * h;
-            const double q = a * rh;
-            sum_r2 = fma(r, rh, sum_r2);
-            dprod.multiply(d);
-
-            // next step's operands; the last step of a pass re-reads its own (harmless, never used)
-            const int nst = st + 1 < pass_steps ? st + 1 : st;
-            const int nxt = step0 + nst;
-            rec_ym = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff, nxt * REC_STEP_BYTES, 0));
-            rec_ov = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff + 16, nxt * REC_STEP_BYTES, 0));
-            a = a_row[nst * DLAGP_STEP_PIXELS];
-            // keep the prefetches above in front of the MFMAs: their results are not needed before
-            // the next step, 16 MFMAs (>= 1024 cycles) from here
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(DLAGP_PRIO_MFMA);
-            __builtin_amdgcn_sched_barrier(0);
-            const int soff = nxt * STEP_BYTES;
+        // One step of 4 pixel slots.  FETCH: also fetch the next step's operands (everywhere but in the cached kernel's
+        // last step of a pass, which is written out below).  A macro, not a lambda: the step loop of the Voigt kernels
+        // is tuned to the instruction (an inlined lambda came out 2.6 % slower on configs[1]).
+#define DLAGP_STEP_BODY(st, FETCH)                                                                                       \
+        {                                                                                                                \
+            __builtin_amdgcn_s_setprio(DLAGP_PRIO_HEAD);                                                                 \
+            const double a2 = a * a;                                                                                     \
+            const double d = fma(rec_ov.x, a2, rec_ov.y);                                                                \
+            const double h = fast_rcp1(d);                                                                               \
+            const double r = fma(-rec_ym.y, a, rec_ym.x);                                                                \
+            const double rh = r * h;                                                                                     \
+            const double w = a2 * h;                                                                                     \
+            const double q = a * rh;                                                                                     \
+            sum_r2 = fma(r, rh, sum_r2);                                                                                 \
+            dprod.multiply(d);                                                                                           \
+            /* next step's operands; the last step of a pass re-reads its own (harmless, never used) */                  \
+            const int nst = (st) + 1 < pass_steps ? (st) + 1 : (st);                                                     \
+            const int nxt = step0 + nst;                                                                                 \
+            if (FETCH) {                                                                                                 \
+                rec_ym = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff, nxt * REC_STEP_BYTES, 0)); \
+                rec_ov = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff + 16, nxt * REC_STEP_BYTES, 0)); \
+                a = a_row[nst * DLAGP_STEP_PIXELS];                                                                      \
+            }                                                                                                            \
+            /* keep the prefetches above in front of the MFMAs: their results are not needed before */                   \
+            /* the next step, 16 MFMAs (>= 1024 cycles) from here */                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            __builtin_amdgcn_s_setprio(DLAGP_PRIO_MFMA);                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            const int soff = nxt * STEP_BYTES;                                                                           \
+            _Pragma("unroll") for (int j = 0; j < NPAIR; ++j) {                                                          \
+                const v2d f = frag[j];                                                                                   \
+                if (j < NBIGPAIR) {                                                                                      \
+                    acc[2 * j] = __builtin_amdgcn_mfma_f64_16x16x4f64(2 * j < DLAGP_MFMA_NTW ? w : q, f.x, acc[2 * j], 0, 0, 0); \
+                    acc[2 * j + 1] =                                                                                     \
+                        __builtin_amdgcn_mfma_f64_16x16x4f64(2 * j + 1 < DLAGP_MFMA_NTW ? w : q, f.y, acc[2 * j + 1], 0, 0, 0); \
+                } else {                                                                                                 \
+                    /* A operand lane = pixel * 16 + sample is also the 4-block form's (sample = block * 4 + row) */     \
+                    acc_sw = __builtin_amdgcn_mfma_f64_4x4x4f64(w, f.x, acc_sw, 0, 0, 0);                                \
+                    acc_sq = __builtin_amdgcn_mfma_f64_4x4x4f64(q, f.y, acc_sq, 0, 0, 0);                                \
+                }                                                                                                        \
+                /* rolling prefetch: this register pair is next used one full step later */                              \
+                if (FETCH)                                                                                               \
+                    frag[j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(                             \
+                                                          p_rsrc, p_voff + (j & 3) * 1024, soff + (j >> 2) * 4096, 0));  \
+            }                                                                                                            \
+            /* pin the interleaving: two MFMAs, then the load that refills their operand pair */                         \
+            _Pragma("unroll") for (int j = 0; j < NPAIR; ++j) {                                                          \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); /* MFMA */                                            \
+                if (FETCH) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); /* VMEM read */                            \
+            }                                                                                                            \
+        }
+        if constexpr (!CACHED) {
+            for (int st = 0; st < pass_steps; ++st) DLAGP_STEP_BODY(st, true)
+        } else {
+            // Cached levels: the last two steps are written out so that the memory traffic of the NEXT pass can start
+            // between them.  Vector-memory operations complete in order and the step loop waits for its operand
+            // prefetches, so anything issued in front of it (the old place of the row reads and the write-back) holds
+            // up its first steps for a trip to HBM; issued here, behind the last operand prefetch of the pass, the
+            // write-back of this pass's products and the 32 row reads of the next pass are in flight during two steps of
+            // MFMAs and nothing waits for them before the next pass's products.  (Inside the loop, behind a condition,
+            // the compiler's wait counts at the loop head would have to assume the worst of both paths.)
+            for (int st = 0; st + 2 < pass_steps; ++st) DLAGP_STEP_BODY(st, true)
+            DLAGP_STEP_BODY(pass_steps - 2, true)  // a pass holds an even number of steps >= 2 (chunks of 8 slots)
+            {
+                const int npx = pass_steps * DLAGP_STEP_PIXELS;
+                const long last = S - 1 - sample0;
+                if (src.cache_write && lane < npx) {
+                    __attribute__((address_space(1))) double *out_col =
+                        (__attribute__((address_space(1))) double *)src.running + ((long)b * S + sample0) * src.cache_stride +
+                        (long)step0 * DLAGP_STEP_PIXELS + lane;
 #pragma unroll
-            for (int j = 0; j < NPAIR; ++j) {
-                const v2d f = frag[j];
-                if (j < NBIGPAIR) {
-                    acc[2 * j] = __builtin_amdgcn_mfma_f64_16x16x4f64(2 * j < DLAGP_MFMA_NTW ? w : q, f.x, acc[2 * j], 0, 0, 0);
-                    acc[2 * j + 1] =
-                        __builtin_amdgcn_mfma_f64_16x16x4f64(2 * j + 1 < DLAGP_MFMA_NTW ? w : q, f.y, acc[2 * j + 1], 0, 0, 0);
-                } else {
-                    // A operand lane = pixel * 16 + sample is also the 4-block form's (sample = block * 4 + row)
-                    acc_sw = __builtin_amdgcn_mfma_f64_4x4x4f64(w, f.x, acc_sw, 0, 0, 0);
-                    acc_sq = __builtin_amdgcn_mfma_f64_4x4x4f64(q, f.y, acc_sq, 0, 0, 0);
+                    for (int ss = 0; ss < 16; ++ss)
+                        if (ss <= last) {
+                            const double prod = a_lds[ss * A_STRIDE + lane];
+                            if (DLAGP_CACHE_STORE_NT) __builtin_nontemporal_store(prod, out_col + ss * src.cache_stride);
+                            else out_col[ss * src.cache_stride] = prod;
+                        }
                 }
-                // rolling prefetch: this register pair is next used one full step later
-                frag[j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(
-                                                      p_rsrc, p_voff + (j & 3) * 1024, soff + (j >> 2) * 4096, 0));
+                if (pass + 1 < pass_end) issue_rows(pd_next);
             }
-            // pin the interleaving: two MFMAs, then the load that refills their operand pair
-#pragma unroll
-            for (int j = 0; j < NPAIR; ++j) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
-            }
+            DLAGP_STEP_BODY(pass_steps - 1, false)
+        }
+#undef DLAGP_STEP_BODY
+        // Level 1 of a multi-level sweep: keep the convolved profiles for the deeper levels.  Stored here, at the end of
+        // the pass, not right after the convolution: vector-memory operations complete in order, so stores issued
+        // in front of the step loop made its first steps wait for 16 write acknowledgements from HBM (MODE 1 ran 19 %
+        // slower than MODE 0); from here they drain during the next pass's Voigt loop.  a_lds[] is intact until the
+        // next convolution.
+        if constexpr (MODE == 1 && DLAGP_M1_STORE_LATE) {
+            const int npx = pass_steps * DLAGP_STEP_PIXELS;
+            __attribute__((address_space(1))) double *dst =
+                (__attribute__((address_space(1))) double *)src.cache +
+                ((long)b * S + sample0) * src.cache_stride + (long)step0 * DLAGP_STEP_PIXELS + lane;
+            const long valid = S - sample0 < 16 ? S - sample0 : 16;
+            // streaming stores: 24 KB per sample written once and read a level later -- kept out of the L2 that
+            // serves the sightline's operand
+            if (lane < npx)
+                for (int ss = 0; ss < valid; ++ss) {
+                    if (DLAGP_CACHE_STORE_NT) __builtin_nontemporal_store(a_lds[ss * A_STRIDE + lane], dst + ss * src.cache_stride);
+                    else dst[ss * src.cache_stride] = a_lds[ss * A_STRIDE + lane];
+                }
         }
         __builtin_amdgcn_s_setprio(DLAGP_PRIO_CONV);
         // the next pass overwrites raw[] / a_lds[]: order the LDS reads above before those writes

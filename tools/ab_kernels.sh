@@ -1,0 +1,16 @@
+#!/bin/bash
+# On the GPU box: per-kernel average durations (rocprofv3 kernel stats) of one bench configuration for several builds.
+# usage: tools/ab_kernels.sh "<bench args>" <libA.so> <libB.so> ...
+ARGS=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
+for L in "$@"; do
+  tag=$(basename $L .so)
+  DLAGP_LIB=$PWD/$L rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abk_$tag -- python3 bench.py --no-cpu-baseline $ARGS > gpurun_out/abk_$tag.log 2>&1
+  python3 - $tag <<'PY'
+import csv, glob, sys
+f = glob.glob('gpurun_out/abk_%s/*/*_kernel_stats.csv' % sys.argv[1])[0]
+rows = [r for r in csv.DictReader(open(f)) if 'accumulate' in r['Name'] or 'finalize' in r['Name']]
+print(sys.argv[1].ljust(8), '  '.join('%s x%s %.1f us' % (r['Name'].split('<')[-1][:22] if '<' in r['Name'] else r['Name'][7:22], r['Calls'], float(r['AverageNs']) / 1e3) for r in rows))
+PY
+  rm -rf gpurun_out/abk_$tag
+done
