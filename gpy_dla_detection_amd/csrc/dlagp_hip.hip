@@ -3,6 +3,7 @@
 //
 // Build: make -C gpy_dla_detection_amd/csrc   (hipcc --offload-arch=gfx950)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -605,8 +606,11 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
 // ------------------------------------------------------------------------------------------------
 // launch sequence common to single-sightline and batch evaluation
 // ------------------------------------------------------------------------------------------------
+// The timing events (option "timing") ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL): recorded with
+// hipEventRecord before and after the launch they were two barrier packets of ~6 us each around a 0.29 ms kernel.
 #define DLAGP_LAUNCH_MFMA(...)                                                                                     \
-    hipLaunchKernelGGL((accumulate_mfma<__VA_ARGS__>), grid, dim3(DLAGP_MFMA_THREADS), prep_lds, stream, table,     \
+    hipExtLaunchKernelGGL((accumulate_mfma<__VA_ARGS__>), grid, dim3(DLAGP_MFMA_THREADS), (uint32_t)prep_lds, stream, \
+                          ev_start, ev_stop, 0u, table,                                                             \
                        plan->passes.as<const PassDesc>(), plan->items.as<const WorkItem>(), nb, S, kd, src, part, \
                        status, launch_flags)
 
@@ -621,7 +625,7 @@ static int patch_mode(const LaunchGroup &g, int kd) {
 template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, const LaunchPlan *plan, int nb,
                         long S, int kd, int num_lines, const SampleSource &src, double *part, int *status,
-                        int patch, bool lls, int launch_flags) {
+                        int patch, bool lls, int launch_flags, hipEvent_t ev_start, hipEvent_t ev_stop) {
     // 16 samples + one spare row that the look-ahead of the sample loop may read; PATCH 2: 3 ints per (sample, absorber)
     const size_t prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * kd * (lls ? 6 : (LINES > 0 ? LINES : num_lines) + 1) * sizeof(double) +
                             (patch == 2 ? (size_t)DLAGP_MFMA_GROUP * kd * 3 * sizeof(int) : 0);
@@ -689,8 +693,8 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
     g.last_stream = stream;
     g.launched = true;
 
-    // timing (option "timing"): a pair of events around the accumulate launch.  The pair joins the list that
-    // dlagp_timing_read reads only once both events have been recorded; any earlier exit destroys it.
+    // timing (option "timing"): a pair of events attached to the accumulate launch.  The pair joins the list that
+    // dlagp_timing_read reads only once the launch has been enqueued; any earlier exit destroys it.
     struct TimingGuard {
         EventPair ev{};
         bool armed = false;
@@ -708,8 +712,8 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
             return fail(DLAGP_EDEVICE, "hipEventCreate failed");
         }
         tg.armed = true;
-        HIP_TRY(hipEventRecord(tg.ev.start, stream));
     }
+    const hipEvent_t ev_start = timing ? tg.ev.start : nullptr, ev_stop = timing ? tg.ev.stop : nullptr;
 
     int *status = status_shared ? status_shared : ws.status.as<int>();
     g_last_launch_path = use_mfma ? 2 : 1;
@@ -727,11 +731,11 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
             const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * sizeof(double);
             DLAGP_LAUNCH_MFMA(3, true, false, 2);
         } else if (g.broadening) {
-            if (lines3) launch_mfma<3, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags);
-            else launch_mfma<0, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags);
+            if (lines3) launch_mfma<3, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags, ev_start, ev_stop);
+            else launch_mfma<0, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags, ev_start, ev_stop);
         } else {
-            if (lines3) launch_mfma<3, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags);
-            else launch_mfma<0, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags);
+            if (lines3) launch_mfma<3, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags, ev_start, ev_stop);
+            else launch_mfma<0, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags, ev_start, ev_stop);
         }
         HIP_TRY(hipGetLastError());
     } else {
@@ -745,13 +749,13 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_generic),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         dim3 grid((unsigned)S, (unsigned)nb);
-        hipLaunchKernelGGL(accumulate_generic, grid, dim3(DLAGP_GENERIC_THREADS), lds_bytes, stream, table, (long)S,
-                           kd, src, ws.part.as<double>(), status, lds_entries, lds_pixels, keep_status ? 1 : 0);
+        hipExtLaunchKernelGGL(accumulate_generic, grid, dim3(DLAGP_GENERIC_THREADS), (uint32_t)lds_bytes, stream,
+                              ev_start, ev_stop, 0u, table, (long)S, kd, src, ws.part.as<double>(), status, lds_entries,
+                              lds_pixels, keep_status ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
 
-    if (timing) {
-        HIP_TRY(hipEventRecord(tg.ev.stop, stream));
+    if (timing) {  // both events belong to the launch that has just been enqueued
         std::lock_guard<std::mutex> lock(g_timing_mutex);
         g_timing_events.push_back(tg.ev);  // owned by the list from here on: dlagp_timing_read destroys them
         tg.armed = false;

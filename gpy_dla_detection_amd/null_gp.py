@@ -61,6 +61,32 @@ def prepare_data(params: Parameters, X: np.ndarray, Y: np.ndarray, noise_varianc
     return out
 
 
+class _LinearInterpolant:
+    """
+    `scipy.interpolate.interp1d(grid, values)` (kind "linear", bounds_error) as the reference builds it
+    (null_gp.py:67-71), without the per-object set-up: the reference's driver constructs three GP objects per
+    spectrum, 22 interpolants each, which was a quarter of the per-spectrum time of the drop-in route.  Same
+    arithmetic -- interp1d's linear path is `np.interp` on a sorted grid -- and the same ValueError outside the grid.
+    """
+
+    __slots__ = ("x", "y")
+
+    def __init__(self, grid: np.ndarray, values: np.ndarray):
+        self.x = np.asarray(grid, dtype=np.float64)
+        self.y = np.asarray(values, dtype=np.float64)
+        if self.x.ndim != 1 or self.x.shape != self.y.shape:
+            raise ValueError("x and y arrays must be equal in length along interpolation axis.")
+
+    def __call__(self, x_new) -> np.ndarray:
+        x_new = np.asarray(x_new, dtype=np.float64)
+        if x_new.size:
+            if np.min(x_new) < self.x[0]:
+                raise ValueError("A value in x_new is below the interpolation range's minimum value ({}).".format(self.x[0]))
+            if np.max(x_new) > self.x[-1]:
+                raise ValueError("A value in x_new is above the interpolation range's maximum value ({}).".format(self.x[-1]))
+        return np.interp(x_new, self.x, self.y)
+
+
 class NullGP:
     """
     p(y | lambda, z_qso, v, omega, M) = N(y; mu a_lya, A_lya (M M' + Omega) A_lya + V)
@@ -109,10 +135,14 @@ class NullGP:
         self._device_sightline: Optional[_sl.DeviceSightline] = None
         self._device_key = None
 
-        # linear interpolants of the learned model (reference :67-71)
-        self.mu_interpolator = interpolate.interp1d(rest_wavelengths, mu)
-        self.log_omega_interpolator = interpolate.interp1d(rest_wavelengths, log_omega)
-        self.list_M_interpolators = [interpolate.interp1d(rest_wavelengths, column) for column in M.T]
+        # linear interpolants of the learned model (reference :67-71; scipy's interp1d when the grid is unsorted)
+        if np.all(np.diff(np.asarray(rest_wavelengths, dtype=np.float64)) > 0):
+            make = _LinearInterpolant
+        else:
+            make = interpolate.interp1d
+        self.mu_interpolator = make(rest_wavelengths, mu)
+        self.log_omega_interpolator = make(rest_wavelengths, log_omega)
+        self.list_M_interpolators = [make(rest_wavelengths, column) for column in np.asarray(M).T]
 
     # ------------------------------------------------------------------------------------------
     # data / model preparation (host; reference :73-242)
