@@ -76,6 +76,8 @@ static Option g_opt_profile_cache_max_mb = 196608;
 static Option g_opt_plan_item_cost = 20;   // fixed cost of a work item in the planner's model, tenths of a chunk
 static Option g_opt_plan_rest_first = 0;   // dispatch the remainder pieces before the full ones (tuning)
 static Option g_opt_plan_slots = 2048;     // wave slots the planner fills: 256 CUs x 4 SIMDs x 2 waves (tuning)
+// launches of up to this many blocks of 16 samples finalise with 16 lanes per sample (kernels_common.h); 0: never
+static Option g_opt_finalize_row16_blocks = DLAGP_FIN_ROW16_MAX_BLOCKS;
 // read-only diagnostics of the most recent launch / sweep (dlagp_get_option): which kernel served it
 static Option g_last_launch_path = 0;    // 1 generic kernel, 2 MFMA kernel
 static Option g_last_launch_items = 0;   // work items (waves) of the last MFMA launch
@@ -130,7 +132,10 @@ static int ensure_device(int device) {
     lc.c = DLAGP_SPEED_OF_LIGHT_CGS;
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(DLAGP_LINES), &lc, sizeof(lc)));
     // finalize_rank20 stages its partial sums in dynamic LDS
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_rank20),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_rank20<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double))));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_rank20<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double))));
     g_device_ready[device] = 1;
@@ -166,9 +171,19 @@ struct DeviceBuffer {
     void *ptr = nullptr;
     size_t bytes = 0;
     static constexpr size_t kPoolMaxBuffer = (size_t)64 << 20;
+    // Sizes are rounded up to eight steps per octave (<= 12.5 % more): the arrays of a spectrum scale with its pixel
+    // count, which differs from spectrum to spectrum, and the pool hands out exact sizes only -- without the
+    // rounding nearly every buffer of a new context was a hipMalloc and every released one a hipFree.
+    static size_t bucket(size_t want) {
+        if (want <= 4096) return 4096;
+        size_t step = 512;
+        while ((step << 4) < want) step <<= 1;  // step = 2^(floor(log2(want - 1)) - 3)
+        return (want + step - 1) / step * step;
+    }
     int reserve(size_t want) {
         if (want <= bytes) return DLAGP_OK;
         release();
+        want = bucket(want);
         int device = 0;
         HIP_TRY(hipGetDevice(&device));
         if (want <= kPoolMaxBuffer) {
@@ -261,7 +276,11 @@ struct Workspace {
 };
 
 static std::mutex g_spare_mutex;
-static std::map<int, Workspace> g_spare_workspace;  // per device: workspace of the last destroyed batch
+// per device: workspaces of destroyed batches, adopted by the next batches created.  A pipelined catalogue run has
+// three batches alive at a time (one being prepared, one in its sweeps, one being finished): with a single spare
+// every other batch freed and reallocated gigabytes (hipFree synchronises the device: 7 ms per batch).
+static std::map<int, std::vector<Workspace>> g_spare_workspace;
+static Option g_opt_spare_workspaces = 3;
 
 // Decomposition of one MFMA launch (a launch group at one sample count) into work items, see build_plan
 struct LaunchPlan {
@@ -351,6 +370,7 @@ struct dlagp_ctx {
     DeviceBuffer y, mu, omega2, v, pos, lam, P, aux;
     DeviceBuffer Pm, slot_pixel, slot_pos;  // MFMA path: slot-ordered operand and slot tables
     DeviceBuffer dense_M;      // interpolated / uploaded factor, row-major [n][k], kept for dlagp_ctx_read_model
+    DeviceBuffer scratch_a, scratch_b;  // inputs of the set-up kernels, released once the set-up stream has drained
     std::vector<int> h_pos;    // host copy of pos[]
     std::vector<int> h_slot_pos;  // window start of every slot (padding slots repeat their chunk's last pixel), for planning
     bool mfma_ok = false;      // rank padded to 20
@@ -763,10 +783,15 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
 
     if (g.k == DLAGP_FIN_K) {
         const size_t lds_bytes = DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double);
-        hipLaunchKernelGGL(finalize_rank20, dim3((unsigned)nblocks),
-                           dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
-                           ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
-                           plan ? plan->counts.as<const unsigned char>() : nullptr);
+        const bool row16 = (int64_t)nblocks <= g_opt_finalize_row16_blocks;
+        if (row16)
+            hipLaunchKernelGGL(finalize_rank20<true>, dim3((unsigned)nblocks), dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
+                               ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
+                               plan ? plan->counts.as<const unsigned char>() : nullptr);
+        else
+            hipLaunchKernelGGL(finalize_rank20<false>, dim3((unsigned)nblocks), dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
+                               ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
+                               plan ? plan->counts.as<const unsigned char>() : nullptr);
     } else {
         const int threads = DLAGP_FINALIZE_THREADS;
         hipLaunchKernelGGL(finalize_samples<0>, dim3((unsigned)((rows + threads - 1) / threads)), dim3(threads), 0,
@@ -871,6 +896,8 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
                       ws.out.as<double>(), nullptr);
     if (rc) return rc;
     if ((rc = tr.run_downloads())) return rc;
+    g.launched = false;  // run_downloads drained the stream: nothing of this group is in flight (drain() has nothing to wait for)
+    for (auto &p : g.parts) p->launched = false;
     int status = 0;
     HIP_TRY(hipMemcpy(&status, ws.status.ptr, sizeof(int), hipMemcpyDeviceToHost));
     if (status) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
@@ -972,16 +999,50 @@ static hipStream_t setup_stream(int device) {
     static thread_local std::map<int, hipStream_t> streams;
     auto it = streams.find(device);
     if (it != streams.end()) return it->second;
+    // highest priority: the set-up kernels are tiny, and behind a sweep's long-running waves they otherwise wait for
+    // wave slots while a host thread sits in the synchronisation that ends every context creation
     hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;  // fall back to the null stream
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) != hipSuccess)
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;  // fall back to the null stream
     streams[device] = s;
     return s;
 }
 
-// host -> device on the set-up stream, complete on return (the source may be a temporary)
-static int upload_now(void *dst, const void *src, size_t bytes, hipStream_t stream) {
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+// Host -> device on the set-up stream WITHOUT a synchronisation per array: the bytes are copied into a page-locked
+// arena of the calling thread (so the source may be a temporary) and go out as one asynchronous copy each; the arena
+// is recycled by setup_sync(), which every set-up sequence ends with.  (Context creation used to synchronise the
+// stream eleven times -- once per array -- which was 0.6 ms per spectrum and the catalogue driver's bottleneck.)
+struct SetupArena {
+    PinnedBuffer buf;
+    size_t used = 0;
+};
+static SetupArena &setup_arena(int device) {
+    static thread_local std::map<int, SetupArena> arenas;
+    return arenas[device];
+}
+
+// all staged uploads and kernels of the calling thread's set-up stream are complete on return
+static int setup_sync(int device) {
+    HIP_TRY(hipStreamSynchronize(setup_stream(device)));
+    setup_arena(device).used = 0;
+    return DLAGP_OK;
+}
+
+static int upload_staged(void *dst, const void *src, size_t bytes, int device) {
+    if (!bytes) return DLAGP_OK;
+    SetupArena &arena = setup_arena(device);
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (arena.used + need > arena.buf.bytes) {
+        int rc = setup_sync(device);  // copies in flight still read the old arena
+        if (rc) return rc;
+        if (need > arena.buf.bytes && (rc = arena.buf.reserve(std::max(need * 2, (size_t)4 << 20)))) return rc;
+    }
+    char *slot = static_cast<char *>(arena.buf.ptr) + arena.used;
+    std::memcpy(slot, src, bytes);
+    arena.used += need;
+    HIP_TRY(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, setup_stream(device)));
     return DLAGP_OK;
 }
 
@@ -1011,7 +1072,9 @@ static int finish_group(LaunchGroup &g, const std::vector<int> *positions = null
     if (lls_mixed) g.mfma_ok = false;
     int rc = g.d_table.reserve(table.size() * sizeof(SightlineDev));
     if (rc) return rc;
-    return upload_now(g.d_table.ptr, table.data(), table.size() * sizeof(SightlineDev), setup_stream(g.device));
+    // the table must be in place before the group's first launch, which runs on the caller's stream
+    if ((rc = upload_staged(g.d_table.ptr, table.data(), table.size() * sizeof(SightlineDev), g.device))) return rc;
+    return setup_sync(g.device);
 }
 
 // A batch whose members could each run the MFMA kernel but differ in line count, broadening or Lyman-limit flag:
@@ -1140,13 +1203,14 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
         if (!rc) rc = ctx->Pm.reserve(pm_bytes);
         if (!rc) rc = ctx->slot_pixel.reserve(sb);
         if (!rc) rc = ctx->slot_pos.reserve(sb);
-        if (!rc) rc = upload_now(ctx->slot_pixel.ptr, slot_pixel.data(), sb, setup);
-        if (!rc) rc = upload_now(ctx->slot_pos.ptr, ctx->h_slot_pos.data(), sb, setup);
+        if (!rc) rc = upload_staged(ctx->slot_pixel.ptr, slot_pixel.data(), sb, device);
+        if (!rc) rc = upload_staged(ctx->slot_pos.ptr, ctx->h_slot_pos.data(), sb, device);
     }
-    if (!rc) rc = upload_now(ctx->pos.ptr, hpos.data(), (size_t)sl.n_pad * sizeof(int), setup);
-    if (!rc) rc = upload_now(ctx->lam.ptr, wavelengths, (size_t)sl.num_entries * sizeof(double), setup);
+    if (!rc) rc = upload_staged(ctx->pos.ptr, hpos.data(), (size_t)sl.n_pad * sizeof(int), device);
+    if (!rc) rc = upload_staged(ctx->lam.ptr, wavelengths, (size_t)sl.num_entries * sizeof(double), device);
     if (!rc) rc = fill(ctx);
     if (rc) {
+        (void)setup_sync(device);  // staged copies may still be writing the buffers that go back to the pool
         dlagp_destroy(ctx);
         return rc;
     }
@@ -1169,16 +1233,19 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     }
     hipLaunchKernelGGL(build_shared_operand, dim3(1024), dim3(256), 0, setup, ctx->dense_M.as<double>(), n, sl.n_pad,
                        k_eff, sl.ntw, sl.ntq, sl.npair, ctx->P.as<double>());
-    hipError_t err = hipGetLastError();
-    if (err == hipSuccess) err = hipStreamSynchronize(setup);
+    const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
+        (void)setup_sync(device);
         dlagp_destroy(ctx);
         return fail(DLAGP_EDEVICE, "context set-up kernels failed: %s", hipGetErrorString(err));
     }
     ctx->self.device = device;
     ctx->self.ctxs.push_back(ctx);
-    rc = finish_group(ctx->self);
+    rc = finish_group(ctx->self);  // ends with the one synchronisation of the whole set-up sequence
+    ctx->scratch_a.release();      // temporaries of the set-up kernels (the stream is idle now)
+    ctx->scratch_b.release();
     if (rc) {
+        (void)setup_sync(device);
         dlagp_destroy(ctx);
         return rc;
     }
@@ -1187,10 +1254,10 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
 }
 
 // upload n doubles padded to n_pad with `pad`
-static int upload_padded(DeviceBuffer &buf, const double *src, int n, int n_pad, double pad, hipStream_t stream) {
+static int upload_padded(DeviceBuffer &buf, const double *src, int n, int n_pad, double pad, int device) {
     std::vector<double> host(n_pad, pad);
     std::copy(src, src + n, host.begin());
-    return upload_now(buf.ptr, host.data(), (size_t)n_pad * sizeof(double), stream);
+    return upload_staged(buf.ptr, host.data(), (size_t)n_pad * sizeof(double), device);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1215,16 +1282,15 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
     if (!y || !mu || !M || !omega2 || !v) return fail(DLAGP_EINVAL, "NULL input array");
     return create_context(out, n, n_u, k, wavelengths, keep, num_lines, broadening, device, [&](dlagp_ctx *ctx) -> int {
         const SightlineDev &sl = ctx->sl;
-        const hipStream_t setup = setup_stream(ctx->device);
-        int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0, setup);
-        if (!rc) rc = upload_padded(ctx->mu, mu, n, sl.n_pad, 0.0, setup);
-        if (!rc) rc = upload_padded(ctx->omega2, omega2, n, sl.n_pad, 0.0, setup);
-        if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0, setup);
+        int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0, ctx->device);
+        if (!rc) rc = upload_padded(ctx->mu, mu, n, sl.n_pad, 0.0, ctx->device);
+        if (!rc) rc = upload_padded(ctx->omega2, omega2, n, sl.n_pad, 0.0, ctx->device);
+        if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0, ctx->device);
         if (rc) return rc;
         std::vector<double> hM((size_t)n * sl.k, 0.0);
         for (int i = 0; i < n; ++i)
             for (int c = 0; c < k; ++c) hM[(size_t)i * sl.k + c] = M[i * m_row_stride + c * m_col_stride];
-        return upload_now(ctx->dense_M.ptr, hM.data(), hM.size() * sizeof(double), setup);
+        return upload_staged(ctx->dense_M.ptr, hM.data(), hM.size() * sizeof(double), ctx->device);
     });
 }
 
@@ -1315,26 +1381,24 @@ int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, in
                           [&](dlagp_ctx *ctx) -> int {
         const SightlineDev &sl = ctx->sl;
         const hipStream_t setup = setup_stream(ctx->device);
-        int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0, setup);
-        if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0, setup);
+        int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0, ctx->device);
+        if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0, ctx->device);
         if (rc) return rc;
-        DeviceBuffer dx, dw;
+        // the kernel's inputs live until the end of the set-up sequence (create_context releases them after its one
+        // synchronisation: a buffer handed back to the pool while the kernel is in flight could be given to another thread)
+        DeviceBuffer &dx = ctx->scratch_a, &dw = ctx->scratch_b;
         rc = dx.reserve((size_t)n * sizeof(double));
         if (!rc) rc = dw.reserve((size_t)n * sizeof(double));
-        if (!rc) rc = upload_now(dx.ptr, x, (size_t)n * sizeof(double), setup);
-        if (!rc) rc = upload_now(dw.ptr, this_wavelengths, (size_t)n * sizeof(double), setup);
-        hipError_t err = hipSuccess;
-        if (!rc) {
-            hipLaunchKernelGGL(interp_model, dim3((sl.n_pad + 63) / 64), dim3(64), 0, setup, model->dev, n, sl.n_pad,
-                               sl.k, dx.as<const double>(), dw.as<const double>(), z_qso, ctx->mu.as<double>(),
-                               ctx->omega2.as<double>(), ctx->dense_M.as<double>());
-            err = hipGetLastError();
-            if (err == hipSuccess) err = hipStreamSynchronize(setup);
-        }
-        dx.release();
-        dw.release();
-        if (!rc && err != hipSuccess) rc = fail(DLAGP_EDEVICE, "interp_model failed: %s", hipGetErrorString(err));
-        return rc;
+        if (!rc) rc = upload_staged(dx.ptr, x, (size_t)n * sizeof(double), ctx->device);
+        if (!rc) rc = upload_staged(dw.ptr, this_wavelengths, (size_t)n * sizeof(double), ctx->device);
+        if (rc) return rc;
+        hipLaunchKernelGGL(interp_model, dim3((sl.n_pad + DLAGP_INTERP_PIXELS - 1) / DLAGP_INTERP_PIXELS),
+                           dim3(DLAGP_INTERP_THREADS), 0, setup, model->dev, n, sl.n_pad,
+                           sl.k, dx.as<const double>(), dw.as<const double>(), z_qso, ctx->mu.as<double>(),
+                           ctx->omega2.as<double>(), ctx->dense_M.as<double>());
+        const hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return fail(DLAGP_EDEVICE, "interp_model failed: %s", hipGetErrorString(err));
+        return DLAGP_OK;
     });
 }
 
@@ -1380,6 +1444,8 @@ void dlagp_destroy(dlagp_ctx *ctx) {
     ctx->slot_pixel.release();
     ctx->slot_pos.release();
     ctx->dense_M.release();
+    ctx->scratch_a.release();
+    ctx->scratch_b.release();
     delete ctx;
 }
 
@@ -1487,9 +1553,9 @@ int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
     {  // adopt the workspace the previous batch on this device left behind (see dlagp_batch_destroy)
         std::lock_guard<std::mutex> lock(g_spare_mutex);
         auto it = g_spare_workspace.find(batch->group.device);
-        if (it != g_spare_workspace.end()) {
-            batch->group.ws = it->second;
-            g_spare_workspace.erase(it);
+        if (it != g_spare_workspace.end() && !it->second.empty()) {
+            batch->group.ws = it->second.back();
+            it->second.pop_back();
         }
     }
     {
@@ -1518,18 +1584,17 @@ void dlagp_batch_destroy(dlagp_batch *batch) {
     }
     // A catalogue run builds one batch after the other: the sweep workspace (partial sums, profile cache --
     // gigabytes) is handed to the next batch of this device instead of being freed and allocated again.
-    // One workspace per device is kept; option "pool_mb" = 0 turns this off as well.
+    // Up to `spare_workspaces` (3) per device are kept; option "pool_mb" = 0 turns this off as well.
     Workspace keep{};
     bool parked = false;
-    if (g_opt_pool_mb > 0) {
+    if (g_opt_pool_mb > 0 && g_opt_spare_workspaces > 0) {
         std::lock_guard<std::mutex> lock(g_spare_mutex);
-        auto it = g_spare_workspace.find(batch->group.device);
-        if (it != g_spare_workspace.end()) {
-            keep = it->second;  // the older spare goes
-            it->second = batch->group.ws;
-        } else {
-            g_spare_workspace[batch->group.device] = batch->group.ws;
+        std::vector<Workspace> &spares = g_spare_workspace[batch->group.device];
+        if ((int64_t)spares.size() >= g_opt_spare_workspaces) {
+            keep = spares.front();  // the oldest spare goes
+            spares.erase(spares.begin());
         }
+        spares.push_back(batch->group.ws);
         batch->group.ws = Workspace{};
         parked = true;
     }
@@ -1621,6 +1686,8 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
                       ws.base.as<int>(), nullptr);
     if (rc) return rc;
     if ((rc = tr.run_downloads())) return rc;
+    g.launched = false;  // as in sweep_from_host
+    for (auto &p : g.parts) p->launched = false;
     int status = 0;
     HIP_TRY(hipMemcpy(&status, ws.alive.as<int>() + nb, sizeof(int), hipMemcpyDeviceToHost));
     if (status) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
@@ -1695,7 +1762,8 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
     if (nb <= 0 || S <= 0 || level < 0) return fail(DLAGP_EINVAL, "need nb > 0, S > 0, level >= 0");
     HIP_TRY(hipSetDevice(device));
     hipLaunchKernelGGL(level_evidence, dim3((unsigned)nb), dim3(DLAGP_EVIDENCE_THREADS), 0,
-                       static_cast<hipStream_t>(stream), d_ll, (long)S, level, d_too_close, d_evidence);
+                       static_cast<hipStream_t>(stream), d_ll, (long)S, level, d_too_close, d_evidence,
+                       std::log((double)S));
     HIP_TRY(hipGetLastError());
     return DLAGP_OK;
 }
@@ -1759,7 +1827,7 @@ int dlagp_set_option(const char *name, int64_t value) {
             std::lock_guard<std::mutex> lock(g_spare_mutex);
             for (auto &kv : g_spare_workspace) {
                 (void)hipSetDevice(kv.first);
-                kv.second.release();
+                for (Workspace &w : kv.second) w.release();
             }
             g_spare_workspace.clear();
         }
@@ -1769,6 +1837,8 @@ int dlagp_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "plan_item_cost")) g_opt_plan_item_cost = value;
     else if (!strcmp(name, "plan_rest_first")) g_opt_plan_rest_first = value;
     else if (!strcmp(name, "plan_slots")) g_opt_plan_slots = value > 0 ? value : 2048;
+    else if (!strcmp(name, "finalize_row16_blocks")) g_opt_finalize_row16_blocks = value;
+    else if (!strcmp(name, "spare_workspaces")) g_opt_spare_workspaces = value;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 }
@@ -1792,6 +1862,8 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "plan_item_cost")) *value = g_opt_plan_item_cost;
     else if (!strcmp(name, "plan_rest_first")) *value = g_opt_plan_rest_first;
     else if (!strcmp(name, "plan_slots")) *value = g_opt_plan_slots;
+    else if (!strcmp(name, "finalize_row16_blocks")) *value = g_opt_finalize_row16_blocks;
+    else if (!strcmp(name, "spare_workspaces")) *value = g_opt_spare_workspaces;
     else if (!strcmp(name, "last_launch_path")) *value = g_last_launch_path;
     else if (!strcmp(name, "last_launch_items")) *value = g_last_launch_items;
     else if (!strcmp(name, "last_launch_parts")) *value = g_last_launch_parts;

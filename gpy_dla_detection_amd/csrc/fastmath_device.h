@@ -26,6 +26,21 @@ __device__ __forceinline__ double fast_rcp1(double x) {
     return fma(r, fma(-x, r, 1.0), r);
 }
 
+// 1/sqrt(x) for the Cholesky pivots: v_rsq_f64 seed + two coupled Newton (Goldschmidt) steps on g ~ sqrt(x) and
+// h ~ 1/(2 sqrt(x)); relative error ~2e-16 for normal x.  Ten instructions instead of the nineteen of an IEEE sqrt
+// followed by fast_rcp.  x <= 0, NaN and infinity give what v_rsq_f64 gives (NaN / infinity / 0): callers test the pivot.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-g, h, 0.5);
+    h = fma(h, r, h);
+    return h + h;
+}
+
 // exp(x) for x <= 0 (also correct for moderate x > 0); max relative error 2e-14.
 // x = k ln2 + r, |r| <= ln2/2, e^r by a degree-9 fit, scaled with v_ldexp_f64 (underflows to 0).
 // One Horner step p * r + c with the coefficient forced into a scalar register pair.  hipcc

@@ -69,7 +69,7 @@ __global__ void build_shared_operand(const double *__restrict__ M_dev, int n, in
 
 // ---------------------------------------------------------------------------------------------
 // Model interpolation: NullGP.get_interp (reference null_gp.py:179-242) on the device.
-// One thread per kept pixel i:
+// Per kept pixel i (32 threads each, see the kernel):
 //   linear interpolation of mu, log_omega and the k columns of M at the pixel's rest wavelength
 //     (scipy interp1d(kind="linear") = numpy.interp: slope = (f[j+1]-f[j])/(x[j+1]-x[j]),
 //      value = slope (x - x[j]) + f[j], null_gp.py:67-71,189-195) -- same operation order, no FMA;
@@ -118,47 +118,72 @@ __device__ __forceinline__ double numpy_interp(const double *__restrict__ xp, co
     return __dadd_rn(__dmul_rn(slope, x - xp[j]), fp[j]);
 }
 
-__global__ void interp_model(ModelDev model, int n, int n_pad, int k_out, const double *__restrict__ x,
-                             const double *__restrict__ wavelengths, double z_qso, double *__restrict__ mu_out,
-                             double *__restrict__ omega2_out, double *__restrict__ M_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pad) return;
-    if (i >= n) {
-        mu_out[i] = 0.0;
-        omega2_out[i] = 0.0;
-        return;
-    }
-    const double xi = x[i];
-    // largest j with grid[j] <= xi (the host has checked grid[0] <= xi <= grid[n_grid - 1])
-    int lo = 0, hi = model.n_grid - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (model.grid[mid] <= xi) lo = mid;
-        else hi = mid - 1;
-    }
-    const int j = lo;
+// 32 threads per kept pixel (8 pixels per workgroup): thread l evaluates series member l's two optical depths (two
+// `pow` calls: one thread per pixel doing all 62 of them made this a 127 us kernel, the longest step of context
+// creation), thread 0 sums them in numpy's order and forms the two factors, then the 32 threads share the pixel's
+// k + 2 interpolations.  Arithmetic per value unchanged.
+#define DLAGP_INTERP_PIXELS 8
+#define DLAGP_INTERP_THREADS (32 * DLAGP_INTERP_PIXELS)
+static_assert(DLAGP_MAX_LINES <= 32, "one thread per series member");
 
-    const double w = wavelengths[i];
-    double tau_prev[DLAGP_MAX_LINES], tau_noise[DLAGP_MAX_LINES];
+__global__ __launch_bounds__(DLAGP_INTERP_THREADS) void interp_model(
+    ModelDev model, int n, int n_pad, int k_out, const double *__restrict__ x, const double *__restrict__ wavelengths,
+    double z_qso, double *__restrict__ mu_out, double *__restrict__ omega2_out, double *__restrict__ M_out) {
+    __shared__ double tau_prev[DLAGP_INTERP_PIXELS][32], tau_noise[DLAGP_INTERP_PIXELS][32];
+    __shared__ double factor[DLAGP_INTERP_PIXELS][2];
+    __shared__ int cell[DLAGP_INTERP_PIXELS];
+    const int p = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int i = blockIdx.x * DLAGP_INTERP_PIXELS + p;
+    const bool real = i < n;
     const int L = model.num_forest_lines;
-    for (int l = 0; l < L; ++l) {
+    const double xi = real ? x[i] : 0.0;
+    if (real && l < L) {
+        const double w = wavelengths[i];
         const double z_abs = (w - model.lines[l]) / model.lines[l];
         const double base = 1.0 + z_abs;
         const double inside = z_abs <= z_qso ? 1.0 : 0.0;
-        tau_prev[l] = model.scale_prev[l] * pow(base, model.prev_beta) * inside;
-        tau_noise[l] = model.scale_noise[l] * pow(base, model.beta) * inside;
+        tau_prev[p][l] = model.scale_prev[l] * pow(base, model.prev_beta) * inside;
+        tau_noise[p][l] = model.scale_noise[l] * pow(base, model.beta) * inside;
     }
-    const double absorption = exp(-numpy_row_sum(tau_prev, L));
-    const double scaling = __dadd_rn(1.0 - exp(-numpy_row_sum(tau_noise, L)), model.c_0);
-
-    mu_out[i] = numpy_interp(model.grid, model.mu, j, model.n_grid, xi) * absorption;
-    double o2 = exp(2.0 * numpy_interp(model.grid, model.log_omega, j, model.n_grid, xi));
-    o2 = __dmul_rn(o2, __dmul_rn(scaling, scaling));
-    omega2_out[i] = __dmul_rn(o2, __dmul_rn(absorption, absorption));
-    for (int c = 0; c < k_out; ++c)
-        M_out[(long)i * k_out + c] =
-            c < model.k ? numpy_interp(model.grid, model.M + (long)c * model.n_grid, j, model.n_grid, xi) * absorption
-                        : 0.0;
+    if (real && l == 31) {
+        // largest j with grid[j] <= xi (the host has checked grid[0] <= xi <= grid[n_grid - 1])
+        int lo = 0, hi = model.n_grid - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (model.grid[mid] <= xi) lo = mid;
+            else hi = mid - 1;
+        }
+        cell[p] = lo;
+    }
+    __syncthreads();
+    if (real && l == 0) {
+        factor[p][0] = exp(-numpy_row_sum(tau_prev[p], L));
+        factor[p][1] = __dadd_rn(1.0 - exp(-numpy_row_sum(tau_noise[p], L)), model.c_0);
+    }
+    __syncthreads();
+    if (i >= n_pad) return;
+    if (!real) {  // padding pixels
+        if (l == 0) {
+            mu_out[i] = 0.0;
+            omega2_out[i] = 0.0;
+        }
+        return;
+    }
+    const int j = cell[p];
+    const double absorption = factor[p][0], scaling = factor[p][1];
+    for (int c = l; c < k_out + 2; c += 32) {
+        if (c < k_out) {
+            M_out[(long)i * k_out + c] =
+                c < model.k ? numpy_interp(model.grid, model.M + (long)c * model.n_grid, j, model.n_grid, xi) * absorption
+                            : 0.0;
+        } else if (c == k_out) {
+            mu_out[i] = numpy_interp(model.grid, model.mu, j, model.n_grid, xi) * absorption;
+        } else {
+            double o2 = exp(2.0 * numpy_interp(model.grid, model.log_omega, j, model.n_grid, xi));
+            o2 = __dmul_rn(o2, __dmul_rn(scaling, scaling));
+            omega2_out[i] = __dmul_rn(o2, __dmul_rn(absorption, absorption));
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -361,7 +386,23 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
 #define DLAGP_FIN_THREADS 256
 #define DLAGP_FIN_STAGED (DLAGP_FIN_COLS + DLAGP_FIN_K + 3)  // vech(B - I), u, 3 scalars
 #define DLAGP_FINALIZE_LDS_DOUBLES (DLAGP_FIN_STAGED * DLAGP_FIN_SAMPLES)
+// launches of up to this many blocks of 16 samples factor with 16 lanes per sample (latency-bound: few workgroups per
+// CU, the dependent chain of the one-lane form is what they wait for); larger launches keep one lane per sample
+#ifndef DLAGP_FIN_ROW16_MAX_BLOCKS
+#define DLAGP_FIN_ROW16_MAX_BLOCKS 4096
+#endif
 
+// f(integral_constant<int, I>) for I = BEGIN .. END - 1, unrolled at compile time (DPP controls and register indices
+// must be constants)
+template <int BEGIN, int END, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (BEGIN < END) {
+        f(std::integral_constant<int, BEGIN>{});
+        static_for<BEGIN + 1, END>(f);
+    }
+}
+
+template <bool ROW16>
 __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const double *__restrict__ part, int nsplit, long rows, long S,
                                                       const SightlineDev *__restrict__ sightlines,
                                                       double *__restrict__ out, int *__restrict__ status,
@@ -430,6 +471,84 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
             fin_lds[idx] = acc;
         }
     __syncthreads();
+    if constexpr (ROW16) {
+    // ---- factor + solve: SIXTEEN lanes per sample, all four waves (4 samples each).
+    // Lane q of a sample's row of 16 lanes holds row q of the sample's matrix (slot 0) and, for q <= 4, row 16 + q
+    // (slot 1) in registers; u rides along as row 20, so that its row of the factor is t = L^-1 u.  Right-looking: for
+    // column j the pivot and then the column's entries are handed round the 16 lanes with DPP row broadcasts (no LDS,
+    // no waits), every lane scales its own rows' entries and updates their trailing columns.  Every real entry sees
+    // the same operations in the same order as in the row-by-row form below (one lane per sample: a dependent chain
+    // of 1540 FMAs that took 17 of this kernel's 29 us on a 625-block launch) -- identical results.  Entries above
+    // the diagonal and rows 21..31 are scratch: updated like everything else, never read by a real entry.
+        const int smp = tid >> 4, q = tid & 15;
+        const double *col = fin_lds + smp;
+        double A0[16], A1[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            // row i < 20: vech(B - I) entry (i, k), the identity added on the diagonal (null_gp.py:341); row 20: u; columns
+            // beyond the row and rows 21..31 start at zero.  Branch-free: a clamped, always valid address and a select.
+            if (k < 16) {
+                const int kc = k < q ? k : q;
+                double v = col[(q * (q + 1) / 2 + kc) * NS];
+                v = k <= q ? v : 0.0;
+                if (k == q) v += 1.0;
+                A0[k] = v;
+            }
+            const int i = 16 + q, ic = i < K ? i : K;
+            const int kc = ic < K ? (k < ic ? k : ic) : k;
+            double v = col[(ic < K ? ic * (ic + 1) / 2 + kc : NC + k) * NS];
+            v = (i < K ? k <= i : i == K) ? v : 0.0;
+            if (k == i) v += 1.0;
+            A1[k] = v;
+        }
+        LogProduct pivots;
+        bool bad = false;
+        auto row_bcast = [](double v, auto lane_c) __attribute__((always_inline)) {
+            constexpr int ctrl = 0x150 + decltype(lane_c)::value;  // DPP row_newbcast: lane L of every row of 16 lanes
+            // every lane is written (full row and bank masks): the "old" operand is never kept, so hand in the source
+            const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), ctrl, 0xf, 0xf, false);
+            const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), ctrl, 0xf, 0xf, false);
+            return __hiloint2double(hi, lo);
+        };
+        // fully unrolled: every register index and DPP control below is a compile-time constant
+        auto column = [&](auto j_c) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_c)::value;
+            double s;
+            if constexpr (j < 16) s = row_bcast(A0[j], std::integral_constant<int, j>{});
+            else s = row_bcast(A1[j], std::integral_constant<int, j - 16>{});
+            if (s <= 0.0) bad = true;  // NaN pivots propagate silently, as LAPACK's do
+            pivots.multiply(s);        // log det B = sum log L_ii^2
+            const double inv = fast_rsqrt(s);
+            if constexpr (j < 16) A0[j] *= inv;  // rows > j: L_ij (row j itself and the rows above it: scratch)
+            A1[j] *= inv;
+            auto update = [&](auto k_c) __attribute__((always_inline)) {
+                constexpr int k = decltype(k_c)::value;
+                double lkj;
+                if constexpr (k < 16) lkj = row_bcast(A0[j], std::integral_constant<int, k>{});
+                else lkj = row_bcast(A1[j], std::integral_constant<int, k - 16>{});
+                if constexpr (k < 16) A0[k] = fma(-A0[j], lkj, A0[k]);
+                A1[k] = fma(-A1[j], lkj, A1[k]);
+            };
+            static_for<j + 1, K>(update);
+            __builtin_amdgcn_sched_barrier(0);  // columns in program order (the scheduler otherwise interleaves several)
+        };
+        static_for<0, K>(column);
+        if (q != 4 || smp >= valid) return;  // row 20 = t sits in lane 4; samples beyond S hold unwritten partials
+        double tt = 0.0;
+#pragma unroll
+        for (int m = 0; m < K; ++m) tt = fma(A1[m], A1[m], tt);
+        const double sum_r2 = col[(NC + K) * NS];
+        const double sum_logd = col[(NC + K + 1) * NS];
+        const double n_log_2pi = col[(NC + K + 2) * NS];
+        double result = -0.5 * ((sum_r2 - tt) + (sum_logd + pivots.log_value()) + n_log_2pi);
+        if (bad) {
+            result = __builtin_nan("");
+            atomicOr(status, 1);
+        }
+        out[row0 + smp] = result;
+        return;
+    }
+    // ---- factor + solve, one lane per sample (launches of many blocks: fewest instructions per sample)
     if (tid >= valid) return;  // lanes beyond the sightline's last sample hold unwritten partials
     const long row = row0 + tid;
     double *mine = fin_lds + tid;
@@ -456,8 +575,7 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
         for (int m = 0; m < i; ++m) s = fma(-r[m], r[m], s);
         if (s <= 0.0) bad = true;  // NaN pivots propagate silently, as LAPACK's do
         pivots.multiply(s);        // log det B = sum log L_ii^2
-        const double diag = sqrt(s);
-        const double inv = fast_rcp(diag);
+        const double inv = fast_rsqrt(s);  // the same pivot arithmetic as the 16-lane form
         inv_diag[i] = inv;
 #pragma unroll
         for (int j = 0; j < i; ++j) mine[vech_col(i, j) * NS] = r[j];
@@ -490,14 +608,14 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
 
 __global__ __launch_bounds__(DLAGP_EVIDENCE_THREADS) void level_evidence(double *__restrict__ ll, long S, int level,
                                                                        const unsigned char *__restrict__ too_close,
-                                                                       double *__restrict__ evidence) {
+                                                                       double *__restrict__ evidence, double log_s) {
     __shared__ double red[DLAGP_EVIDENCE_THREADS / 64];
     __shared__ double red2[DLAGP_EVIDENCE_THREADS / 64];
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     double *row = ll + blockIdx.x * S;
     const unsigned char *mask = too_close ? too_close + blockIdx.x * S : nullptr;
-    const double log_s = log((double)S);
+    // log_s = log(S) comes from the host: 1024 threads evaluating the same ~400-cycle log was 0.7 us of an 8 us kernel
 
     // Up to 16 values per thread stay in registers between the two passes, and all of a thread's loads are
     // issued before the first use (a load / store / load chain on the same array serialised on memory

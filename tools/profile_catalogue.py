@@ -47,6 +47,14 @@ def main():
     rbs.process_qso(spectra[:batch_size], z_qsos[:batch_size], params, FixedPrior(), dla, sub, learned, batch_size=batch_size)
     for name in ("sightline", "batch", "nulls", "sweep", "release"):
         setattr(rbs.DeviceEngine, name, timed(name, getattr(rbs.DeviceEngine, name)))
+    from gpy_dla_detection_amd import _lib, parallel, sightline
+
+    lib = _lib.load()
+    for cname in ("dlagp_batch_sweep", "dlagp_batch_null", "dlagp_create_from_model", "dlagp_batch_create",
+                  "dlagp_batch_destroy", "dlagp_destroy"):
+        setattr(lib, cname, timed("C:" + cname, getattr(lib, cname)))
+    sightline.DeviceBatch.sweep = timed("py:DeviceBatch.sweep", sightline.DeviceBatch.sweep)
+    parallel.resampling_uniforms = timed("py:resampling_uniforms", parallel.resampling_uniforms)
     rbs.prepare_data = timed("prepare_data", rbs.prepare_data)
     rbs.map_traceback = timed("map_traceback", rbs.map_traceback)
     rbs.occupation_log_priors = timed("log_priors", rbs.occupation_log_priors)
