@@ -397,8 +397,8 @@ def main() -> None:
     if args.debug & 2:
         st = sl.debug_read()
         if rank == 0 and st[5]:
-            names = ["voigt", "conv", "mfma_loop", "epilogue", "wave_total"]
-            print("stamps: waves=%d  " % st[5] + "  ".join("%s=%.0f" % (n, st[i] / st[5]) for i, n in enumerate(names)) + "  (cycles per wave)", file=sys.stderr)
+            names = ["voigt", "conv", "mfma_loop", "epilogue", "passes+epilogue", None, "prologue"]
+            print("stamps: waves=%d  " % st[5] + "  ".join("%s=%.0f" % (n, st[i] / st[5]) for i, n in enumerate(names) if n) + "  (cycles per wave)", file=sys.stderr)
 
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)

@@ -208,7 +208,7 @@ __device__ __forceinline__ G as_global(const T *p) {
 
 // Diagnostic cycle stamps (debug bit 1): per-phase shader-clock totals over all waves, read back with
 // dlagp_debug_read.  Slots: 0 Voigt sample loop, 1 convolution, 2 weights + MFMA loop, 3 epilogue,
-// 4 whole wave, 5 wave count.  Compiled only into the STAMPS instantiations of the kernel.
+// 4 pass loop + epilogue, 5 wave count, 6 prologue.  Compiled only into the STAMPS instantiations of the kernel.
 __device__ unsigned long long DLAGP_STAMPS[8];
 #ifdef DLAGP_TRACE_BUILD
 // diagnostic build only (tools/wave_timeline.py): per work item {start, end (100 MHz real time), HW_ID | XCC_ID << 32, passes}
@@ -293,6 +293,8 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     // (A/B on one device, -5 % kernel time against equal priorities): Voigt loop 2, the latency-bound parts
     // (pass set-up, convolution) 1, the dependent weight arithmetic at the head of each step 3, MFMAs 0.
     __builtin_amdgcn_s_setprio(2);
+    unsigned long long t_entry = 0;
+    if (STAMPS) t_entry = stamp_now();
     const WorkItem &item = items[blockIdx.x];
     const int b = __builtin_amdgcn_readfirstlane(item.b);
     const SightlineDev &sl = sightlines[b];
@@ -971,6 +973,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         atomicAdd(&DLAGP_STAMPS[3], now - t_mark);
         atomicAdd(&DLAGP_STAMPS[4], now - t_start);
         atomicAdd(&DLAGP_STAMPS[5], 1ULL);
+        atomicAdd(&DLAGP_STAMPS[6], t_start - t_entry);  // prologue: descriptor, per-sample constants, core patch table
     }
 }
 

@@ -1447,6 +1447,93 @@ def test_async_device_sweeps_survive_growth_of_every_scratch_buffer():
     batch.close()
 
 
+def test_both_finalisations_give_the_same_numbers(restore_options):
+    """
+    finalize_rank20 factors with 16 lanes per sample on launches of up to `finalize_row16_blocks` blocks and with one
+    lane per sample beyond: every entry of the factor sees the same operations in the same order, so the two forms
+    agree bit for bit (full BASELINE size, one and two absorbers, the non-PD flag included).
+    """
+    from gpy_dla_detection_amd.sightline import DeviceSightline, get_option, set_option
+
+    sight = make_sightline(2)
+    dev = device_sightline(sight)
+    z, _, nhi = make_qmc_samples(sight, 10000)
+    z2, n2 = np.stack([z, z[::-1]], axis=1)[:3000], np.stack([nhi, nhi[::-1]], axis=1)[:3000]
+    default = get_option("finalize_row16_blocks")
+    assert default >= 625
+    try:
+        wide, wide2 = dev.eval(z, nhi), dev.eval(z2, n2)
+        set_option("finalize_row16_blocks", 0)
+        serial, serial2 = dev.eval(z, nhi), dev.eval(z2, n2)
+    finally:
+        set_option("finalize_row16_blocks", default)
+    np.testing.assert_array_equal(wide, serial)
+    np.testing.assert_array_equal(wide2, serial2)
+    st = oracle_state(sight)
+    from oracle import ref_like as R
+
+    for i in (0, 17, 4999, 9999):
+        want = R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]])
+        assert abs(wide[i] - want) <= RTOL_LL * abs(want)
+    neg = DeviceSightline(sight.y, sight.this_mu, 10.0 * sight.this_M, sight.this_omega2, -np.abs(sight.v),
+                          sight.padded_wavelengths, sight.keep)
+    for blocks in (default, 0):
+        set_option("finalize_row16_blocks", blocks)
+        try:
+            with pytest.raises(np.linalg.LinAlgError):
+                neg.eval(z[:64], nhi[:64])
+        finally:
+            set_option("finalize_row16_blocks", default)
+
+
+def test_long_sightline_and_concurrent_context_creation():
+    """
+    Context creation stages its uploads in a page-locked arena of the calling thread (one synchronisation per context):
+    a sightline three times the BASELINE length makes the arena grow mid-sequence, and contexts built by several
+    threads at once (the catalogue driver's workers) stay independent.  Both against the oracle.
+    """
+    import threading
+
+    from oracle import ref_like as R
+
+    big = make_sightline(6, n_unmasked=9100, n_masked=140)
+    dev = device_sightline(big)
+    z, _, nhi = make_qmc_samples(big, 48)
+    got = dev.eval(z, nhi)
+    st = oracle_state(big)
+    for i in (0, 11, 47):
+        want = R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]])
+        assert abs(got[i] - want) <= RTOL_LL * abs(want)
+    assert abs(dev.null() - R.null_log_model_evidence(st)) <= RTOL_LL * abs(R.null_log_model_evidence(st))
+    dev.close()
+
+    sights = [make_sightline(10 + i, n_unmasked=500 + 37 * i, n_masked=5 + i) for i in range(12)]
+    results, errors = [None] * len(sights), []
+
+    def work(lo, hi):
+        try:
+            for i in range(lo, hi):
+                for _ in range(3):  # create / evaluate / destroy: the pool hands buffers from thread to thread
+                    d = device_sightline(sights[i])
+                    zz, _, nn = make_qmc_samples(sights[i], 32)
+                    results[i] = (zz, nn, d.eval(zz, nn), d.null())
+                    d.close()
+        except Exception as exc:  # surfaced below: an assertion inside a thread would otherwise vanish
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(lo, lo + 3)) for lo in range(0, len(sights), 3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for sight, (zz, nn, ll, null) in zip(sights, results):
+        st = oracle_state(sight)
+        want = np.array([R.sample_log_likelihood_k_dlas(st, [zz[i]], [nn[i]]) for i in (0, 31)])
+        np.testing.assert_allclose(ll[[0, 31]], want, rtol=RTOL_LL)
+        assert abs(null - R.null_log_model_evidence(st)) <= RTOL_LL * abs(null)
+
+
 def test_device_entry_points_are_graph_capturable():
     """
     dlagp_eval_device + dlagp_level_evidence_device only enqueue work on the caller's stream once the workspace
