@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """
-profiles/r02_pmc_traffic.json from the per-kernel counter means tools/pmc_pass.sh printed (one rocprofv3 --pmc pass per
+profiles/r03_pmc_traffic.json from the per-kernel counter means tools/pmc_pass.sh printed (one rocprofv3 --pmc pass per
 counter group of `bench.py --steps 5 --warmup 1 --ramp-ms 0 --no-cpu-baseline`), gfx950 read-side correction applied
 (MI355X_MICROARCH.md, HBM: FETCH_SIZE counts 128-byte requests at 64 bytes for 16-byte-per-lane streaming reads).
-usage: tools/summarise_pmc.py gpurun_out/pmc_r02_counters.txt > profiles/r02_pmc_traffic.json
+usage: tools/summarise_pmc.py gpurun_out/pmc_r02_counters.txt > profiles/r03_pmc_traffic.json
 """
 import json
 import re
