@@ -32,6 +32,7 @@ SIGNATURES = {
     "dlagp_model_destroy": (None, [c_void_p]),
     "dlagp_create_from_model": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int, _dp, _dp, _dp, _dp, c_double,
                                         _dp, POINTER(c_ubyte), c_int, c_int]),
+    "dlagp_setup_sync": (c_int, [c_int]),
     "dlagp_ctx_read_model": (c_int, [c_void_p, _dp, _dp, _dp]),
     "dlagp_ctx_n": (c_int, [c_void_p]),
     "dlagp_ctx_k": (c_int, [c_void_p]),

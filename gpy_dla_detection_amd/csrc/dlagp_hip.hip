@@ -371,6 +371,7 @@ struct dlagp_ctx {
     DeviceBuffer Pm, slot_pixel, slot_pos;  // MFMA path: slot-ordered operand and slot tables
     DeviceBuffer dense_M;      // interpolated / uploaded factor, row-major [n][k], kept for dlagp_ctx_read_model
     DeviceBuffer scratch_a, scratch_b;  // inputs of the set-up kernels, released once the set-up stream has drained
+    bool setup_pending = false;         // created with DLAGP_FLAG_DEFER_SYNC and not known to be complete yet
     std::vector<int> h_pos;    // host copy of pos[]
     std::vector<int> h_slot_pos;  // window start of every slot (padding slots repeat their chunk's last pixel), for planning
     bool mfma_ok = false;      // rank padded to 20
@@ -1048,7 +1049,7 @@ static int upload_staged(void *dst, const void *src, size_t bytes, int device) {
 
 // fill the group-level summary from its members and upload the descriptor table; `positions`: where each member
 // sits in the caller's arrays (a part of a heterogeneous batch), default 0, 1, 2, ...
-static int finish_group(LaunchGroup &g, const std::vector<int> *positions = nullptr) {
+static int finish_group(LaunchGroup &g, const std::vector<int> *positions = nullptr, bool defer_sync = false) {
     std::vector<SightlineDev> table;
     g.k = g.ctxs[0]->sl.k;
     g.row_width = g.ctxs[0]->sl.row_width;
@@ -1074,7 +1075,7 @@ static int finish_group(LaunchGroup &g, const std::vector<int> *positions = null
     if (rc) return rc;
     // the table must be in place before the group's first launch, which runs on the caller's stream
     if ((rc = upload_staged(g.d_table.ptr, table.data(), table.size() * sizeof(SightlineDev), g.device))) return rc;
-    return setup_sync(g.device);
+    return defer_sync ? DLAGP_OK : setup_sync(g.device);
 }
 
 // A batch whose members could each run the MFMA kernel but differ in line count, broadening or Lyman-limit flag:
@@ -1109,6 +1110,7 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
                           int num_lines, int flags, int device, Fill fill) {
     const int broadening = flags & DLAGP_FLAG_BROADENING;
     const int lls_break = (flags & DLAGP_FLAG_LLS_BREAK) != 0;
+    const bool defer_sync = (flags & DLAGP_FLAG_DEFER_SYNC) != 0;
     if (!out) return fail(DLAGP_EINVAL, "out is NULL");
     *out = nullptr;
     if (!wavelengths || !keep) return fail(DLAGP_EINVAL, "NULL input array");
@@ -1116,7 +1118,8 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     if (k < 1 || k > DLAGP_MAX_RANK) return fail(DLAGP_EINVAL, "rank k=%d outside [1, %d]", k, DLAGP_MAX_RANK);
     if (num_lines < 1 || num_lines > DLAGP_MAX_LINES)
         return fail(DLAGP_EINVAL, "num_lines=%d outside [1, %d]", num_lines, DLAGP_MAX_LINES);
-    if (flags & ~(DLAGP_FLAG_BROADENING | DLAGP_FLAG_LLS_BREAK)) return fail(DLAGP_EINVAL, "unknown flag bits 0x%x", flags);
+    if (flags & ~(DLAGP_FLAG_BROADENING | DLAGP_FLAG_LLS_BREAK | DLAGP_FLAG_DEFER_SYNC))
+        return fail(DLAGP_EINVAL, "unknown flag bits 0x%x", flags);
     int kept = 0;
     for (int j = 0; j < n_u; ++j) kept += keep[j] != 0;
     if (kept != n)
@@ -1241,9 +1244,14 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     }
     ctx->self.device = device;
     ctx->self.ctxs.push_back(ctx);
-    rc = finish_group(ctx->self);  // ends with the one synchronisation of the whole set-up sequence
-    ctx->scratch_a.release();      // temporaries of the set-up kernels (the stream is idle now)
-    ctx->scratch_b.release();
+    // ends with the one synchronisation of the whole set-up sequence -- unless the caller defers it to the batch it is
+    // building (DLAGP_FLAG_DEFER_SYNC); the kernels' temporaries then stay with the context until it is destroyed
+    rc = finish_group(ctx->self, nullptr, defer_sync);
+    ctx->setup_pending = defer_sync;
+    if (!defer_sync) {
+        ctx->scratch_a.release();
+        ctx->scratch_b.release();
+    }
     if (rc) {
         (void)setup_sync(device);
         dlagp_destroy(ctx);
@@ -1367,6 +1375,11 @@ void dlagp_model_destroy(dlagp_model *model) {
     delete model;
 }
 
+int dlagp_setup_sync(int device) {
+    int rc = ensure_device(device);
+    return rc ? rc : setup_sync(device);
+}
+
 int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, int n_u, const double *x,
                             const double *y, const double *v, const double *this_wavelengths, double z_qso,
                             const double *wavelengths, const uint8_t *keep, int num_lines, int broadening) {
@@ -1420,6 +1433,9 @@ int dlagp_ctx_read_model(dlagp_ctx *ctx, double *this_mu, double *this_M, double
 void dlagp_destroy(dlagp_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    // deferred set-up (DLAGP_FLAG_DEFER_SYNC) that nobody waited for: its copies and kernels may still be writing the
+    // buffers released below.  The creating thread's stream is not known here: wait for the device.
+    if (ctx->setup_pending) (void)hipDeviceSynchronize();
     {
         // batches are meant to be destroyed before their members; if one is still alive, its launches may be using
         // this context's arrays
@@ -1562,7 +1578,9 @@ int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
         std::lock_guard<std::mutex> lock(g_membership_mutex);
         for (dlagp_ctx *ctx : batch->group.ctxs) ctx->batches.push_back(batch);
     }
-    int rc = finish_group(batch->group);
+    int rc = finish_group(batch->group);  // synchronises the calling thread's set-up stream: deferred members are complete
+    if (!rc)
+        for (dlagp_ctx *ctx : batch->group.ctxs) ctx->setup_pending = false;
     if (!rc) rc = split_mixed_batch(batch->group);
     if (rc) {
         dlagp_batch_destroy(batch);

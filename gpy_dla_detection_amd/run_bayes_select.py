@@ -99,9 +99,11 @@ class DeviceEngine:
 
         keep = ~state["pixel_mask"][state["ind_unmasked"]]  # dla_gp.py:360
         grid = state["padded_wavelengths"] if broadening else state["unmasked_wavelengths"]
+        # no wait per spectrum: `batch()` below ends with the one synchronisation that covers the batch's members (each
+        # wait would queue behind the waves of the sweep that is running meanwhile)
         return DeviceSightline.from_model(
             self.model, state["x"], state["y"], state["v"], state["this_wavelengths"], z_qso, grid, keep,
-            num_lines=self.params.num_lines, broadening=broadening)
+            num_lines=self.params.num_lines, broadening=broadening, defer_sync=True)
 
     def batch(self, sightlines):
         from .sightline import DeviceBatch

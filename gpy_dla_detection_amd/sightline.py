@@ -85,11 +85,15 @@ class DeviceSightline:
 
     @classmethod
     def from_model(cls, model: DeviceModel, x, y, v, this_wavelengths, z_qso: float, wavelengths, keep,
-                   num_lines: int = 3, broadening: bool = True, lls_break: bool = False):
+                   num_lines: int = 3, broadening: bool = True, lls_break: bool = False, defer_sync: bool = False):
         """
         NullGP.get_interp on the device (dlagp_create_from_model): the GP mean, factor and absorption
         noise are interpolated from `model` at the kept pixels' rest wavelengths `x` and suppressed by
         the Lyman-series mean flux at the observed `this_wavelengths` (reference null_gp.py:179-242).
+
+        `defer_sync` (batch drivers): do not wait for the context's set-up work; the sightline may only be used after
+        THIS thread has built a `DeviceBatch` with it (or called `setup_sync`) -- one wait per batch instead of one per
+        spectrum.
         """
         lib = _lib.load()
         x, y, v, this_wavelengths = (_lib.as_f64(a) for a in (x, y, v, this_wavelengths))
@@ -107,7 +111,7 @@ class DeviceSightline:
             ctypes.byref(handle), model._handle, n, n_u, _lib.ptr(x), _lib.ptr(y), _lib.ptr(v),
             _lib.ptr(this_wavelengths), float(z_qso), _lib.ptr(wavelengths),
             keep.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), int(num_lines),
-            int(bool(broadening)) | (2 if lls_break else 0)))
+            int(bool(broadening)) | (2 if lls_break else 0) | (4 if defer_sync else 0)))
         self = cls.__new__(cls)
         self._handle = handle
         self.n, self.k, self.device = n, model.k, model.device
@@ -308,6 +312,11 @@ def level_evidence_device(d_ll: int, nb: int, S: int, level: int, d_evidence: in
     """
     _lib.check(_lib.load().dlagp_level_evidence_device(d_ll, nb, S, level, d_too_close or None, d_evidence,
                                                        device, stream))
+
+
+def setup_sync(device: int = 0) -> None:
+    """wait for the calling thread's deferred context set-up work (`DeviceSightline.from_model(..., defer_sync=True)`)"""
+    _lib.check(_lib.load().dlagp_setup_sync(int(device)))
 
 
 def set_option(name: str, value: int) -> None:

@@ -58,6 +58,14 @@ extern "C" {
                                    a log-uniform grid (and the deeper levels of a sweep, which
                                    multiply cached profiles) run the MFMA kernel, the rest the
                                    generic one */
+#define DLAGP_FLAG_DEFER_SYNC 4 /* batch drivers: return without waiting for the context's uploads
+                                   and set-up kernels (they run on the calling thread's set-up
+                                   stream).  The context may only be USED after the same thread has
+                                   created a batch with it (dlagp_batch_create ends with the one
+                                   synchronisation that covers all its members) or called
+                                   dlagp_setup_sync; destroying it is always safe.  Creating the
+                                   contexts of a catalogue batch costs one wait instead of one per
+                                   spectrum (each wait queues behind the running sweep's waves) */
 
 typedef struct dlagp_ctx dlagp_ctx;     /* one sightline's model + data, resident in HBM    */
 typedef struct dlagp_batch dlagp_batch; /* a launch group of sightlines on one device       */
@@ -133,6 +141,9 @@ void dlagp_model_destroy(dlagp_model *model);
  * num_lines / broadening as in dlagp_create.  A rest wavelength outside the model grid returns
  * DLAGP_EINVAL (scipy's interp1d raises ValueError there).  The context lives on the model's device.
  */
+/* waits for the calling thread's pending context set-up work on `device` (see DLAGP_FLAG_DEFER_SYNC) */
+int dlagp_setup_sync(int device);
+
 int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, int n_u,
                             const double *x, const double *y, const double *v,
                             const double *this_wavelengths, double z_qso,

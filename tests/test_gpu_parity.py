@@ -904,6 +904,45 @@ def test_device_interpolation_matches_reference_golden():
                                    host.padded_wavelengths, ~host.pixel_mask[host.ind_unmasked])
 
 
+def test_deferred_context_set_up_completes_with_the_batch():
+    """
+    DLAGP_FLAG_DEFER_SYNC (the catalogue driver): contexts created without waiting for their uploads and set-up kernels are
+    complete once the same thread has built a batch with them -- same numbers as contexts created one wait at a time -- and
+    a pending context may be destroyed without ever having been waited for.
+    """
+    from gpy_dla_detection_amd.null_gp import NullGP
+    from gpy_dla_detection_amd.set_parameters import Parameters
+    from gpy_dla_detection_amd.sightline import DeviceBatch, DeviceModel, DeviceSightline, setup_sync
+    from tests.golden_inputs import raw_spectrum_and_model
+
+    z_qso, rest, flux, nv, mask, rest_grid, mu, M, log_omega, lc0, lt0, lb = raw_spectrum_and_model()
+    params = Parameters()
+    host = NullGP(params, FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb)
+    host.set_data(rest, flux, nv, mask, z_qso, normalize=True, build_model=False)
+    model = DeviceModel(rest_grid, mu, np.asfortranarray(M), log_omega, lc0, lt0, lb, num_forest_lines=params.num_forest_lines)
+    keep = ~host.pixel_mask[host.ind_unmasked]
+
+    def make(defer, scale=1.0):
+        return DeviceSightline.from_model(model, host.x, scale * host.y, host.v, host.this_wavelengths, z_qso,
+                                          host.padded_wavelengths, keep, defer_sync=defer)
+
+    S = 200
+    z = 2.2 + 0.5 * halton(S, 2)
+    nhi = 10.0 ** (20.0 + 2.5 * halton(S, 3))
+    waited = DeviceBatch([make(False, 1.0 + 0.01 * i) for i in range(6)])
+    want, want_null = waited.eval(np.tile(z, (6, 1)), np.tile(nhi, (6, 1))), waited.nulls()
+    deferred = [make(True, 1.0 + 0.01 * i) for i in range(6)]
+    batch = DeviceBatch(deferred)  # ends with the one synchronisation
+    np.testing.assert_array_equal(batch.eval(np.tile(z, (6, 1)), np.tile(nhi, (6, 1))), want)
+    np.testing.assert_array_equal(batch.nulls(), want_null)
+    single = make(True)
+    setup_sync(0)
+    assert abs(single.null() - want_null[0]) <= 1e-13 * abs(want_null[0])
+    for _ in range(20):  # never waited for: destroy must cope
+        make(True).close()
+    assert abs(make(False).null() - want_null[0]) <= 1e-13 * abs(want_null[0])
+
+
 # ------------------------------------------------------------------------------------------------
 # f3: the catalogue driver end to end on the device vs the reference's own loop body (G8)
 # ------------------------------------------------------------------------------------------------
@@ -1161,7 +1200,7 @@ def test_lls_profile_matches_reference_golden_and_oracle():
         k8 = np.ascontiguousarray(keep, dtype=np.uint8)
         _lib.check(_lib.load().dlagp_create(ctypes.byref(h), n, n_u, 20, _lib.ptr(y), _lib.ptr(mu), _lib.ptr(M), 20, 1,
                                             _lib.ptr(omega2), _lib.ptr(v), _lib.ptr(grid),
-                                            k8.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), 3, 4, 0))  # unknown flag bit
+                                            k8.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), 3, 8, 0))  # unknown flag bit
 
 
 def test_lls_gp_class_runs_the_sweep_with_the_break():
