@@ -1387,6 +1387,49 @@ def test_randomised_sightlines_against_oracle(restore_options):
     assert worst < RTOL_LL
 
 
+def test_randomised_device_sweeps_against_the_oracle_driven_host_levels():
+    """
+    The whole device chain against the oracle: batches of 1..4 random sightlines of random flavour (3 / 5 / 1 lines, with and
+    without broadening), random sample counts, depths 1..4, the levels chained on the device (accumulate, finalize,
+    separation mask, evidence, resampling, profile cache) -- against `parallel.sweep_batch` around the ORACLE as evaluator
+    (the reference's level logic in NumPy): same base indices, same NaN pattern, evidences and likelihoods to 1e-9.
+    """
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+    from oracle import ref_like as R
+
+    rng = np.random.default_rng(31)
+    flavours = [dict(), dict(), dict(broadening=False), dict(num_lines=5), dict(num_lines=1)]
+    for trial in range(8):
+        nb = int(rng.integers(1, 5))
+        S = int(rng.integers(20, 90))
+        max_dlas = int(rng.integers(1, 5))
+        sights, states, devs = [], [], []
+        for b in range(nb):
+            n_u = int(rng.integers(80, 520))
+            sight = make_sightline(2000 + 10 * trial + b, n_unmasked=n_u, n_masked=int(rng.integers(0, n_u // 10)))
+            f = flavours[int(rng.integers(0, len(flavours)))]
+            sights.append(sight)
+            states.append(oracle_state(sight, num_lines=f.get("num_lines", 3), broadening=f.get("broadening", True)))
+            devs.append(device_sightline(sight, **f))
+        zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+        nhi = make_qmc_samples(sights[0], S)[2]
+        min_sep = 3000.0e3 / 299792458.0
+
+        def oracle_eval(z, n):
+            return np.stack([np.array([R.sample_log_likelihood_k_dlas(st, z[b][i], n[b][i]) for i in range(z.shape[1])])
+                             for b, st in enumerate(states)])
+
+        want = parallel.sweep_batch(oracle_eval, zs, nhi, max_dlas, min_sep, seed=trial)
+        batch = DeviceBatch(devs)
+        got = parallel.sweep_batch_device(batch, zs, nhi, max_dlas, min_sep, seed=trial)
+        batch.close()
+        np.testing.assert_array_equal(got[2], want[2], err_msg="trial %d" % trial)
+        assert np.array_equal(np.isnan(got[1]), np.isnan(want[1])), trial
+        np.testing.assert_allclose(got[1], want[1], rtol=RTOL_LL, equal_nan=True, err_msg="trial %d" % trial)
+        np.testing.assert_allclose(got[0], want[0], rtol=RTOL_LL, equal_nan=True, err_msg="trial %d" % trial)
+
+
 def test_async_launches_survive_scratch_growth_and_destroy():
     """
     Stream rules of the *_device entry points (include/dlagp.h): a launch that needs larger scratch drains the stream
