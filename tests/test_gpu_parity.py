@@ -276,6 +276,70 @@ def test_edge_cases_and_errors():
     assert np.isnan(dev.eval(z[:1], [np.nan])[0])
 
 
+def test_extreme_shapes_against_the_oracle():
+    """
+    Shapes at the ends of what the boundary accepts, each against the oracle: one kept pixel, fewer pixels than a chunk,
+    every pixel but the ends masked, rank 1 and rank 64, eight absorbers per sample with 31 lines (too large for the MFMA
+    kernel's per-sample constants: generic kernel), and 100 000 samples of one sightline in a single launch.
+    """
+    from gpy_dla_detection_amd.sightline import DeviceSightline, get_option
+    from oracle import ref_like as R
+
+    rng = np.random.default_rng(5)
+
+    def tiny(n_u, keep, k):
+        wl = 3900.0 * 10.0 ** (1e-4 * np.arange(-3, n_u + 3))
+        n = int(keep.sum())
+        M = 0.1 * rng.standard_normal((n, k))
+        return dict(y=1.0 + 0.1 * rng.standard_normal(n), this_mu=np.ones(n), this_M=M, this_omega2=0.01 * np.ones(n),
+                    v=0.02 * np.ones(n), padded_wavelengths=wl, unmasked_wavelengths=wl[3:-3], keep=keep)
+
+    cases = [
+        tiny(1, np.ones(1, bool), 20),
+        tiny(5, np.ones(5, bool), 20),
+        tiny(40, np.r_[True, np.zeros(38, bool), True], 20),
+        tiny(33, rng.random(33) > 0.3, 1),
+        tiny(70, rng.random(70) > 0.1, 64),
+    ]
+    for case in cases:
+        st = R.SpectrumState(**case)
+        dev = DeviceSightline(case["y"], case["this_mu"], case["this_M"], case["this_omega2"], case["v"],
+                              case["padded_wavelengths"], case["keep"])
+        z = np.array([2.2100, 2.2113, 2.2127])  # Lyman alpha inside and next to the few pixels
+        nhi = np.array([1e20, 3e21, 1e22])
+        got = dev.eval(z, nhi)
+        want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in range(3)])
+        np.testing.assert_allclose(got, want, rtol=RTOL_LL, atol=1e-12)
+        got2 = dev.eval(np.stack([z, z[::-1]], 1), np.stack([nhi, nhi[::-1]], 1))
+        want2 = np.array([R.sample_log_likelihood_k_dlas(st, [z[i], z[2 - i]], [nhi[i], nhi[2 - i]]) for i in range(3)])
+        np.testing.assert_allclose(got2, want2, rtol=RTOL_LL, atol=1e-12)
+        null = R.null_log_model_evidence(st)
+        assert abs(dev.null() - null) <= RTOL_LL * abs(null) + 1e-12
+        dev.close()
+    # eight absorbers x 31 lines
+    sight = make_sightline(8, n_unmasked=300, n_masked=9)
+    dev = device_sightline(sight, num_lines=31)
+    st = oracle_state(sight, num_lines=31)
+    z, _, nhi = make_qmc_samples(sight, 8)
+    z8, n8 = np.stack([np.roll(z, j) for j in range(8)], 1), np.stack([np.roll(nhi, j) for j in range(8)], 1)
+    got = dev.eval(z8, n8)
+    want = np.array([R.sample_log_likelihood_k_dlas(st, z8[i], n8[i]) for i in range(8)])
+    np.testing.assert_allclose(got, want, rtol=RTOL_LL)
+    # 100 000 samples in one launch (6250 blocks of 16: beyond the 16-lane finalisation's range)
+    sight = make_sightline(9, n_unmasked=420, n_masked=11)
+    dev = device_sightline(sight)
+    st = oracle_state(sight)
+    S = 100000
+    z, _, nhi = make_qmc_samples(sight, S)
+    got = dev.eval(z, nhi)
+    assert get_option("last_launch_path") == 2 and np.all(np.isfinite(got))
+    pick = [0, 1, 15, 16, 4097, 65535, 65536, S - 1]
+    want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in pick])
+    np.testing.assert_allclose(got[pick], want, rtol=RTOL_LL)
+    # a smaller launch cuts the pixels differently (another summation order): equal to rounding
+    np.testing.assert_allclose(got[:640], dev.eval(z[:640], nhi[:640]), rtol=1e-13)
+
+
 def test_batch_equals_single_sightline_launches():
     from gpy_dla_detection_amd.sightline import DeviceBatch
 
