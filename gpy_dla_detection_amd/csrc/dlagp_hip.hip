@@ -132,12 +132,12 @@ static int ensure_device(int device) {
     lc.c = DLAGP_SPEED_OF_LIGHT_CGS;
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(DLAGP_LINES), &lc, sizeof(lc)));
     // finalize_rank20 stages its partial sums in dynamic LDS
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_rank20<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double))));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_rank20<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double))));
+    for (const void *fn : {reinterpret_cast<const void *>(finalize_rank20<true, true>),
+                           reinterpret_cast<const void *>(finalize_rank20<true, false>),
+                           reinterpret_cast<const void *>(finalize_rank20<false, true>),
+                           reinterpret_cast<const void *>(finalize_rank20<false, false>)})
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double))));
     g_device_ready[device] = 1;
     return DLAGP_OK;
 }
@@ -785,14 +785,12 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
     if (g.k == DLAGP_FIN_K) {
         const size_t lds_bytes = DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double);
         const bool row16 = (int64_t)nblocks <= g_opt_finalize_row16_blocks;
-        if (row16)
-            hipLaunchKernelGGL(finalize_rank20<true>, dim3((unsigned)nblocks), dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
-                               ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
-                               plan ? plan->counts.as<const unsigned char>() : nullptr);
-        else
-            hipLaunchKernelGGL(finalize_rank20<false>, dim3((unsigned)nblocks), dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
-                               ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
-                               plan ? plan->counts.as<const unsigned char>() : nullptr);
+        // which layout the partial sums are in: the MFMA kernel's tiles as they come, or the generic kernel's columns
+        auto fin = row16 ? (use_mfma ? finalize_rank20<true, true> : finalize_rank20<true, false>)
+                         : (use_mfma ? finalize_rank20<false, true> : finalize_rank20<false, false>);
+        hipLaunchKernelGGL(fin, dim3((unsigned)nblocks), dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
+                           ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
+                           plan ? plan->counts.as<const unsigned char>() : nullptr);
     } else {
         const int threads = DLAGP_FINALIZE_THREADS;
         hipLaunchKernelGGL(finalize_samples<0>, dim3((unsigned)((rows + threads - 1) / threads)), dim3(threads), 0,

@@ -385,7 +385,8 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
 #define DLAGP_FIN_SAMPLES 16   // samples per workgroup: small, so that every CU pulls partial sums
 #define DLAGP_FIN_THREADS 256
 #define DLAGP_FIN_STAGED (DLAGP_FIN_COLS + DLAGP_FIN_K + 3)  // vech(B - I), u, 3 scalars
-#define DLAGP_FINALIZE_LDS_DOUBLES (DLAGP_FIN_STAGED * DLAGP_FIN_SAMPLES)
+#define DLAGP_FIN_LDS_STRIDE 17  // doubles per staged column in LDS: odd, so that columns two apart fall on different banks
+#define DLAGP_FINALIZE_LDS_DOUBLES (DLAGP_FIN_STAGED * DLAGP_FIN_LDS_STRIDE)
 // launches of up to this many blocks of 16 samples factor with 16 lanes per sample (latency-bound: few workgroups per
 // CU, the dependent chain of the one-lane form is what they wait for); larger launches keep one lane per sample
 #ifndef DLAGP_FIN_ROW16_MAX_BLOCKS
@@ -402,7 +403,20 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-template <bool ROW16>
+// Where the MFMA kernel leaves element (sample, column) of a block's partial sums (a block-piece is row_width x 16
+// doubles, as in the column-major layout of the generic kernel): its 14 full tiles as the MFMA hands them out, two
+// accumulator registers per store -- [tile][r >> 1][lane][r & 1], lane = (sample & 3) * 16 + column-in-tile, r = sample >> 2 --
+// so that the kernel's epilogue is 28 stores of 1 KB (16 bytes per lane: stores are issue-bound, MI355X_MICROARCH.md) and
+// no transposition through LDS; then the nine extras, 16 samples each: vech columns 208, 209, u 16..19 (the 4x4x4
+// MFMAs' outputs), sum r^2/d, sum log d, n log 2pi.
+#define DLAGP_NATIVE_EXTRAS (DLAGP_MFMA_BIG_TILES * 256)
+__host__ __device__ __forceinline__ int native_tile_offset(int tile, int sample, int cc) {
+    const int r = sample >> 2;
+    return ((tile * 2 + (r >> 1)) * 64 + ((sample & 3) << 4) + cc) * 2 + (r & 1);
+}
+
+// NATIVE: the partial sums come from the MFMA kernel (layout above); else from the generic kernel (column-major).
+template <bool ROW16, bool NATIVE>
 __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const double *__restrict__ part, int nsplit, long rows, long S,
                                                       const SightlineDev *__restrict__ sightlines,
                                                       double *__restrict__ out, int *__restrict__ status,
@@ -433,20 +447,48 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     // 16-byte loads: a thread takes two neighbouring samples of a column (the 16 samples of a column are 128
     // contiguous bytes), which halves the number of load instructions in flight per byte.
     typedef double d2 __attribute__((ext_vector_type(2)));
-    constexpr int PAIRS = DLAGP_FIN_STAGED * (NS / 2);
+    constexpr int LS = DLAGP_FIN_LDS_STRIDE;
+    // One staging item = 16 bytes of a block-piece and the two LDS slots they go to.
+    //   column-major layout: two neighbouring samples of one staged column (236 x 8 items);
+    //   native layout: one lane's register pair of a tile -- samples s and s + 4 of one column (14 x 2 x 64 items, in
+    //   memory order: perfectly coalesced), then the extras two samples at a time (9 x 8 items).
+    constexpr int TILE_ITEMS = DLAGP_MFMA_BIG_TILES * 128;
+    constexpr int PAIRS = NATIVE ? TILE_ITEMS + 9 * (NS / 2) : DLAGP_FIN_STAGED * (NS / 2);
     constexpr int ITER = (PAIRS + DLAGP_FIN_THREADS - 1) / DLAGP_FIN_THREADS;
+    const long piece_stride = nblocks * (long)rw * 16;
+    const double *piece0 = part + partial_index(0, nblocks, block, rw, 0, 0);
+    auto locate = [&](int idx, int &src, int &lds_a, int &lds_b) __attribute__((always_inline)) {
+        if constexpr (NATIVE) {
+            if (idx < TILE_ITEMS) {
+                const int cc = idx & 15, q = (idx >> 4) & 3, rp = (idx >> 6) & 1, t = idx >> 7;
+                const int c = (t < DLAGP_MFMA_W_TILES ? 16 * t : NC) + cc;  // tile 13 holds u 0..15
+                src = 2 * idx;
+                lds_a = c * LS + q + 8 * rp;  // sample q + 4 (2 rp)
+                lds_b = lds_a + 4;            // sample q + 4 (2 rp + 1)
+            } else {
+                const int e = (idx - TILE_ITEMS) >> 3, sp = 2 * ((idx - TILE_ITEMS) & 7);
+                const int c = e < 2 ? DLAGP_MFMA_SMALL_W_COL + e : (e < 6 ? NC + DLAGP_MFMA_SMALL_Q_COL + (e - 2) : NC + K + (e - 6));
+                src = DLAGP_NATIVE_EXTRAS + e * 16 + sp;
+                lds_a = c * LS + sp;
+                lds_b = lds_a + 1;
+            }
+        } else {
+            const int c = idx / (NS / 2), smp = 2 * (idx % (NS / 2));
+            src = (c < NC ? c : (c < NC + K ? qbase + (c - NC) : sbase + (c - NC - K))) * 16 + smp;
+            lds_a = c * LS + smp;
+            lds_b = lds_a + 1;
+        }
+    };
     auto stage = [&](auto nsplit_c) {
         constexpr int H = decltype(nsplit_c)::value;
         d2 v[ITER][H];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int idx = tid + it * DLAGP_FIN_THREADS;
-            const int cl = idx < PAIRS ? idx : tid;  // clamp: a valid address, value unused
-            const int c = cl / (NS / 2), smp = 2 * (cl % (NS / 2));
-            const int src = c < NC ? c : (c < NC + K ? qbase + (c - NC) : sbase + (c - NC - K));
+            int src, lds_a, lds_b;
+            locate(idx < PAIRS ? idx : tid, src, lds_a, lds_b);  // clamp: a valid address, value unused
 #pragma unroll
-            for (int h = 0; h < H; ++h)
-                v[it][h] = *reinterpret_cast<const d2 *>(part + partial_index(h, nblocks, block, rw, src, smp));
+            for (int h = 0; h < H; ++h) v[it][h] = *reinterpret_cast<const d2 *>(piece0 + h * piece_stride + src);
         }
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
@@ -454,7 +496,12 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
             d2 acc = d2{0.0, 0.0};
 #pragma unroll
             for (int h = 0; h < H; ++h) acc += v[it][h];
-            if (idx < PAIRS) *reinterpret_cast<d2 *>(fin_lds + 2 * idx) = acc;
+            int src, lds_a, lds_b;
+            locate(idx < PAIRS ? idx : tid, src, lds_a, lds_b);
+            if (idx < PAIRS) {
+                fin_lds[lds_a] = acc.x;
+                fin_lds[lds_b] = acc.y;
+            }
         }
     };
     if (nsplit == 1) stage(std::integral_constant<int, 1>{});
@@ -463,12 +510,13 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     else if (nsplit == 4) stage(std::integral_constant<int, 4>{});
     else if (nsplit == 5) stage(std::integral_constant<int, 5>{});
     else
-        for (int idx = tid; idx < DLAGP_FIN_STAGED * NS; idx += DLAGP_FIN_THREADS) {
-            const int c = idx / NS, smp = idx % NS;
-            const int src = c < NC ? c : (c < NC + K ? qbase + (c - NC) : sbase + (c - NC - K));
-            double acc = 0.0;
-            for (int h = 0; h < nsplit; ++h) acc += part[partial_index(h, nblocks, block, rw, src, smp)];
-            fin_lds[idx] = acc;
+        for (int idx = tid; idx < PAIRS; idx += DLAGP_FIN_THREADS) {
+            int src, lds_a, lds_b;
+            locate(idx, src, lds_a, lds_b);
+            d2 acc = d2{0.0, 0.0};
+            for (int h = 0; h < nsplit; ++h) acc += *reinterpret_cast<const d2 *>(piece0 + h * piece_stride + src);
+            fin_lds[lds_a] = acc.x;
+            fin_lds[lds_b] = acc.y;
         }
     __syncthreads();
     if constexpr (ROW16) {
@@ -489,14 +537,14 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
             // beyond the row and rows 21..31 start at zero.  Branch-free: a clamped, always valid address and a select.
             if (k < 16) {
                 const int kc = k < q ? k : q;
-                double v = col[(q * (q + 1) / 2 + kc) * NS];
+                double v = col[(q * (q + 1) / 2 + kc) * LS];
                 v = k <= q ? v : 0.0;
                 if (k == q) v += 1.0;
                 A0[k] = v;
             }
             const int i = 16 + q, ic = i < K ? i : K;
             const int kc = ic < K ? (k < ic ? k : ic) : k;
-            double v = col[(ic < K ? ic * (ic + 1) / 2 + kc : NC + k) * NS];
+            double v = col[(ic < K ? ic * (ic + 1) / 2 + kc : NC + k) * LS];
             v = (i < K ? k <= i : i == K) ? v : 0.0;
             if (k == i) v += 1.0;
             A1[k] = v;
@@ -537,9 +585,9 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
         double tt = 0.0;
 #pragma unroll
         for (int m = 0; m < K; ++m) tt = fma(A1[m], A1[m], tt);
-        const double sum_r2 = col[(NC + K) * NS];
-        const double sum_logd = col[(NC + K + 1) * NS];
-        const double n_log_2pi = col[(NC + K + 2) * NS];
+        const double sum_r2 = col[(NC + K) * LS];
+        const double sum_logd = col[(NC + K + 1) * LS];
+        const double n_log_2pi = col[(NC + K + 2) * LS];
         double result = -0.5 * ((sum_r2 - tt) + (sum_logd + pivots.log_value()) + n_log_2pi);
         if (bad) {
             result = __builtin_nan("");
@@ -561,13 +609,13 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     for (int i = 0; i < K; ++i) {
         double r[K];
 #pragma unroll
-        for (int j = 0; j <= i; ++j) r[j] = mine[vech_col(i, j) * NS];
+        for (int j = 0; j <= i; ++j) r[j] = mine[vech_col(i, j) * LS];
         r[i] += 1.0;  // identity on the diagonal (null_gp.py:341)
 #pragma unroll
         for (int j = 0; j < i; ++j) {
             double s = r[j];
 #pragma unroll
-            for (int m = 0; m < j; ++m) s = fma(-r[m], mine[vech_col(j, m) * NS], s);
+            for (int m = 0; m < j; ++m) s = fma(-r[m], mine[vech_col(j, m) * LS], s);
             r[j] = s * inv_diag[j];
         }
         double s = r[i];
@@ -578,17 +626,17 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
         const double inv = fast_rsqrt(s);  // the same pivot arithmetic as the 16-lane form
         inv_diag[i] = inv;
 #pragma unroll
-        for (int j = 0; j < i; ++j) mine[vech_col(i, j) * NS] = r[j];
-        double ti = mine[(NC + i) * NS];
+        for (int j = 0; j < i; ++j) mine[vech_col(i, j) * LS] = r[j];
+        double ti = mine[(NC + i) * LS];
 #pragma unroll
         for (int m = 0; m < i; ++m) ti = fma(-r[m], t[m], ti);
         ti *= inv;
         t[i] = ti;
         tt = fma(ti, ti, tt);
     }
-    const double sum_r2 = mine[(NC + K) * NS];
-    const double sum_logd = mine[(NC + K + 1) * NS];
-    const double n_log_2pi = mine[(NC + K + 2) * NS];
+    const double sum_r2 = mine[(NC + K) * LS];
+    const double sum_logd = mine[(NC + K + 1) * LS];
+    const double n_log_2pi = mine[(NC + K + 2) * LS];
     double result = -0.5 * ((sum_r2 - tt) + (sum_logd + pivots.log_value()) + n_log_2pi);
     if (bad) {
         result = __builtin_nan("");

@@ -31,7 +31,7 @@
 //            a = sum_t taps_t raw[pos + t] (voigt.py:319, dla_gp.py:388), d = omega2 a^2 + v,
 //            r = y - mu a, w = a^2/d, q = a r/d, running sum r^2/d and product of d
 //            (dla_gp.py:392-394, null_gp.py:329-333,356), then the 16 MFMAs   (null_gp.py:339-354)
-// Output: partial sums part[piece][block][column][16] (partial_index) for the finalize kernel.
+// Output: partial sums part[piece][block][native layout, kernels_common.h] for finalize_rank20<.., NATIVE = true>.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -887,59 +887,31 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     }
     if (stamps) t_mark = stamp_now();
 
-    // ---------------- epilogue: partial sums to part[split][block][column][16] ----------------
-    // D layout: lane holds column (lane & 15) of rows (lane >> 4) + 4 r of the 16-sample tile.
-    // Transposed through LDS (raw[] is free now) so that each store writes 16 consecutive samples
-    // of 4 columns (4 x 128 B segments).
+    // ---------------- epilogue: partial sums of this (piece, block) for finalize_rank20<.., NATIVE> ----------------
+    // The 14 full tiles go out as the MFMA leaves them (D layout: lane holds column lane & 15 of sample
+    // (lane >> 4) + 4 r), two accumulator registers per store: 28 stores of 1 KB, 16 bytes per lane, no predicates (rows
+    // beyond S are never read back as results) and no transposition -- the finalisation sorts them into its LDS image
+    // while it sums the pieces (kernels_common.h, native_tile_offset).  Up to round 2 every tile went through LDS
+    // first and left in 56 stores of 8 bytes per lane.
     const int rw = sl.row_width;
     const long rows_left = S - sample0;  // valid samples of this wave
     const long ngroups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
     const long nblocks = (long)nb * ngroups;
-    // this wave's block of the partial sums: [column][16 samples], contiguous
     __attribute__((address_space(1))) double *base =
         (__attribute__((address_space(1))) double *)(part) + partial_index(split, nblocks, b * ngroups + group, rw, 0, 0);
-    constexpr int TR_STRIDE = 17;  // [16 columns][16 samples + 1]
-    // row layout of the finalize kernels (kernels_common.h): vech columns 0..223, then u at 224..
-    constexpr int QBASE = 14 * DLAGP_TILE_COLS;
-#ifndef DLAGP_EPILOGUE_TILES
-#define DLAGP_EPILOGUE_TILES 6  // tiles transposed per LDS round trip (3 fit raw[], 3 more a_lds[])
-#endif
-    constexpr int TILE_LDS = 16 * TR_STRIDE;
-    static_assert(3 * TILE_LDS <= 16 * DLAGP_RAW_STRIDE && 3 * TILE_LDS <= 16 * A_STRIDE, "transpose buffers");
-    static_assert(DLAGP_EPILOGUE_TILES >= 1 && DLAGP_EPILOGUE_TILES <= 6, "at most six tiles fit the two buffers");
+    typedef v2d __attribute__((address_space(1))) *gstore_d2;
+    const gstore_d2 tiles = (gstore_d2)base + lane;
 #pragma unroll
-    for (int t0 = 0; t0 < DLAGP_MFMA_NT; t0 += DLAGP_EPILOGUE_TILES) {
-#pragma unroll
-        for (int j = 0; j < DLAGP_EPILOGUE_TILES; ++j) {
-            if (t0 + j < DLAGP_MFMA_NT) {
-                double *buf = j < 3 ? raw + j * TILE_LDS : a_lds + (j - 3) * TILE_LDS;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) buf[s_loc * TR_STRIDE + slot + 4 * r] = acc[t0 + j][r];
-            }
-        }
-        lds_wave_sync();
-#pragma unroll
-        for (int j = 0; j < DLAGP_EPILOGUE_TILES; ++j) {
-            const int t = t0 + j;
-            if (t < DLAGP_MFMA_NT) {
-                const double *buf = j < 3 ? raw + j * TILE_LDS : a_lds + (j - 3) * TILE_LDS;
-                const int col0 = t < DLAGP_MFMA_NTW ? t * DLAGP_TILE_COLS : QBASE;
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const int col = cc * 4 + slot;  // lane -> (sample = s_loc, column = col)
-                    const double val = buf[col * TR_STRIDE + s_loc];
-                    if (s_loc < rows_left) base[(col0 + col) * 16 + s_loc] = val;  // 512 contiguous bytes
-                }
-            }
-        }
-        lds_wave_sync();
+    for (int t = 0; t < DLAGP_MFMA_NT; ++t) {
+        tiles[(t * 2 + 0) * 64] = v2d{acc[t][0], acc[t][1]};
+        tiles[(t * 2 + 1) * 64] = v2d{acc[t][2], acc[t][3]};
     }
     {
         // 4x4x4 outputs: lane = row * 16 + block * 4 + column  ->  sample = block * 4 + row
         const int smp = ((lane >> 2) & 3) * 4 + (lane >> 4), j = lane & 3;
         if (smp < rows_left) {
-            if (j < 2) base[(DLAGP_MFMA_SMALL_W_COL + j) * 16 + smp] = acc_sw;
-            base[(QBASE + DLAGP_MFMA_SMALL_Q_COL + j) * 16 + smp] = acc_sq;
+            if (j < 2) base[DLAGP_NATIVE_EXTRAS + j * 16 + smp] = acc_sw;  // vech columns 208, 209
+            base[DLAGP_NATIVE_EXTRAS + (2 + j) * 16 + smp] = acc_sq;       // u 16..19
         }
     }
     double logd = dprod.log_value();
@@ -948,10 +920,9 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     logd += __shfl_xor(logd, 16);
     logd += __shfl_xor(logd, 32);
     if (slot == 0 && s_loc < rows_left) {
-        constexpr int SBASE = 16 * DLAGP_TILE_COLS;  // (ntw + ntq) * 16 of the rank-20 row layout
-        base[SBASE * 16 + s_loc] = sum_r2;
-        base[(SBASE + 1) * 16 + s_loc] = logd;
-        base[(SBASE + 2) * 16 + s_loc] = split == 0 ? sl.n * DLAGP_LOG_2PI : 0.0;
+        base[DLAGP_NATIVE_EXTRAS + 6 * 16 + s_loc] = sum_r2;
+        base[DLAGP_NATIVE_EXTRAS + 7 * 16 + s_loc] = logd;
+        base[DLAGP_NATIVE_EXTRAS + 8 * 16 + s_loc] = split == 0 ? sl.n * DLAGP_LOG_2PI : 0.0;
     }
 #ifdef DLAGP_TRACE_BUILD
     if (threadIdx.x == 0 && blockIdx.x < 8192) {
