@@ -867,18 +867,27 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         // slower than MODE 0); from here they drain during the next pass's Voigt loop.  a_lds[] is intact until the
         // next convolution.
         if constexpr (MODE == 1 && DLAGP_M1_STORE_LATE) {
+            typedef __attribute__((address_space(1))) v2d *gst2;
             const int npx = pass_steps * DLAGP_STEP_PIXELS;
-            __attribute__((address_space(1))) double *dst =
-                (__attribute__((address_space(1))) double *)src.cache +
-                ((long)b * S + sample0) * src.cache_stride + (long)step0 * DLAGP_STEP_PIXELS + lane;
+            // 16 bytes per lane: lane = (h, slot pair j) stores slots 2 j, 2 j + 1 of the samples 2 i + h -- stores are
+            // issue-bound (profiles/r03_experiments.txt): 8 instructions per pass instead of 16.  (The same for the
+            // cached levels' row reads and write-backs spilled registers and ran 7 % slower: they keep 8 bytes per lane.)
+            const int h = lane >> 5, j2 = 2 * (lane & 31);
+            double *dst = src.cache + ((long)b * S + sample0) * src.cache_stride + (long)step0 * DLAGP_STEP_PIXELS + j2;
             const long valid = S - sample0 < 16 ? S - sample0 : 16;
             // streaming stores: 24 KB per sample written once and read a level later -- kept out of the L2 that
             // serves the sightline's operand
-            if (lane < npx)
-                for (int ss = 0; ss < valid; ++ss) {
-                    if (DLAGP_CACHE_STORE_NT) __builtin_nontemporal_store(a_lds[ss * A_STRIDE + lane], dst + ss * src.cache_stride);
-                    else dst[ss * src.cache_stride] = a_lds[ss * A_STRIDE + lane];
+            if (j2 < npx) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int ss = 2 * i + h;
+                    if (ss < valid) {
+                        const v2d row = *reinterpret_cast<const v2d *>(&a_lds[ss * A_STRIDE + j2]);
+                        if (DLAGP_CACHE_STORE_NT) __builtin_nontemporal_store(row, (gst2)(dst + ss * src.cache_stride));
+                        else *(gst2)(dst + ss * src.cache_stride) = row;
+                    }
                 }
+            }
         }
         __builtin_amdgcn_s_setprio(DLAGP_PRIO_CONV);
         // the next pass overwrites raw[] / a_lds[]: order the LDS reads above before those writes
