@@ -179,8 +179,11 @@ int dlagp_eval_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, cons
 
 /*
  * Batch of sightlines evaluated by one launch sequence.  All contexts must live on the same
- * device.  Sample arrays are laid out [nb][S][kd], outputs [nb][S].  Destroy a batch before its member contexts;
- * a context destroyed first drains the batch's launches, and the batch then refuses further calls (DLAGP_EINVAL).
+ * device and have the same rank.  Sample arrays are laid out [nb][S][kd], outputs [nb][S].  Members may differ in line
+ * count, broadening and Lyman-limit flag: such a batch runs as one launch group per flavour on the caller's stream, results
+ * at the members' positions as if it were homogeneous (dlagp_get_option "last_launch_groups").  Destroy a batch before its
+ * member contexts; a context destroyed first drains the batch's launches, and the batch then refuses further calls
+ * (DLAGP_EINVAL).
  */
 int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb);
 void dlagp_batch_destroy(dlagp_batch *batch);
@@ -260,8 +263,8 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  * Tuning / measurement hooks.
  *   dlagp_set_option: "pixel_splits" (0 = automatic work decomposition, h > 0 = every block of 16 samples
  *                     is cut into h equal pixel ranges), "path" (0 = automatic, 1 = generic
- *                     kernel, 2 = MFMA kernel), "timing" (1 = bracket the accumulate kernel
- *                     of every launch with HIP events on its stream), "debug" (bit 1: launch the
+ *                     kernel, 2 = MFMA kernel), "timing" (1 = attach a pair of HIP events to the
+ *                     dispatch of the accumulate kernel of every launch), "debug" (bit 1: launch the
  *                     stamped instantiation of the MFMA kernel, see dlagp_debug_read),
  *                     "core_patch" (1 = the MFMA kernel evaluates the line cores outside its sample
  *                     loop when it can: 3 lines, 1 absorber per sample, log-uniform wavelength grid;
@@ -275,7 +278,11 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     "profile_cache_max_mb" (upper bound of that allocation, default 196608; never more than half of the free HBM)
  *                     "plan_item_cost" (fixed cost of a work item in the planner's model, tenths of a chunk, default
  *                     20), "plan_slots" (wave slots the planner fills, default 2048 = 256 CUs x 4 SIMDs x 2 waves),
- *                     "plan_rest_first" (dispatch remainder pieces first; tuning experiments only)
+ *                     "plan_rest_first" (dispatch remainder pieces first; tuning experiments only),
+ *                     "finalize_row16_blocks" (launches of up to this many blocks of 16 samples factor with 16 lanes
+ *                     per sample, larger ones with one lane per sample: identical results; default 4096, 0 = never),
+ *                     "spare_workspaces" (sweep workspaces of destroyed batches kept per device for the next
+ *                     batches, default 3)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.
  */
@@ -284,7 +291,9 @@ int dlagp_set_option(const char *name, int64_t value);
  * "last_launch_path" (1 = generic kernel, 2 = MFMA kernel), "last_launch_items" (waves of the last MFMA
  * launch), "last_launch_parts" (most pieces a block of 16 samples was cut into), "last_sweep_cached"
  * (1 = the last dlagp_batch_sweep* used the profile cache), "last_launch_patch" (how the last MFMA launch handled
- * the line cores: 0 tested inside the sample loop, 1 repaired once per wave, 2 repaired pass by pass). */
+ * the line cores: 0 tested inside the sample loop, 1 repaired once per wave, 2 repaired pass by pass),
+ * "last_launch_groups" (homogeneous launch groups the last call ran as: > 1 for a batch that mixes line counts,
+ * broadening or Lyman-limit flags). */
 int dlagp_get_option(const char *name, int64_t *value);
 /* The work decomposition the MFMA path would choose for `groups` blocks of 16 samples of sightlines with `chunks`
  * chunks of 8 pixel slots each (pure host arithmetic, no device needed): every block is cut into `full` pieces of
@@ -293,7 +302,7 @@ int dlagp_plan_cut(int64_t groups, double chunks, int64_t forced_splits, int *fu
 int dlagp_timing_read(double *total_ms, int64_t *launches, int reset);
 /* Diagnostic build aid: with option "debug" bit 1 set the MFMA kernel sums shader-clock stamps per
  * phase over all waves (current device): [0] Voigt loop, [1] convolution, [2] weights + MFMA loop,
- * [3] epilogue, [4] whole wave, [5] waves.  Not for production launches. */
+ * [3] epilogue, [4] pass loop + epilogue, [5] waves, [6] prologue.  Not for production launches. */
 int dlagp_debug_read(uint64_t *out, int n, int reset);
 /* Diagnostic: the Voigt profile V(v; sigma, gamma_line) of reference voigt.py:241-248 (replaces scipy.special.wofz
  * there) at n velocities [cm/s] (host pointers), evaluated exactly as the kernels evaluate it: form 0 = generic
