@@ -2,7 +2,8 @@
 """
 Soak run on the GPU box: random batches (1-9 sightlines of 9..3300 pixels, random and run-shaped masks, 1-4 absorbers per
 sample, 1/3/5/31 lines, with and without broadening / the Lyman-limit term, S from 1 to 10 000, forced and automatic work
-decompositions), MFMA kernel (path 2) against the generic kernel (path 1) on the same inputs.
+decompositions; since round 3 also batches whose members differ in flavour), MFMA kernel (path 2) against the generic
+kernel (path 1) on the same inputs.
 usage: python3 tools/soak_paths.py <seed> <trials>      (round 2: seeds 1-3 x 300 trials, 3.0 M values, worst 4.4e-11)
 """
 import sys, numpy as np
@@ -31,7 +32,15 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
         else:
             s = make_sightline(int(rng.integers(0, 1000)), n_unmasked=n_u, n_masked=int(rng.integers(0, max(1, n_u // 10))))
         sights.append(s)
-    devs = [sl.DeviceSightline.from_state(s, num_lines=lines, broadening=broad, lls_break=lls) for s in sights]
+    mixed = nb > 1 and rng.random() < 0.4  # every member its own flavour: one MFMA launch group per flavour
+    devs = []
+    for s in sights:
+        if mixed:
+            m_lls = bool(rng.random() < 0.2)
+            flav = dict(num_lines=3 if m_lls else int(rng.choice([3, 3, 1, 5, 31])), broadening=bool(rng.random() < 0.7), lls_break=m_lls)
+        else:
+            flav = dict(num_lines=lines, broadening=broad, lls_break=lls)
+        devs.append(sl.DeviceSightline.from_state(s, **flav))
     zz = np.stack([np.stack([np.roll(make_qmc_samples(s, S)[0], 3 * j) for j in range(kd)], axis=1) for s in sights])
     nn = np.stack([np.stack([np.roll(make_qmc_samples(s, S)[2], 5 * j) for j in range(kd)], axis=1) for s in sights])
     splits = int(rng.choice([0, 0, 0, 1, 2, 5]))
