@@ -90,6 +90,7 @@ class DeviceEngine:
         from .sightline import DeviceModel
 
         self.params = params
+        self.defer_sync = True  # contexts of a batch are waited for once, by the batch's creation (`sightline`)
         self.model = DeviceModel(*learned[:7], prev_tau_0=learned.prev_tau_0, prev_beta=learned.prev_beta,
                                  num_forest_lines=params.num_forest_lines, device=device)
 
@@ -103,7 +104,7 @@ class DeviceEngine:
         # wait would queue behind the waves of the sweep that is running meanwhile)
         return DeviceSightline.from_model(
             self.model, state["x"], state["y"], state["v"], state["this_wavelengths"], z_qso, grid, keep,
-            num_lines=self.params.num_lines, broadening=broadening, defer_sync=True)
+            num_lines=self.params.num_lines, broadening=broadening, defer_sync=self.defer_sync)
 
     def batch(self, sightlines):
         from .sightline import DeviceBatch
