@@ -76,6 +76,7 @@ static Option g_opt_profile_cache_max_mb = 196608;
 static Option g_opt_plan_item_cost = 20;   // fixed cost of a work item in the planner's model, tenths of a chunk
 static Option g_opt_plan_rest_first = 0;   // dispatch the remainder pieces before the full ones (tuning)
 static Option g_opt_plan_slots = 2048;     // wave slots the planner fills: 256 CUs x 4 SIMDs x 2 waves (tuning)
+static Option g_opt_plan_xcd_affine = 1;   // batches: deal the work items so that an XCD sweeps one sightline at a time
 // launches of up to this many blocks of 16 samples finalise with 16 lanes per sample (kernels_common.h); 0: never
 static Option g_opt_finalize_row16_blocks = DLAGP_FIN_ROW16_MAX_BLOCKS;
 // read-only diagnostics of the most recent launch / sweep (dlagp_get_option): which kernel served it
@@ -314,7 +315,7 @@ struct LaunchGroup {
     Workspace ws;
     int max_slots = 0;  // largest n_slots of a member (row stride of the profile cache)
     // key: (S, and the planner options in force: forced split count, item cost, dispatch order, slot count)
-    typedef std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t> PlanKey;
+    typedef std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t> PlanKey;
     std::map<PlanKey, std::unique_ptr<LaunchPlan>> plans;
     // A batch whose members differ in line count, broadening or Lyman-limit flag cannot share one instantiation of
     // the MFMA kernel.  Instead of sending all of them to the generic kernel (21x slower) it runs as several
@@ -535,7 +536,8 @@ static void choose_cut(long groups, double C, int64_t forced, int *full_out, dou
 }
 
 static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
-    const LaunchGroup::PlanKey key(S, g_opt_pixel_splits, g_opt_plan_item_cost, g_opt_plan_rest_first, g_opt_plan_slots);
+    const LaunchGroup::PlanKey key(S, g_opt_pixel_splits, g_opt_plan_item_cost, g_opt_plan_rest_first, g_opt_plan_slots,
+                                   g_opt_plan_xcd_affine);
     auto it = g.plans.find(key);
     if (it != g.plans.end()) {
         *out = it->second.get();
@@ -593,6 +595,21 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
     // dispatch order: the full pieces in (sightline, group, piece) order, then the remainders
     const bool rest_first = g_opt_plan_rest_first != 0;
     if (remainder) std::stable_partition(pieces.begin(), pieces.end(), [=](const Piece &x) { return x.rest == rest_first; });
+    // XCD affinity (batches, one piece per block): workgroups are dealt round-robin over the 8 XCDs (observed, for speed
+    // only), each with its own 4 MB L2, and a sightline's MFMA operand is 6 MB.  In (sightline, group) order every XCD
+    // has waves of the ~3 sightlines that are in flight at a time; dealt so that workgroup i works on a sightline
+    // b = i (mod 8), every XCD sweeps ONE sightline's operand with all of its waves.  Option "plan_xcd_affine".
+    if (g_opt_plan_xcd_affine != 0 && !remainder && full == 1 && nb >= 8) {
+        std::vector<Piece> dealt;
+        dealt.reserve(pieces.size());
+        // pieces are in (b, group) order, ngroups each: rounds of 8 sightlines, inside a round group-major
+        for (int b0 = 0; b0 < nb; b0 += 8) {
+            const int width = std::min(8, nb - b0);
+            for (long grp = 0; grp < ngroups; ++grp)
+                for (int x = 0; x < width; ++x) dealt.push_back(pieces[(size_t)(b0 + x) * ngroups + grp]);
+        }
+        pieces.swap(dealt);
+    }
     std::vector<WorkItem> items;
     items.reserve(pieces.size());
     for (const Piece &pc : pieces) items.push_back(WorkItem{pc.b, pc.group, pc.part, pc.pass_begin, pc.pass_end, 0, 0, 0});
@@ -1853,6 +1870,7 @@ int dlagp_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "plan_item_cost")) g_opt_plan_item_cost = value;
     else if (!strcmp(name, "plan_rest_first")) g_opt_plan_rest_first = value;
     else if (!strcmp(name, "plan_slots")) g_opt_plan_slots = value > 0 ? value : 2048;
+    else if (!strcmp(name, "plan_xcd_affine")) g_opt_plan_xcd_affine = value;
     else if (!strcmp(name, "finalize_row16_blocks")) g_opt_finalize_row16_blocks = value;
     else if (!strcmp(name, "spare_workspaces")) g_opt_spare_workspaces = value;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
@@ -1878,6 +1896,7 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "plan_item_cost")) *value = g_opt_plan_item_cost;
     else if (!strcmp(name, "plan_rest_first")) *value = g_opt_plan_rest_first;
     else if (!strcmp(name, "plan_slots")) *value = g_opt_plan_slots;
+    else if (!strcmp(name, "plan_xcd_affine")) *value = g_opt_plan_xcd_affine;
     else if (!strcmp(name, "finalize_row16_blocks")) *value = g_opt_finalize_row16_blocks;
     else if (!strcmp(name, "spare_workspaces")) *value = g_opt_spare_workspaces;
     else if (!strcmp(name, "last_launch_path")) *value = g_last_launch_path;
