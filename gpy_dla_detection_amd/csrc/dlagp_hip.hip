@@ -278,10 +278,10 @@ struct Workspace {
 
 static std::mutex g_spare_mutex;
 // per device: workspaces of destroyed batches, adopted by the next batches created.  A pipelined catalogue run has
-// three batches alive at a time (one being prepared, one in its sweeps, one being finished): with a single spare
-// every other batch freed and reallocated gigabytes (hipFree synchronises the device: 7 ms per batch).
+// up to four batches alive at a time (one being prepared, two in their sweeps, one being finished): with a single
+// spare every other batch freed and reallocated gigabytes (hipFree synchronises the device: 7 ms per batch).
 static std::map<int, std::vector<Workspace>> g_spare_workspace;
-static Option g_opt_spare_workspaces = 3;
+static Option g_opt_spare_workspaces = 4;
 
 // Decomposition of one MFMA launch (a launch group at one sample count) into work items, see build_plan
 struct LaunchPlan {
@@ -836,6 +836,20 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
     return DLAGP_OK;
 }
 
+// The host-pointer entry points (dlagp_eval, dlagp_null, dlagp_batch_*, dlagp_absorption) run on a stream of the CALLING
+// THREAD, not on the null stream: two host threads that sweep different batches then overlap -- one's transfers and
+// host-side work beside the other's kernels -- instead of queueing behind each other (the catalogue driver's two sweep
+// threads).  Every such call still returns with its own work complete.
+static hipStream_t work_stream(int device) {
+    static thread_local std::map<int, hipStream_t> streams;
+    auto it = streams.find(device);
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;  // fall back to the null stream
+    streams[device] = s;
+    return s;
+}
+
 // One batch of host <-> device transfers through the workspace's pinned staging buffer.
 //   add(): registers a transfer and returns nothing; run_uploads() copies host -> stage -> device (async on
 //   the null stream, the stage is not reused before the final synchronisation); run_downloads() enqueues
@@ -848,10 +862,11 @@ struct Transfers {
         size_t offset;
     };
     PinnedBuffer &stage;
+    hipStream_t stream;
     std::vector<Item> up, down;
     size_t total = 0;
     static constexpr size_t kDirect = 64 * 1024;
-    explicit Transfers(PinnedBuffer &s) : stage(s) {}
+    Transfers(PinnedBuffer &s, hipStream_t st) : stage(s), stream(st) {}
     void upload(void *device, const void *host, size_t bytes) {
         if (bytes) up.push_back({device, const_cast<void *>(host), bytes, 0});
     }
@@ -872,7 +887,7 @@ struct Transfers {
         for (const Item &it : up) {
             if (it.bytes > kDirect) {
                 std::memcpy(static_cast<char *>(stage.ptr) + it.offset, it.host, it.bytes);
-                HIP_TRY(hipMemcpyAsync(it.device, static_cast<char *>(stage.ptr) + it.offset, it.bytes, hipMemcpyHostToDevice, nullptr));
+                HIP_TRY(hipMemcpyAsync(it.device, static_cast<char *>(stage.ptr) + it.offset, it.bytes, hipMemcpyHostToDevice, stream));
             } else {
                 HIP_TRY(hipMemcpy(it.device, it.host, it.bytes, hipMemcpyHostToDevice));
             }
@@ -882,8 +897,8 @@ struct Transfers {
     int run_downloads() {
         for (const Item &it : down)
             if (it.bytes > kDirect)
-                HIP_TRY(hipMemcpyAsync(static_cast<char *>(stage.ptr) + it.offset, it.device, it.bytes, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipStreamSynchronize(nullptr));
+                HIP_TRY(hipMemcpyAsync(static_cast<char *>(stage.ptr) + it.offset, it.device, it.bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
         for (const Item &it : down) {
             if (it.bytes > kDirect) std::memcpy(it.host, static_cast<char *>(stage.ptr) + it.offset, it.bytes);
             else HIP_TRY(hipMemcpy(it.host, it.device, it.bytes, hipMemcpyDeviceToHost));
@@ -901,7 +916,8 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
     if ((rc = grow(g, ws.z, nsamp * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.nhi, nsamp * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.out, (size_t)rows * sizeof(double)))) return rc;
-    Transfers tr(ws.stage);
+    const hipStream_t stream = work_stream(g.device);
+    Transfers tr(ws.stage, stream);
     if (kd > 0) {
         tr.upload(ws.z.ptr, z, nsamp * sizeof(double));
         tr.upload(ws.nhi.ptr, nhi, nsamp * sizeof(double));
@@ -909,7 +925,7 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
     tr.download(out, ws.out.ptr, (size_t)rows * sizeof(double));
     if ((rc = tr.reserve()) || (rc = tr.run_uploads())) return rc;
     rc = launch_sweep(g, S, kd, SampleSource{ws.z.as<double>(), ws.nhi.as<double>(), nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0},
-                      ws.out.as<double>(), nullptr);
+                      ws.out.as<double>(), stream);
     if (rc) return rc;
     if ((rc = tr.run_downloads())) return rc;
     g.launched = false;  // run_downloads drained the stream: nothing of this group is in flight (drain() has nothing to wait for)
@@ -1617,7 +1633,7 @@ void dlagp_batch_destroy(dlagp_batch *batch) {
     }
     // A catalogue run builds one batch after the other: the sweep workspace (partial sums, profile cache --
     // gigabytes) is handed to the next batch of this device instead of being freed and allocated again.
-    // Up to `spare_workspaces` (3) per device are kept; option "pool_mb" = 0 turns this off as well.
+    // Up to `spare_workspaces` (4) per device are kept; option "pool_mb" = 0 turns this off as well.
     Workspace keep{};
     bool parked = false;
     if (g_opt_pool_mb > 0 && g_opt_spare_workspaces > 0) {
@@ -1706,7 +1722,8 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
     if ((rc = grow(g, ws.evidences, nb * max_dlas * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.sample_ll, rows * max_dlas * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.base, std::max<size_t>(n_base, 1) * sizeof(int32_t)))) return rc;
-    Transfers tr(ws.stage);
+    const hipStream_t stream = work_stream(g.device);
+    Transfers tr(ws.stage, stream);
     tr.upload(ws.z.ptr, sample_z, rows * sizeof(double));
     tr.upload(ws.nhi.ptr, sample_nhi, n_nhi * sizeof(double));
     tr.upload(ws.uniforms.ptr, uniforms, n_base * sizeof(double));
@@ -1716,7 +1733,7 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
     if ((rc = tr.reserve()) || (rc = tr.run_uploads())) return rc;
     rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), nhi_stride, min_z_separation,
                       ws.uniforms.as<double>(), ws.evidences.as<double>(), ws.sample_ll.as<double>(),
-                      ws.base.as<int>(), nullptr);
+                      ws.base.as<int>(), stream);
     if (rc) return rc;
     if ((rc = tr.run_downloads())) return rc;
     g.launched = false;  // as in sweep_from_host

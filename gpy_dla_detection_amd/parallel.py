@@ -21,11 +21,17 @@ The reference processes one spectrum at a time in a single Python process
 Message sizes: (2 + max_dlas) doubles per sightline -- 48 B for the default model list
 [null, sub-DLA, DLA(1..4)] -- so the gather is latency-bound (1024 sightlines = 48 KB).
 """
+import threading
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
 from .dla_gp import finish_level, level_parameters
+
+
+# `sweep_batch` re-seeds and restores the legacy global NumPy RNG around every sightline's turn (the reference resamples
+# with `np.random.choice` on that generator): one sweep at a time per process
+_GLOBAL_RNG_LOCK = threading.RLock()
 
 
 def shard_range(num_items: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -211,6 +217,11 @@ def sweep_batch(
         (the reference driver's behaviour); None leaves the global RNG untouched between sightlines
     :return: evidences (nb, max_dlas), sample_log_likelihoods (nb, S, max_dlas), base_sample_inds (nb, max_dlas - 1, S)
     """
+    with _GLOBAL_RNG_LOCK:
+        return _sweep_batch_locked(batch_eval, sample_z, sample_nhi, max_dlas, min_z_separation, seed)
+
+
+def _sweep_batch_locked(batch_eval, sample_z, sample_nhi, max_dlas, min_z_separation, seed):
     nb, S = sample_z.shape
     evidences = np.full((nb, max_dlas), np.nan)
     sample_ll = np.full((nb, S, max_dlas), np.nan)
@@ -258,10 +269,10 @@ def resampling_uniforms(nb: int, max_dlas: int, S: int, seed: Optional[int] = 0)
     levels = max(max_dlas - 1, 0)
     if seed is None:
         return np.random.random_sample((nb, levels, S))
-    outer_state = np.random.get_state()
-    np.random.seed(seed)
-    one = np.random.random_sample((levels, S))
-    np.random.set_state(outer_state)
+    # a generator of its own, seeded like the global one would be: the same MT19937 stream as `np.random.seed(seed)`
+    # followed by `np.random.random_sample`, without touching the global state (two threads of the catalogue driver
+    # draw their batches' uniforms at the same time)
+    one = np.random.RandomState(seed).random_sample((levels, S))
     return np.broadcast_to(one, (nb, levels, S)).copy()
 
 

@@ -209,37 +209,54 @@ def process_qso(
             local["p_no_dlas"][i] = 1 - local["p_dlas"][i]
         engine.release(batch, sightlines)
 
-    # Two worker threads: one prepares batch i + 1 (NumPy index logic, context creation on its own HIP stream) and
-    # finishes batch i - 1 (priors, posteriors, MAP, freeing contexts) while this thread is inside the sweeps of
-    # batch i (ctypes releases the GIL): the device never waits for the host.  `prefetch=False` runs everything in
+    def sweeps(sightlines, batch, z_dla, z_lls):
+        """the three launches of one batch: null evidences, sub-DLA sweep, DLA sweep"""
+        nulls = engine.nulls(batch, sightlines)
+        # the sub-DLA model is swept before the DLA model (model list order, run_bayes_select.py:189);
+        # with max_dlas = 1 it draws nothing from the RNG, so the DLA sweep sees the freshly seeded stream
+        ev_sub, ll_sub, _ = engine.sweep(batch, z_lls, nhi_sub, 1, min_sep, seed)
+        ev_dla, ll_dla, base = engine.sweep(batch, z_dla, nhi_dla, max_dlas, min_sep, seed)
+        return nulls, ev_sub, ll_sub, ev_dla, ll_dla, base
+
+    # A pipeline of four worker threads over the batches: one prepares (NumPy index logic, context creation on its own
+    # HIP stream), TWO sweep (each call into the library runs on the calling thread's stream and releases the
+    # interpreter lock: while one thread is in its transfers or back in Python, the other's kernels keep the device
+    # busy), one finishes (priors, posteriors, MAP, freeing contexts).  At most `in_flight` batches exist at a time.
+    # `prefetch=False` -- and seed=None, whose draws come from the global RNG in catalogue order -- runs everything in
     # this thread, in order.
     bounds = [(start, min(start + batch_size, hi)) for start in range(lo, hi, batch_size)]
-    pool = ThreadPoolExecutor(max_workers=2) if prefetch and len(bounds) > 1 else None
-    pending = pool.submit(prepare, *bounds[0]) if pool else None
-    finishing = []
-    try:
-        for index, (start, stop) in enumerate(bounds):
-            if pool:
-                sightlines, batch, z_dla, z_lls = pending.result()
-                pending = pool.submit(prepare, *bounds[index + 1]) if index + 1 < len(bounds) else None
-            else:
-                sightlines, batch, z_dla, z_lls = prepare(start, stop)
-            nulls = engine.nulls(batch, sightlines)
-            # the sub-DLA model is swept before the DLA model (model list order, run_bayes_select.py:189);
-            # with max_dlas = 1 it draws nothing from the RNG, so the DLA sweep sees the freshly seeded stream
-            ev_sub, ll_sub, _ = engine.sweep(batch, z_lls, nhi_sub, 1, min_sep, seed)
-            ev_dla, ll_dla, base = engine.sweep(batch, z_dla, nhi_dla, max_dlas, min_sep, seed)
+    if prefetch and len(bounds) > 1 and seed is not None:
+        import threading
 
-            swept = (start, stop, sightlines, batch, z_dla, nulls, ev_sub, ll_sub, ev_dla, ll_dla, base)
-            if pool:
-                finishing.append(pool.submit(finish, *swept))
-            else:
-                finish(*swept)
-        for future in finishing:
-            future.result()
-    finally:
-        if pool:
-            pool.shutdown()
+        in_flight = threading.Semaphore(4)
+        prepare_pool, sweep_pool, finish_pool = (ThreadPoolExecutor(max_workers=w) for w in (1, 2, 1))
+
+        def stage_sweep(start, stop, prepared):
+            sightlines, batch, z_dla, z_lls = prepared.result()
+            return (start, stop, sightlines, batch, z_dla) + sweeps(sightlines, batch, z_dla, z_lls)
+
+        def stage_finish(swept):
+            try:
+                finish(*swept.result())
+            finally:
+                in_flight.release()
+
+        finishing = []
+        try:
+            for start, stop in bounds:
+                in_flight.acquire()
+                prepared = prepare_pool.submit(prepare, start, stop)
+                swept = sweep_pool.submit(stage_sweep, start, stop, prepared)
+                finishing.append(finish_pool.submit(stage_finish, swept))
+            for future in finishing:
+                future.result()
+        finally:
+            for pool in (prepare_pool, sweep_pool, finish_pool):
+                pool.shutdown()
+    else:
+        for start, stop in bounds:
+            sightlines, batch, z_dla, z_lls = prepare(start, stop)
+            finish(start, stop, sightlines, batch, z_dla, *sweeps(sightlines, batch, z_dla, z_lls))
     if own_engine:
         engine.close()
 

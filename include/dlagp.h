@@ -282,7 +282,7 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     "finalize_row16_blocks" (launches of up to this many blocks of 16 samples factor with 16 lanes
  *                     per sample, larger ones with one lane per sample: identical results; default 4096, 0 = never),
  *                     "spare_workspaces" (sweep workspaces of destroyed batches kept per device for the next
- *                     batches, default 3), "plan_xcd_affine" (1 = batches of >= 8 sightlines deal their work items so
+ *                     batches, default 4), "plan_xcd_affine" (1 = batches of >= 8 sightlines deal their work items so
  *                     that the workgroups of one XCD sweep one sightline's operand at a time; default 1)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.

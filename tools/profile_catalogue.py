@@ -55,6 +55,9 @@ def main():
         setattr(lib, cname, timed("C:" + cname, getattr(lib, cname)))
     sightline.DeviceBatch.sweep = timed("py:DeviceBatch.sweep", sightline.DeviceBatch.sweep)
     parallel.resampling_uniforms = timed("py:resampling_uniforms", parallel.resampling_uniforms)
+    from concurrent.futures import Future
+
+    Future.result = timed("main:future.result (waiting for a worker)", Future.result)
     rbs.prepare_data = timed("prepare_data", rbs.prepare_data)
     rbs.map_traceback = timed("map_traceback", rbs.map_traceback)
     rbs.occupation_log_priors = timed("log_priors", rbs.occupation_log_priors)
