@@ -356,6 +356,22 @@ static int grow(LaunchGroup &g, DeviceBuffer &buf, size_t want) {
     return buf.reserve(want);
 }
 
+// A launch group's scratch is shared by its launches, which are ordered only within one stream.  A call that arrives on
+// another stream than the group's previous launches (e.g. a host-pointer call, which runs on the calling thread's own
+// stream, after `*_device` calls on the caller's stream) first drains the previous stream.
+static int enter_stream(LaunchGroup &g, hipStream_t stream) {
+    if (g.launched && g.last_stream != stream) {
+        HIP_TRY(hipStreamSynchronize(g.last_stream));
+        g.launched = false;
+    }
+    for (auto &p : g.parts)
+        if (p->launched && p->last_stream != stream) {
+            HIP_TRY(hipStreamSynchronize(p->last_stream));
+            p->launched = false;
+        }
+    return DLAGP_OK;
+}
+
 // learned GP model resident on one device (state of NullGP.__init__, reference null_gp.py:35-71)
 struct dlagp_model {
     int device = 0;
@@ -711,13 +727,14 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
     const int nb = (int)g.ctxs.size();
     const long rows = (long)nb * S;
     const SightlineDev *table = g.d_table.as<SightlineDev>();
+    int rc;
+    if ((rc = enter_stream(g, stream))) return rc;
 
     bool use_mfma = mfma_path_serves(g, kd, src.cache_mode == 2);
     if (g_opt_path == 2 && kd >= 1 && !use_mfma)
         return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (rank > 20, mixed line counts / broadening / Lyman-limit flags, or kd x lines too large)");
     if (!use_mfma && src.cache_mode)
         return fail(DLAGP_EINVAL, "internal: the profile cache is only served by the MFMA path");
-    int rc;
     LaunchPlan *plan = nullptr;
     if (use_mfma && (rc = build_plan(g, S, &plan))) return rc;
     const int nparts = plan ? plan->max_parts : 1;
@@ -823,9 +840,10 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
 static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &src, double *d_out,
                         hipStream_t stream) {
     g_last_launch_groups = g.parts.empty() ? 1 : (int64_t)g.parts.size();
-    if (g.parts.empty() || kd == 0 || S <= 0) return launch_one(g, S, kd, src, d_out, stream);  // kd == 0: null model, generic kernel anyway
-    int rc = grow(g, g.ws.status, sizeof(int));
+    int rc = enter_stream(g, stream);
     if (rc) return rc;
+    if (g.parts.empty() || kd == 0 || S <= 0) return launch_one(g, S, kd, src, d_out, stream);  // kd == 0: null model, generic kernel anyway
+    if ((rc = grow(g, g.ws.status, sizeof(int)))) return rc;
     g.last_stream = stream;
     g.launched = true;
     bool first = true;
@@ -946,6 +964,7 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     const int nb = (int)g.ctxs.size();
     const size_t rows = (size_t)nb * S;
     int rc;
+    if ((rc = enter_stream(g, stream))) return rc;
     if ((rc = grow(g, ws.level_ll, rows * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.cdf, rows * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.alive, (size_t)(nb + 1) * sizeof(int)))) return rc;  // [nb] = sticky non-PD flag

@@ -171,8 +171,10 @@ int dlagp_absorption(dlagp_ctx *ctx, int kd, const double *z, const double *nhi,
  * Stream rules of every *_device entry point: a context / batch may have launches in flight on ONE
  * stream at a time (its scratch buffers are shared by its launches; successive launches on the same
  * stream are ordered, a call that needs larger scratch drains that stream first); dlagp_destroy /
- * dlagp_batch_destroy drain the stream of the last launch before they recycle device memory.  To move
- * a context to another stream, synchronise the old one first.
+ * dlagp_batch_destroy drain the stream of the last launch before they recycle device memory.  A call on another
+ * stream than the context's / batch's previous launches drains the previous stream first -- that includes the
+ * host-pointer entry points (dlagp_eval, dlagp_null, dlagp_batch_eval / _null / _sweep), which run on a stream of the
+ * calling thread and return with their work complete.
  */
 int dlagp_eval_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, const double *d_nhi,
                       double *d_out, void *stream);

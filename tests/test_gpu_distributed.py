@@ -53,7 +53,7 @@ def test_bench_collectives_run_over_rccl_with_one_rank():
         assert line["evidence"] == plain["evidence"]
     assert weak["scaling"] == "weak" and strong["scaling"] == "strong"
     batch = ["--steps", "1", "--warmup", "1", "--ramp-ms", "5", "--samples", "1000", "--sightlines", "3"]
-    for config in ("3", "5"):
+    for config in ("3", "4", "5"):
         alone = run_bench(0, "--gpus", "1", "--config", config, *batch)
         ranked = run_bench(1, "--gpus", "1", "--config", config, *batch)
         assert ranked["evidence"] == alone["evidence"] and ranked["value"] > 0

@@ -1680,6 +1680,43 @@ def test_long_sightline_and_concurrent_context_creation():
         assert abs(null - R.null_log_model_evidence(st)) <= RTOL_LL * abs(null)
 
 
+def test_host_pointer_calls_after_device_launches_on_another_stream():
+    """
+    The host-pointer entry points run on a stream of the calling thread.  Called on a batch whose `*_device` launches are
+    still in flight on the caller's stream (bench.py config 4: two asynchronous sweeps, then `batch.nulls()`), they first
+    drain that stream -- the launches share the batch's scratch -- and the next device launch drains theirs.
+    """
+    import torch
+
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    dev = torch.device("cuda", 0)
+    sights = [make_sightline(20 + i, n_unmasked=900 + 50 * i, n_masked=10) for i in range(3)]
+    batch = DeviceBatch([device_sightline(s) for s in sights])
+    S = 4000
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    want = batch.eval(zs, np.tile(nhi, (3, 1)))
+    want_nulls = batch.nulls()
+    stream = torch.cuda.Stream(device=dev)
+    d_z = torch.from_numpy(zs).to(dev)
+    d_n = torch.from_numpy(np.tile(nhi, (3, 1))).to(dev)
+    outs = [torch.full((3, S), float("nan"), dtype=torch.float64, device=dev) for _ in range(3)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        batch.eval_device(S, 1, d_z.data_ptr(), d_n.data_ptr(), outs[0].data_ptr(), stream.cuda_stream)
+        batch.eval_device(S, 1, d_z.data_ptr(), d_n.data_ptr(), outs[1].data_ptr(), stream.cuda_stream)
+        nulls = batch.nulls()                      # host-pointer call, another stream: drains `stream` first
+        small = batch.eval(zs[:, :64], np.tile(nhi[:64], (3, 1)))
+        batch.eval_device(S, 1, d_z.data_ptr(), d_n.data_ptr(), outs[2].data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    np.testing.assert_array_equal(nulls, want_nulls)
+    np.testing.assert_allclose(small, want[:, :64], rtol=1e-13)
+    for out in outs:
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+    batch.close()
+
+
 def test_device_entry_points_are_graph_capturable():
     """
     dlagp_eval_device + dlagp_level_evidence_device only enqueue work on the caller's stream once the workspace
