@@ -870,7 +870,7 @@ static hipStream_t work_stream(int device) {
 
 // One batch of host <-> device transfers through the workspace's pinned staging buffer.
 //   add(): registers a transfer and returns nothing; run_uploads() copies host -> stage -> device (async on
-//   the null stream, the stage is not reused before the final synchronisation); run_downloads() enqueues
+//   the call's stream, the stage is not reused before the final synchronisation); run_downloads() enqueues
 //   device -> stage, synchronises the device once and copies stage -> host.  Small transfers use hipMemcpy.
 struct Transfers {
     struct Item {
