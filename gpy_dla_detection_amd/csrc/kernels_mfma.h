@@ -471,9 +471,6 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     v2d frag[NPAIR];
     v2d rec_ym, rec_ov;
 
-#ifndef DLAGP_M1_STORE_LATE
-#define DLAGP_M1_STORE_LATE 1
-#endif
 #ifndef DLAGP_CACHE_STORE_NT
 #define DLAGP_CACHE_STORE_NT 1
 #endif
@@ -740,21 +737,6 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
                 lds_wave_sync();
                 if (stamps) t_conv += stamp_now() - t_mark;
             }
-            // level 1 of a multi-level sweep: keep the convolved profiles for the deeper levels
-            if constexpr (MODE == 1 && !DLAGP_M1_STORE_LATE) {
-                const int npx = pass_steps * DLAGP_STEP_PIXELS;
-                __attribute__((address_space(1))) double *dst =
-                    (__attribute__((address_space(1))) double *)src.cache +
-                    ((long)b * S + sample0) * src.cache_stride + (long)step0 * DLAGP_STEP_PIXELS + lane;
-                const long valid = S - sample0 < 16 ? S - sample0 : 16;
-                // streaming stores: 24 KB per sample written once and read a level later -- kept out of the L2 that
-                // serves the sightline's operand
-                if (lane < npx)
-                    for (int ss = 0; ss < valid; ++ss) {
-                        if (DLAGP_CACHE_STORE_NT) __builtin_nontemporal_store(a_lds[ss * A_STRIDE + lane], dst + ss * src.cache_stride);
-                        else dst[ss * src.cache_stride] = a_lds[ss * A_STRIDE + lane];
-                    }
-            }
         }
         if (stamps) t_mark = stamp_now();
 
@@ -866,7 +848,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         // in front of the step loop made its first steps wait for 16 write acknowledgements from HBM (MODE 1 ran 19 %
         // slower than MODE 0); from here they drain during the next pass's Voigt loop.  a_lds[] is intact until the
         // next convolution.
-        if constexpr (MODE == 1 && DLAGP_M1_STORE_LATE) {
+        if constexpr (MODE == 1) {
             typedef __attribute__((address_space(1))) v2d *gst2;
             const int npx = pass_steps * DLAGP_STEP_PIXELS;
             // 16 bytes per lane: lane = (h, slot pair j) stores slots 2 j, 2 j + 1 of the samples 2 i + h -- stores are
