@@ -9,7 +9,7 @@ for L in "$@"; do
   python3 - $tag <<'PY'
 import csv, glob, sys
 f = glob.glob('gpurun_out/abk_%s/*/*_kernel_stats.csv' % sys.argv[1])[0]
-rows = [r for r in csv.DictReader(open(f)) if 'accumulate' in r['Name'] or 'finalize' in r['Name']]
+rows = [r for r in csv.DictReader(open(f)) if any(k in r['Name'] for k in ('accumulate', 'finalize', 'evidence', 'level_finish'))]
 print(sys.argv[1].ljust(8), '  '.join('%s x%s %.1f us' % (r['Name'].split('<')[-1][:22] if '<' in r['Name'] else r['Name'][7:22], r['Calls'], float(r['AverageNs']) / 1e3) for r in rows))
 PY
   rm -rf gpurun_out/abk_$tag
