@@ -286,8 +286,11 @@ def process_qso(
 
     results = {}
     for name in PER_QUASAR:
+        if world_size == 1:
+            results[name] = local[name]  # no copy: the per-sample arrays are 80 KB x (2 max_dlas) per quasar
+            continue
         rows = local[name].reshape(hi - lo, int(np.prod(local[name].shape[1:])))
-        full = parallel.gather_rows(rows, num, group=group) if world_size > 1 else rows.astype(np.float64)
+        full = parallel.gather_rows(rows, num, group=group)
         results[name] = full.reshape((num,) + local[name].shape[1:]).astype(local[name].dtype)
     # model settings and bookkeeping the reference stores next to the results (:250-268, :293-295)
     for name in ("prior_z_qso_increase", "k", "normalization_min_lambda", "normalization_max_lambda",
