@@ -256,6 +256,7 @@ struct Workspace {
     // and staging of its host-pointer variant
     DeviceBuffer level_ll, cdf, alive, uniforms, evidences, sample_ll, base;
     DeviceBuffer cache, running;  // profile cache / running products of the multi-level sweep, [nb][S][max n_pad]
+    DeviceBuffer sub_z, sub_nhi, sub_evidences, sub_ll;  // the one-absorber model of dlagp_batch_model_evidences
     PinnedBuffer stage;           // host staging of the host-pointer entry points
     void release() {
         stage.release();
@@ -273,6 +274,10 @@ struct Workspace {
         z.release();
         nhi.release();
         out.release();
+        sub_z.release();
+        sub_nhi.release();
+        sub_evidences.release();
+        sub_ll.release();
     }
 };
 
@@ -282,6 +287,7 @@ static std::mutex g_spare_mutex;
 // spare every other batch freed and reallocated gigabytes (hipFree synchronises the device: 7 ms per batch).
 static std::map<int, std::vector<Workspace>> g_spare_workspace;
 static Option g_opt_spare_workspaces = 4;
+static Option g_opt_shared_work_stream = 0;
 
 // Decomposition of one MFMA launch (a launch group at one sample count) into work items, see build_plan
 struct LaunchPlan {
@@ -858,6 +864,11 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
 // THREAD, not on the null stream: two host threads that sweep different batches then overlap -- one's transfers and
 // host-side work beside the other's kernels -- instead of queueing behind each other (the catalogue driver's two sweep
 // threads).  Every such call still returns with its own work complete.
+// Option "shared_work_stream" = 1 puts the KERNELS of all threads on one stream per device instead (transfers stay on
+// the thread's stream, ordered against the kernels by events, and a call waits for its own completion event only): the
+// calls of different threads then run strictly one after the other.  Measured on the catalogue driver it makes no
+// difference (the device serialises two full-size launches anyway; profiles/r03_experiments.txt item 15), so the
+// default stays 0.
 static hipStream_t work_stream(int device) {
     static thread_local std::map<int, hipStream_t> streams;
     auto it = streams.find(device);
@@ -866,6 +877,32 @@ static hipStream_t work_stream(int device) {
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;  // fall back to the null stream
     streams[device] = s;
     return s;
+}
+
+static hipStream_t compute_stream(int device) {
+    if (!g_opt_shared_work_stream) return work_stream(device);
+    static std::mutex mutex;
+    static std::map<int, hipStream_t> streams;
+    std::lock_guard<std::mutex> lock(mutex);
+    auto it = streams.find(device);
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    streams[device] = s;
+    return s;
+}
+
+// the calling thread's pair of events that order its transfer stream against the kernel stream within one call
+struct CallEvents {
+    hipEvent_t uploaded = nullptr, computed = nullptr;
+};
+static int call_events(int device, CallEvents **out) {
+    static thread_local std::map<int, CallEvents> events;
+    CallEvents &ev = events[device];
+    if (!ev.uploaded) HIP_TRY(hipEventCreateWithFlags(&ev.uploaded, hipEventDisableTiming));
+    if (!ev.computed) HIP_TRY(hipEventCreateWithFlags(&ev.computed, hipEventDisableTiming));
+    *out = &ev;
+    return DLAGP_OK;
 }
 
 // One batch of host <-> device transfers through the workspace's pinned staging buffer.
@@ -880,16 +917,17 @@ struct Transfers {
         size_t offset;
     };
     PinnedBuffer &stage;
-    hipStream_t stream;
+    int device;
+    hipStream_t compute, transfer;  // kernels of the call / copies of the call (may be the same stream)
     std::vector<Item> up, down;
     size_t total = 0;
     static constexpr size_t kDirect = 64 * 1024;
-    Transfers(PinnedBuffer &s, hipStream_t st) : stage(s), stream(st) {}
-    void upload(void *device, const void *host, size_t bytes) {
-        if (bytes) up.push_back({device, const_cast<void *>(host), bytes, 0});
+    Transfers(PinnedBuffer &s, int dev) : stage(s), device(dev), compute(compute_stream(dev)), transfer(work_stream(dev)) {}
+    void upload(void *device_ptr, const void *host, size_t bytes) {
+        if (bytes) up.push_back({device_ptr, const_cast<void *>(host), bytes, 0});
     }
-    void download(void *host, const void *device, size_t bytes) {
-        if (bytes && host) down.push_back({const_cast<void *>(device), host, bytes, 0});
+    void download(void *host, const void *device_ptr, size_t bytes) {
+        if (bytes && host) down.push_back({const_cast<void *>(device_ptr), host, bytes, 0});
     }
     int reserve() {
         total = 0;
@@ -901,22 +939,41 @@ struct Transfers {
                 }
         return total ? stage.reserve(total) : DLAGP_OK;
     }
+    // host -> stage -> device on the transfer stream; the kernel stream waits for them (an event, no host wait)
     int run_uploads() {
+        bool queued = false;
         for (const Item &it : up) {
             if (it.bytes > kDirect) {
                 std::memcpy(static_cast<char *>(stage.ptr) + it.offset, it.host, it.bytes);
-                HIP_TRY(hipMemcpyAsync(it.device, static_cast<char *>(stage.ptr) + it.offset, it.bytes, hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(it.device, static_cast<char *>(stage.ptr) + it.offset, it.bytes, hipMemcpyHostToDevice, transfer));
+                queued = true;
             } else {
                 HIP_TRY(hipMemcpy(it.device, it.host, it.bytes, hipMemcpyHostToDevice));
             }
         }
+        if (queued && transfer != compute) {
+            CallEvents *ev = nullptr;
+            int rc = call_events(device, &ev);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev->uploaded, transfer));
+            HIP_TRY(hipStreamWaitEvent(compute, ev->uploaded, 0));
+        }
         return DLAGP_OK;
     }
+    // the call's kernels are complete on return (and nothing else is waited for: the kernel stream may already hold
+    // another thread's launches behind them); device -> stage on the transfer stream, then stage -> host
     int run_downloads() {
+        if (transfer != compute) {
+            CallEvents *ev = nullptr;
+            int rc = call_events(device, &ev);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev->computed, compute));
+            HIP_TRY(hipStreamWaitEvent(transfer, ev->computed, 0));
+        }
         for (const Item &it : down)
             if (it.bytes > kDirect)
-                HIP_TRY(hipMemcpyAsync(static_cast<char *>(stage.ptr) + it.offset, it.device, it.bytes, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(hipMemcpyAsync(static_cast<char *>(stage.ptr) + it.offset, it.device, it.bytes, hipMemcpyDeviceToHost, transfer));
+        HIP_TRY(hipStreamSynchronize(transfer));
         for (const Item &it : down) {
             if (it.bytes > kDirect) std::memcpy(it.host, static_cast<char *>(stage.ptr) + it.offset, it.bytes);
             else HIP_TRY(hipMemcpy(it.host, it.device, it.bytes, hipMemcpyDeviceToHost));
@@ -934,8 +991,8 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
     if ((rc = grow(g, ws.z, nsamp * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.nhi, nsamp * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.out, (size_t)rows * sizeof(double)))) return rc;
-    const hipStream_t stream = work_stream(g.device);
-    Transfers tr(ws.stage, stream);
+    Transfers tr(ws.stage, g.device);
+    const hipStream_t stream = tr.compute;
     if (kd > 0) {
         tr.upload(ws.z.ptr, z, nsamp * sizeof(double));
         tr.upload(ws.nhi.ptr, nhi, nsamp * sizeof(double));
@@ -959,7 +1016,7 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
 // All pointers are device addresses; d_base may not be NULL when max_dlas > 1.
 static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d_sample_z, const double *d_sample_nhi,
                         int64_t nhi_stride, double min_z_separation, const double *d_uniforms, double *d_evidences,
-                        double *d_sample_ll, int *d_base, hipStream_t stream) {
+                        double *d_sample_ll, int *d_base, hipStream_t stream, bool keep_sticky_flag = false) {
     Workspace &ws = g.ws;
     const int nb = (int)g.ctxs.size();
     const size_t rows = (size_t)nb * S;
@@ -976,7 +1033,8 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
                        d_sample_ll, n_ll, nan);
     hipLaunchKernelGGL(fill_f64, dim3(1), dim3(256), 0, stream, d_evidences, (long)nb * max_dlas, nan);
     hipLaunchKernelGGL(fill_i32, dim3(1), dim3(256), 0, stream, ws.alive.as<int>(), (long)nb, 1);
-    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, stream, ws.alive.as<int>() + nb, 1L, 0);
+    if (!keep_sticky_flag)  // a second sweep of the same call adds to the first one's non-PD flag
+        hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, stream, ws.alive.as<int>() + nb, 1L, 0);
     if (n_base > 0)
         hipLaunchKernelGGL(fill_i32, dim3((unsigned)std::min<long>((n_base + 255) / 256, 2048)), dim3(256), 0, stream,
                            d_base, n_base, 0);
@@ -1741,8 +1799,8 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
     if ((rc = grow(g, ws.evidences, nb * max_dlas * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.sample_ll, rows * max_dlas * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.base, std::max<size_t>(n_base, 1) * sizeof(int32_t)))) return rc;
-    const hipStream_t stream = work_stream(g.device);
-    Transfers tr(ws.stage, stream);
+    Transfers tr(ws.stage, g.device);
+    const hipStream_t stream = tr.compute;
     tr.upload(ws.z.ptr, sample_z, rows * sizeof(double));
     tr.upload(ws.nhi.ptr, sample_nhi, n_nhi * sizeof(double));
     tr.upload(ws.uniforms.ptr, uniforms, n_base * sizeof(double));
@@ -1760,6 +1818,74 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
     int status = 0;
     HIP_TRY(hipMemcpy(&status, ws.alive.as<int>() + nb, sizeof(int), hipMemcpyDeviceToHost));
     if (status) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
+    return DLAGP_OK;
+}
+
+// The evidence loop of BayesModelSelect.model_selection (reference bayesian_model_selection.py:84-95) for every
+// sightline of the batch in ONE call: the one-absorber model (sub-DLAs), the occupation sweep of the DLA model and the
+// null model are enqueued back to back and waited for once -- one upload phase, one wait and one download phase per
+// batch instead of three of each.
+int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, const double *sub_sample_z,
+                                const double *sub_sample_nhi, int64_t sub_nhi_stride, const double *sample_z,
+                                const double *sample_nhi, int64_t nhi_stride, double min_z_separation,
+                                const double *uniforms, double *null_evidences, double *sub_evidences,
+                                double *sub_sample_ll, double *evidences, double *sample_ll, int32_t *base_inds) {
+    int rc = check_sweep_args(batch, S, max_dlas, sample_z, sample_nhi, nhi_stride, uniforms, evidences);
+    if (rc) return rc;
+    if ((rc = check_sweep_args(batch, S, 1, sub_sample_z, sub_sample_nhi, sub_nhi_stride, nullptr, sub_evidences))) return rc;
+    if (!null_evidences) return fail(DLAGP_EINVAL, "NULL argument");
+    LaunchGroup &g = batch->group;
+    HIP_TRY(hipSetDevice(g.device));
+    Workspace &ws = g.ws;
+    const size_t nb = g.ctxs.size();
+    const size_t rows = nb * (size_t)S;
+    const size_t n_nhi = nhi_stride ? (size_t)nhi_stride * (nb - 1) + S : (size_t)S;
+    const size_t n_sub_nhi = sub_nhi_stride ? (size_t)sub_nhi_stride * (nb - 1) + S : (size_t)S;
+    const size_t n_base = rows * (max_dlas - 1);
+    if ((rc = grow(g, ws.z, rows * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.nhi, n_nhi * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.uniforms, std::max<size_t>(n_base, 1) * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.evidences, nb * max_dlas * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.sample_ll, rows * max_dlas * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.base, std::max<size_t>(n_base, 1) * sizeof(int32_t)))) return rc;
+    if ((rc = grow(g, ws.sub_z, rows * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.sub_nhi, n_sub_nhi * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.sub_evidences, nb * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.sub_ll, rows * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.out, nb * sizeof(double)))) return rc;
+    Transfers tr(ws.stage, g.device);
+    const hipStream_t stream = tr.compute;
+    tr.upload(ws.sub_z.ptr, sub_sample_z, rows * sizeof(double));
+    tr.upload(ws.sub_nhi.ptr, sub_sample_nhi, n_sub_nhi * sizeof(double));
+    tr.upload(ws.z.ptr, sample_z, rows * sizeof(double));
+    tr.upload(ws.nhi.ptr, sample_nhi, n_nhi * sizeof(double));
+    tr.upload(ws.uniforms.ptr, uniforms, n_base * sizeof(double));
+    tr.download(null_evidences, ws.out.ptr, nb * sizeof(double));
+    tr.download(sub_evidences, ws.sub_evidences.ptr, nb * sizeof(double));
+    tr.download(sub_sample_ll, ws.sub_ll.ptr, rows * sizeof(double));
+    tr.download(evidences, ws.evidences.ptr, nb * max_dlas * sizeof(double));
+    tr.download(sample_ll, ws.sample_ll.ptr, rows * max_dlas * sizeof(double));
+    tr.download(base_inds, ws.base.ptr, n_base * sizeof(int32_t));
+    if ((rc = tr.reserve()) || (rc = tr.run_uploads())) return rc;
+    // model order of the reference's model list (run_bayes_select.py:189): the one-absorber model before the DLA model
+    rc = sweep_levels(g, S, 1, ws.sub_z.as<double>(), ws.sub_nhi.as<double>(), sub_nhi_stride, min_z_separation, nullptr,
+                      ws.sub_evidences.as<double>(), ws.sub_ll.as<double>(), nullptr, stream);
+    if (rc) return rc;
+    rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), nhi_stride, min_z_separation,
+                      ws.uniforms.as<double>(), ws.evidences.as<double>(), ws.sample_ll.as<double>(),
+                      ws.base.as<int>(), stream, /*keep_sticky_flag=*/true);
+    if (rc) return rc;
+    // the null model last: its launch leaves its own flag in ws.status, which the sweeps' launches would reset
+    rc = launch_sweep(g, 1, 0, SampleSource{nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0},
+                      ws.out.as<double>(), stream);
+    if (rc) return rc;
+    if ((rc = tr.run_downloads())) return rc;
+    g.launched = false;  // as in sweep_from_host
+    for (auto &p : g.parts) p->launched = false;
+    int status[2] = {0, 0};
+    HIP_TRY(hipMemcpy(&status[0], ws.alive.as<int>() + nb, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&status[1], ws.status.ptr, sizeof(int), hipMemcpyDeviceToHost));
+    if (status[0] || status[1]) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
     return DLAGP_OK;
 }
 
@@ -1909,6 +2035,7 @@ int dlagp_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "plan_xcd_affine")) g_opt_plan_xcd_affine = value;
     else if (!strcmp(name, "finalize_row16_blocks")) g_opt_finalize_row16_blocks = value;
     else if (!strcmp(name, "spare_workspaces")) g_opt_spare_workspaces = value;
+    else if (!strcmp(name, "shared_work_stream")) g_opt_shared_work_stream = value != 0;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 }
@@ -1935,6 +2062,7 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "plan_xcd_affine")) *value = g_opt_plan_xcd_affine;
     else if (!strcmp(name, "finalize_row16_blocks")) *value = g_opt_finalize_row16_blocks;
     else if (!strcmp(name, "spare_workspaces")) *value = g_opt_spare_workspaces;
+    else if (!strcmp(name, "shared_work_stream")) *value = g_opt_shared_work_stream;
     else if (!strcmp(name, "last_launch_path")) *value = g_last_launch_path;
     else if (!strcmp(name, "last_launch_items")) *value = g_last_launch_items;
     else if (!strcmp(name, "last_launch_parts")) *value = g_last_launch_parts;

@@ -129,6 +129,12 @@ class DeviceEngine:
     def sweep(self, batch, sample_z, sample_nhi, max_dlas, min_z_separation, seed):
         return parallel.sweep_batch_device(batch, sample_z, sample_nhi, max_dlas, min_z_separation, seed)
 
+    def model_evidences(self, batch, z_lls, nhi_sub, z_dla, nhi_dla, max_dlas, min_z_separation, seed):
+        """`nulls` and the two `sweep`s in one call into the library (optional: `process_qso` falls back to the three)"""
+        nb, S = z_dla.shape
+        return batch.model_evidences(z_lls, nhi_sub, z_dla, nhi_dla, max_dlas, min_z_separation,
+                                     parallel.resampling_uniforms(nb, max_dlas, S, seed))
+
     def release(self, batch, sightlines) -> None:
         batch.close()
         for s in sightlines:
@@ -234,7 +240,12 @@ def process_qso(
         engine.release(batch, sightlines)
 
     def sweeps(sightlines, batch, z_dla, z_lls):
-        """the three launches of one batch: null evidences, sub-DLA sweep, DLA sweep"""
+        """the three models of one batch: null evidences, sub-DLA sweep, DLA sweep"""
+        if hasattr(engine, "model_evidences"):  # one call into the library, one wait (the sub-DLA sweep draws nothing
+            # from the RNG, so the uniforms are the DLA sweep's either way)
+            nulls, (ev_sub, ll_sub, _), (ev_dla, ll_dla, base) = engine.model_evidences(
+                batch, z_lls, nhi_sub, z_dla, nhi_dla, max_dlas, min_sep, seed)
+            return nulls, ev_sub, ll_sub, ev_dla, ll_dla, base
         nulls = engine.nulls(batch, sightlines)
         # the sub-DLA model is swept before the DLA model (model list order, run_bayes_select.py:189);
         # with max_dlas = 1 it draws nothing from the RNG, so the DLA sweep sees the freshly seeded stream

@@ -228,6 +228,21 @@ int dlagp_batch_sweep_device(dlagp_batch *batch, int64_t S, int max_dlas, const 
                              double *d_sample_ll, int32_t *d_base_inds, void *stream);
 
 /*
+ * The evidence loop of BayesModelSelect.model_selection (reference bayesian_model_selection.py:84-95: one
+ * log_model_evidence / log_model_evidences call per model of [null, sub-DLA, DLA]) for every sightline of the
+ * batch in one synchronous call: the null evidences (dlagp_batch_null), the one-absorber sweep of the sub-DLA
+ * model (dlagp_batch_sweep with max_dlas = 1 over sub_sample_z / sub_sample_nhi) and the occupation sweep of the
+ * DLA model (dlagp_batch_sweep) are enqueued back to back and waited for once.  Same arguments and the same
+ * results, bit for bit, as the three calls; sub_sample_ll, sample_ll, base_inds may be NULL.
+ *   null_evidences [nb]   sub_evidences [nb]   sub_sample_ll [nb][S]   evidences / sample_ll / base_inds as above
+ */
+int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, const double *sub_sample_z,
+                                const double *sub_sample_nhi, int64_t sub_nhi_stride, const double *sample_z,
+                                const double *sample_nhi, int64_t nhi_stride, double min_z_separation,
+                                const double *uniforms, double *null_evidences, double *sub_evidences,
+                                double *sub_sample_ll, double *evidences, double *sample_ll, int32_t *base_inds);
+
+/*
  * Level evidence on the device (reference dla_gp.py:155-190), for sweeps whose results stay in HBM.
  * d_ll [nb][S] holds the sweep's log-likelihoods and is rewritten in place as the level's column of
  * `sample_log_likelihoods`: minus log S, NaN where d_too_close[b][i] != 0 (NULL = no mask).
@@ -285,7 +300,10 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     per sample, larger ones with one lane per sample: identical results; default 4096, 0 = never),
  *                     "spare_workspaces" (sweep workspaces of destroyed batches kept per device for the next
  *                     batches, default 4), "plan_xcd_affine" (1 = batches of >= 8 sightlines deal their work items so
- *                     that the workgroups of one XCD sweep one sightline's operand at a time; default 1)
+ *                     that the workgroups of one XCD sweep one sightline's operand at a time; default 1),
+ *                     "shared_work_stream" (1 = the kernels of the host-pointer entry points of ALL host threads go to
+ *                     one stream per device, each call waiting for its own completion event; default 0: every
+ *                     calling thread has its own stream)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.
  */

@@ -432,6 +432,101 @@ def test_batch_of_mixed_flavours_runs_as_homogeneous_mfma_groups(restore_options
     mixed.close()
 
 
+def test_model_evidences_in_one_call_equal_the_three_calls(restore_options):
+    """
+    dlagp_batch_model_evidences = dlagp_batch_null + dlagp_batch_sweep (sub-DLA model, one level) + dlagp_batch_sweep
+    (DLA model) enqueued back to back and waited for once: the same arrays bit for bit -- homogeneous batch and batch of
+    mixed flavours, profile cache on and off, from two host threads at once (on their own streams, and with option
+    shared_work_stream: kernels of both threads on one stream, each call waiting for its own completion event only) --
+    and a non-PD member in any of the three models is reported.
+    """
+    import threading
+
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch, DeviceSightline, get_option, set_option
+
+    sights = [make_sightline(20 + i, n_unmasked=n_u, n_masked=m) for i, (n_u, m) in
+              enumerate([(300, 5), (411, 0), (257, 30), (333, 7)])]
+    S, max_dlas, min_sep = 210, 3, 0.004
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    z_sub = np.stack([make_qmc_samples(s, S, sub_dla=True)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    nhi_sub = make_qmc_samples(sights[0], S, sub_dla=True)[2]
+    uniforms = parallel.resampling_uniforms(len(sights), max_dlas, S, seed=3)
+
+    def check(batch, rows=slice(None)):
+        nulls = batch.nulls()
+        sub = batch.sweep(z_sub[rows], nhi_sub, 1, min_sep)
+        dla = batch.sweep(zs[rows], nhi, max_dlas, min_sep, uniforms[rows])
+        got_nulls, got_sub, got_dla = batch.model_evidences(z_sub[rows], nhi_sub, zs[rows], nhi, max_dlas, min_sep,
+                                                            uniforms[rows])
+        np.testing.assert_array_equal(got_nulls, nulls)
+        for got, want in ((got_sub, sub), (got_dla, dla)):
+            assert got[2].shape == want[2].shape and got[1].shape == want[1].shape
+            for a, b in zip(got, want):
+                np.testing.assert_array_equal(a, b)  # NaN == NaN here
+        return got_nulls, got_sub, got_dla
+
+    assert get_option("shared_work_stream") == 0
+    flavours = [dict(), dict(broadening=False), dict(num_lines=5), dict(lls_break=True)]
+    for kinds in ([dict()] * 4, flavours):
+        devs = [device_sightline(s, **f) for s, f in zip(sights, kinds)]
+        batch = DeviceBatch(devs)
+        for cache in (1, 0):
+            set_option("profile_cache", cache)
+            first = check(batch)
+        set_option("profile_cache", 1)
+        # per-sightline column densities: (nb, S) tables for both models
+        wide = batch.model_evidences(z_sub, np.tile(nhi_sub, (4, 1)), zs, np.tile(nhi, (4, 1)), max_dlas, min_sep, uniforms)
+        np.testing.assert_array_equal(wide[2][1], first[2][1])
+        np.testing.assert_array_equal(wide[1][0], first[1][0])
+        batch.close()
+        for d in devs:
+            d.close()
+
+    # two host threads, a batch each, many calls: every call's results are its own
+    devs = [device_sightline(s) for s in sights]
+    halves = [DeviceBatch(devs[:2]), DeviceBatch(devs[2:])]
+    want = [check(halves[0], slice(0, 2)), check(halves[1], slice(2, 4))]
+    errors = []
+
+    def worker(i):
+        rows = slice(2 * i, 2 * i + 2)
+        try:
+            for _ in range(6):
+                got = halves[i].model_evidences(z_sub[rows], nhi_sub, zs[rows], nhi, max_dlas, min_sep, uniforms[rows])
+                np.testing.assert_array_equal(got[0], want[i][0])
+                np.testing.assert_array_equal(got[1][1], want[i][1][1])
+                np.testing.assert_array_equal(got[2][1], want[i][2][1])
+                np.testing.assert_array_equal(got[2][2], want[i][2][2])
+                np.testing.assert_array_equal(halves[i].nulls(), want[i][0])
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    for shared in (0, 1):
+        set_option("shared_work_stream", shared)
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+    set_option("shared_work_stream", 0)
+    for h in halves:
+        h.close()
+
+    # a member with an indefinite B: whichever model meets it first, the call reports it
+    bad = sights[0]
+    neg = DeviceSightline(bad.y, bad.this_mu, 10.0 * bad.this_M, bad.this_omega2, -np.abs(bad.v), bad.padded_wavelengths,
+                          bad.keep)
+    mixed = DeviceBatch([devs[1], neg])
+    with pytest.raises(np.linalg.LinAlgError):
+        mixed.model_evidences(z_sub[[1, 0]], nhi_sub, zs[[1, 0]], nhi, max_dlas, min_sep, uniforms[:2])
+    mixed.close()
+    with pytest.raises(ValueError):
+        DeviceBatch(devs[:2]).model_evidences(z_sub[:2, :50], nhi_sub[:50], zs[:2], nhi, max_dlas, min_sep, uniforms[:2])
+
+
 def test_full_size_properties():
     """BASELINE config 2 (n = 3000, k = 20, S = 10 000): size-independent properties"""
     sight = make_sightline(1)
@@ -477,6 +572,7 @@ def restore_options():
     set_option("pixel_splits", 0)
     set_option("profile_cache", 1)
     set_option("core_patch", 1)
+    set_option("shared_work_stream", 0)
 
 
 @pytest.mark.parametrize("shape", [dict(index=4, n_unmasked=1250, n_masked=28, k=20),

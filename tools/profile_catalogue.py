@@ -22,6 +22,7 @@ from tools.measure_catalogue import FixedPrior, make_inputs  # noqa: E402
 
 totals = defaultdict(float)
 lock = threading.Lock()
+events = []  # (name, thread, start, end) of the engine-level calls, for a timeline (DLAGP_TIMELINE=<file>)
 
 
 def timed(name, fn):
@@ -30,8 +31,11 @@ def timed(name, fn):
         try:
             return fn(*args, **kwargs)
         finally:
+            t1 = time.perf_counter()
             with lock:
-                totals[name] += time.perf_counter() - t0
+                totals[name] += t1 - t0
+                if not name.startswith(("C:", "py:")):
+                    events.append((name, threading.get_ident(), t0, t1))
     return wrapper
 
 
@@ -61,9 +65,14 @@ def main():
     rbs.prepare_data = timed("prepare_data", rbs.prepare_data)
     rbs.map_traceback = timed("map_traceback", rbs.map_traceback)
     rbs.occupation_log_priors = timed("log_priors", rbs.occupation_log_priors)
+    events.clear()
     t0 = time.perf_counter()
     rbs.process_qso(spectra, z_qsos, params, FixedPrior(), dla, sub, learned, batch_size=batch_size)
     wall = time.perf_counter() - t0
+    if os.environ.get("DLAGP_TIMELINE"):
+        threads = {t: i for i, t in enumerate(sorted({e[1] for e in events}))}
+        with open(os.environ["DLAGP_TIMELINE"], "w") as f:
+            json.dump([(n, threads[t], round((a - t0) * 1e3, 3), round((b - t0) * 1e3, 3)) for n, t, a, b in events], f)
     out = {"spectra": num, "S": S, "batch_size": batch_size, "wall_s": wall, "spectra_per_s": num / wall,
            "seconds_inside": {k: round(v, 4) for k, v in sorted(totals.items())}}
     print(json.dumps(out))
