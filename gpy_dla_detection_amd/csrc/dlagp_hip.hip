@@ -288,6 +288,7 @@ static std::mutex g_spare_mutex;
 static std::map<int, std::vector<Workspace>> g_spare_workspace;
 static Option g_opt_spare_workspaces = 4;
 static Option g_opt_shared_work_stream = 0;
+static Option g_opt_shared_rows = 1;  // cached levels: a wave whose samples stack the same cached row reads it once
 
 // Decomposition of one MFMA launch (a launch group at one sample count) into work items, see build_plan
 struct LaunchPlan {
@@ -787,7 +788,7 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
         g_last_launch_patch = patch;
         const bool lls = g.lls_break;
         double *part = ws.part.as<double>();
-        const int launch_flags = keep_status ? DLAGP_LAUNCH_KEEP_STATUS : 0;
+        const int launch_flags = (keep_status ? DLAGP_LAUNCH_KEEP_STATUS : 0) | (g_opt_shared_rows ? 0 : DLAGP_LAUNCH_GENERAL_ROWS);
         if (src.cache_mode == 2) {
             const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * sizeof(double);
             DLAGP_LAUNCH_MFMA(3, true, false, 2);
@@ -2036,6 +2037,7 @@ int dlagp_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "finalize_row16_blocks")) g_opt_finalize_row16_blocks = value;
     else if (!strcmp(name, "spare_workspaces")) g_opt_spare_workspaces = value;
     else if (!strcmp(name, "shared_work_stream")) g_opt_shared_work_stream = value != 0;
+    else if (!strcmp(name, "shared_rows")) g_opt_shared_rows = value != 0;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 }
@@ -2063,6 +2065,7 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "finalize_row16_blocks")) *value = g_opt_finalize_row16_blocks;
     else if (!strcmp(name, "spare_workspaces")) *value = g_opt_spare_workspaces;
     else if (!strcmp(name, "shared_work_stream")) *value = g_opt_shared_work_stream;
+    else if (!strcmp(name, "shared_rows")) *value = g_opt_shared_rows;
     else if (!strcmp(name, "last_launch_path")) *value = g_last_launch_path;
     else if (!strcmp(name, "last_launch_items")) *value = g_last_launch_items;
     else if (!strcmp(name, "last_launch_parts")) *value = g_last_launch_parts;

@@ -61,7 +61,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define DLAGP_MAX_PASS_CHUNKS (DLAGP_MAX_PASS_STEPS / DLAGP_CHUNK_STEPS)
 #define DLAGP_AUX_FIELDS 8       // per-pixel record: y, mu, omega2, v, window start, 3 spare
 #define DLAGP_BUFFER_FLAGS 0x00020000  // word 3 of a raw buffer resource on gfx9-family targets
-#define DLAGP_LAUNCH_KEEP_STATUS 0x10000  // launch_flags: do not clear the non-PD flag (see accumulate_mfma)
+#define DLAGP_LAUNCH_KEEP_STATUS 0x10000   // launch_flags: do not clear the non-PD flag (see accumulate_mfma)
+#define DLAGP_LAUNCH_GENERAL_ROWS 0x20000  // cached levels: 16 row reads per pass even where one would do (option shared_rows = 0)
 
 struct PassDesc {
     int entry_start;  // first entry computed by phase 1
@@ -260,12 +261,15 @@ __device__ __forceinline__ void lds_wave_sync() {
 // (lambda_rest / limit) 10^(-17.2/3), and the smallest grid wavelength T with fl(T / (1 + z)) > limit, found
 // by stepping ulps around limit (1 + z), so that the in-loop test `lambda >= T` reproduces the reference's
 // `rest_wavelengths > lambda_Lyman_limit` (:280) exactly without a division per entry.
-template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, int PATCH = 0, bool LLS = false>
-__global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
+//
+// UNIFORM (MODE 2 only, chosen per wave by the kernel below): the 16 samples of the wave stack the same cached row.
+template <int LINES, bool BROADEN, bool STAMPS, int MODE, int PATCH, bool LLS, bool UNIFORM>
+__device__ __forceinline__ void accumulate_mfma_body(
     const SightlineDev *__restrict__ sightlines, const PassDesc *__restrict__ passes,
     const WorkItem *__restrict__ items, int nb, long S, int kd,
     SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags) {
     constexpr bool CACHED = MODE == 2;
+    static_assert(!UNIFORM || CACHED, "only the cached levels read rows");
     constexpr int A_STRIDE = 4 * DLAGP_MAX_PASS_STEPS + 2;  // 58: stride/2 odd -> conflict-free b64 reads
     __shared__ double raw[16 * DLAGP_RAW_STRIDE];
     __shared__ double a_lds[16 * A_STRIDE];
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     // cached levels (MODE 2): the row of the running product and the cached row of the new absorber, per sample, for
     // the 64 pixel slots of a pass (lane = slot); loaded a pass ahead, see the step loop
     constexpr int NROW = CACHED ? 16 : 1;
-    double own[NROW], other[NROW];
+    double own[NROW], other[UNIFORM ? 1 : NROW];
     auto issue_rows = [&](const PassDesc &pd) __attribute__((always_inline)) {
         if constexpr (CACHED) {
             typedef const __attribute__((address_space(1))) double *gcd;
@@ -514,12 +518,13 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
             const long last = S - 1 - sample0;  // rows beyond S repeat the last sample (never stored)
             gcd cache_col = (gcd)src.cache + col;
             gcd run_col = (gcd)(kd == 2 ? src.cache : src.running) + (row0 + sample0) * src.cache_stride + col;
+            if constexpr (UNIFORM) other[0] = cache_col[(row0 + __builtin_amdgcn_readfirstlane(row_lds[0])) * src.cache_stride];
 #pragma unroll
             for (int ss = 0; ss < 16; ++ss) {
                 const long rel = ss < last ? ss : last;
                 // the running product is read once: streamed past the L2 that serves the sightline's operand
                 own[ss] = DLAGP_CACHE_STORE_NT ? __builtin_nontemporal_load(run_col + rel * src.cache_stride) : run_col[rel * src.cache_stride];
-                other[ss] = cache_col[(row0 + row_lds[ss]) * src.cache_stride];
+                if constexpr (!UNIFORM) other[ss] = cache_col[(row0 + row_lds[ss]) * src.cache_stride];
             }
         }
     };
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
             const int npx = pass_steps * DLAGP_STEP_PIXELS;
 #pragma unroll
             for (int ss = 0; ss < 16; ++ss) {
-                const double prod = own[ss] * other[ss];
+                const double prod = own[ss] * other[UNIFORM ? 0 : ss];
                 if (lane < npx) a_lds[ss * A_STRIDE + lane] = prod;
             }
             lds_wave_sync();
@@ -936,6 +941,32 @@ __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
         atomicAdd(&DLAGP_STAMPS[4], now - t_start);
         atomicAdd(&DLAGP_STAMPS[5], 1ULL);
         atomicAdd(&DLAGP_STAMPS[6], t_start - t_entry);  // prologue: descriptor, per-sample constants, core patch table
+    }
+}
+
+// The kernel: one wave per work item, see accumulate_mfma_body.  On the cached levels the wave first looks at the cached
+// rows its 16 samples stack on their running products.  The resampled base indices of a level concentrate on very few
+// QMC points (their weights are exp(log-likelihood): one to four distinct values among 10 000 draws on every spectrum
+// looked at, profiles/r03_experiments.txt item 16), so the 16 are nearly always the SAME row -- which is then read once
+// per pass instead of 16 times, by a copy of the body that holds one row register pair instead of 16.
+template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, int PATCH = 0, bool LLS = false>
+__global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
+    const SightlineDev *__restrict__ sightlines, const PassDesc *__restrict__ passes,
+    const WorkItem *__restrict__ items, int nb, long S, int kd,
+    SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags) {
+    if constexpr (MODE == 2) {
+        const WorkItem &item = items[blockIdx.x];
+        const long gb = sightlines[__builtin_amdgcn_readfirstlane(item.b)].batch_index;
+        long smp = (long)__builtin_amdgcn_readfirstlane(item.group) * DLAGP_MFMA_GROUP + (threadIdx.x & 15);
+        smp = smp < S ? smp : S - 1;
+        const int mine = (int)sample_point(src, gb, smp, kd - 1, S, kd);
+        const bool uniform = __builtin_amdgcn_ballot_w64(mine != __builtin_amdgcn_readfirstlane(mine)) == 0;
+        if (uniform && !(launch_flags & DLAGP_LAUNCH_GENERAL_ROWS))
+            accumulate_mfma_body<LINES, BROADEN, STAMPS, MODE, PATCH, LLS, true>(sightlines, passes, items, nb, S, kd, src, part, status, launch_flags);
+        else
+            accumulate_mfma_body<LINES, BROADEN, STAMPS, MODE, PATCH, LLS, false>(sightlines, passes, items, nb, S, kd, src, part, status, launch_flags);
+    } else {
+        accumulate_mfma_body<LINES, BROADEN, STAMPS, MODE, PATCH, LLS, false>(sightlines, passes, items, nb, S, kd, src, part, status, launch_flags);
     }
 }
 

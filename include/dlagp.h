@@ -303,7 +303,9 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     that the workgroups of one XCD sweep one sightline's operand at a time; default 1),
  *                     "shared_work_stream" (1 = the kernels of the host-pointer entry points of ALL host threads go to
  *                     one stream per device, each call waiting for its own completion event; default 0: every
- *                     calling thread has its own stream)
+ *                     calling thread has its own stream), "shared_rows" (1 = on the cached levels of a sweep a wave whose
+ *                     16 samples stack the same cached profile reads it once per pass; 0 = always 16 reads; identical
+ *                     results; default 1)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.
  */

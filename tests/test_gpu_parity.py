@@ -527,6 +527,36 @@ def test_model_evidences_in_one_call_equal_the_three_calls(restore_options):
         DeviceBatch(devs[:2]).model_evidences(z_sub[:2, :50], nhi_sub[:50], zs[:2], nhi, max_dlas, min_sep, uniforms[:2])
 
 
+def test_cached_levels_read_a_shared_row_once(restore_options):
+    """
+    The resampled base indices concentrate on very few QMC points, so the 16 samples of a wave mostly stack the SAME
+    cached row; such a wave reads it once per pass (option shared_rows, default 1) instead of 16 times.  Same arithmetic:
+    the sweep is bit-identical with the option off, on sightlines whose levels hold both kinds of waves.
+    """
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch, get_option, set_option
+
+    sights = [make_sightline(30 + i, n_unmasked=420 + 40 * i, n_masked=6) for i in range(3)]
+    devs = [device_sightline(s) for s in sights]
+    batch = DeviceBatch(devs)
+    S, max_dlas = 1000, 4  # S not a multiple of 16: the last wave repeats its last sample
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    uniforms = parallel.resampling_uniforms(3, max_dlas, S, seed=2)
+    assert get_option("shared_rows") == 1
+    got = batch.sweep(zs, nhi, max_dlas, 0.002, uniforms)
+    assert get_option("last_sweep_cached") == 1
+    set_option("shared_rows", 0)
+    want = batch.sweep(zs, nhi, max_dlas, 0.002, uniforms)
+    set_option("shared_rows", 1)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+    blocks = got[2][:, :, : S // 16 * 16].reshape(3, max_dlas - 1, -1, 16)
+    shared = (blocks == blocks[..., :1]).all(axis=-1)
+    assert shared.any() and not shared.all()  # both kinds of waves ran
+    batch.close()
+
+
 def test_full_size_properties():
     """BASELINE config 2 (n = 3000, k = 20, S = 10 000): size-independent properties"""
     sight = make_sightline(1)
@@ -573,6 +603,7 @@ def restore_options():
     set_option("profile_cache", 1)
     set_option("core_patch", 1)
     set_option("shared_work_stream", 0)
+    set_option("shared_rows", 1)
 
 
 @pytest.mark.parametrize("shape", [dict(index=4, n_unmasked=1250, n_masked=28, k=20),
