@@ -387,10 +387,12 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
 #define DLAGP_FIN_STAGED (DLAGP_FIN_COLS + DLAGP_FIN_K + 3)  // vech(B - I), u, 3 scalars
 #define DLAGP_FIN_LDS_STRIDE 17  // doubles per staged column in LDS: odd, so that columns two apart fall on different banks
 #define DLAGP_FINALIZE_LDS_DOUBLES (DLAGP_FIN_STAGED * DLAGP_FIN_LDS_STRIDE)
-// launches of up to this many blocks of 16 samples factor with 16 lanes per sample (latency-bound: few workgroups per
-// CU, the dependent chain of the one-lane form is what they wait for); larger launches keep one lane per sample
+// launches of up to this many blocks of 16 samples factor with 16 lanes per sample, larger ones with one lane per
+// sample (option finalize_row16_blocks).  The 16-lane form was written for small launches (few workgroups per CU: the
+// dependent chain of the one-lane form is what they wait for) but is the faster one on large ones too -- 442 against
+// 471 us on 40 000 blocks, 240 against 251 us on 20 000 (profiles/r03_experiments.txt item 18) -- so the default is "all".
 #ifndef DLAGP_FIN_ROW16_MAX_BLOCKS
-#define DLAGP_FIN_ROW16_MAX_BLOCKS 4096
+#define DLAGP_FIN_ROW16_MAX_BLOCKS (1L << 40)
 #endif
 
 // f(integral_constant<int, I>) for I = BEGIN .. END - 1, unrolled at compile time (DPP controls and register indices
