@@ -311,6 +311,13 @@ class ShardRunner:
     def run(self) -> np.ndarray:
         local = np.full((len(self.sightlines), 2 + self.max_dlas), np.nan)
         if self.batch is not None:
+            if hasattr(self.batch, "model_evidences"):  # the three models in one call into the library
+                S = self.z.shape[1]
+                nulls, sub, dla = self.batch.model_evidences(
+                    self.z, self.nhi_sub, self.z, self.nhi_dla, self.max_dlas, self.min_sep,
+                    resampling_uniforms(len(self.sightlines), self.max_dlas, S, 0))
+                local[:, 0], local[:, 1], local[:, 2:] = nulls, sub[0][:, 0], dla[0]
+                return local
             local[:, 0] = self.batch.nulls()
             if hasattr(self.batch, "sweep"):  # levels chained on the device
                 local[:, 1] = sweep_batch_device(self.batch, self.z, self.nhi_sub, 1, self.min_sep)[0][:, 0]
