@@ -43,6 +43,51 @@ def test_set_data_and_get_interp_match_reference_golden():
     assert abs(params.max_z_dla(gp.this_wavelengths, z_qso) - g["max_z_dla"]) < 1e-15
 
 
+def test_get_interp_is_shared_between_the_gp_objects_of_a_spectrum():
+    """
+    The driver's three GP objects per spectrum interpolate the same model onto the same pixels: the second and third
+    take the first one's result (their own copies, same layout, golden G7 to the last digit), and nothing is shared
+    across different pixels, redshifts, learned arrays or in-place edits of the model.
+    """
+    from gpy_dla_detection_amd import null_gp
+    from gpy_dla_detection_amd.null_gp import NullGP
+
+    g = load_golden("set_data.npz")
+    z_qso, rest, flux, nv, mask, rest_grid, mu, M, log_omega, lc0, lt0, lb = raw_spectrum_and_model()
+    params = Parameters()
+    null_gp._INTERP_CACHE.entries.clear()
+    gps = [NullGP(params, FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb) for _ in range(3)]
+    for gp in gps:
+        gp.set_data(rest, flux, nv, mask, z_qso, normalize=True, build_model=True)
+    assert len(null_gp._INTERP_CACHE.entries) == 1  # one computation, two hits
+    for gp in gps:
+        for name in ("this_mu", "this_M", "this_omega2"):
+            np.testing.assert_allclose(getattr(gp, name), g[name], rtol=1e-14, atol=0, err_msg=name)
+            np.testing.assert_array_equal(getattr(gp, name), getattr(gps[0], name))
+        assert gp.this_M.flags["F_CONTIGUOUS"]
+    assert gps[1].this_M is not gps[0].this_M
+    gps[1].this_mu[:] = 0.0  # a caller's edit stays the caller's
+    assert gps[0].this_mu[0] != 0.0 and gps[2].this_mu[0] != 0.0
+    fresh = NullGP(params, FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb)
+    fresh.set_data(rest, flux, nv, mask, z_qso)
+    np.testing.assert_array_equal(fresh.this_mu, gps[0].this_mu)  # the cache's own copy is untouched
+    # other pixels / another redshift / another model: computed, not looked up
+    other = NullGP(params, FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb)
+    other.set_data(rest, flux, nv, mask, z_qso + 0.01)
+    assert len(null_gp._INTERP_CACHE.entries) == 2 and not np.array_equal(other.this_mu, fresh.this_mu)
+    scaled = NullGP(params, FixedPrior(), rest_grid, 2.0 * mu, M, log_omega, lc0, lt0, lb)
+    scaled.set_data(rest, flux, nv, mask, z_qso)
+    np.testing.assert_allclose(scaled.this_mu, 2.0 * fresh.this_mu, rtol=1e-15)
+    edited = mu.copy()
+    first = NullGP(params, FixedPrior(), rest_grid, edited, M, log_omega, lc0, lt0, lb)
+    first.set_data(rest, flux, nv, mask, z_qso)
+    edited *= 3.0  # in place, same array object
+    second = NullGP(params, FixedPrior(), rest_grid, edited, M, log_omega, lc0, lt0, lb)
+    second.set_data(rest, flux, nv, mask, z_qso)
+    np.testing.assert_allclose(second.this_mu, 3.0 * first.this_mu, rtol=1e-15)
+    assert len(null_gp._INTERP_CACHE.entries) <= null_gp._INTERP_CACHE.size
+
+
 def test_parameters_surface():
     p = Parameters()
     assert p.k == 20 and p.num_dla_samples == 10000 and p.num_lines == 3 and p.width == 3
