@@ -283,10 +283,10 @@ struct Workspace {
 
 static std::mutex g_spare_mutex;
 // per device: workspaces of destroyed batches, adopted by the next batches created.  A pipelined catalogue run has
-// up to four batches alive at a time (one being prepared, two in their sweeps, one being finished): with a single
+// up to five batches alive at a time (one being prepared, three in their sweeps, one being finished): with a single
 // spare every other batch freed and reallocated gigabytes (hipFree synchronises the device: 7 ms per batch).
 static std::map<int, std::vector<Workspace>> g_spare_workspace;
-static Option g_opt_spare_workspaces = 4;
+static Option g_opt_spare_workspaces = 5;
 static Option g_opt_shared_work_stream = 0;
 static Option g_opt_shared_rows = 1;  // cached levels: a wave whose samples stack the same cached row reads it once
 

@@ -299,7 +299,7 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     "finalize_row16_blocks" (launches of up to this many blocks of 16 samples factor with 16 lanes
  *                     per sample, larger ones with one lane per sample: identical results; default 2^40 = all, 0 = never),
  *                     "spare_workspaces" (sweep workspaces of destroyed batches kept per device for the next
- *                     batches, default 4), "plan_xcd_affine" (1 = batches of >= 8 sightlines deal their work items so
+ *                     batches, default 5), "plan_xcd_affine" (1 = batches of >= 8 sightlines deal their work items so
  *                     that the workgroups of one XCD sweep one sightline's operand at a time; default 1),
  *                     "shared_work_stream" (1 = the kernels of the host-pointer entry points of ALL host threads go to
  *                     one stream per device, each call waiting for its own completion event; default 0: every

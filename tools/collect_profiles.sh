@@ -16,6 +16,6 @@ for c in 3 5; do
   cp $out/prof_c$c/*/*_kernel_stats.csv $out/kernel_stats_config$c.csv
 done
 python3 tools/measure_configs.py 2>/dev/null | tail -1 > $out/other_configs.json
-python3 tools/measure_catalogue.py 1024 10000 32 2>/dev/null | tail -1 > $out/catalogue_pipeline.json
+python3 tools/measure_catalogue.py 2048 10000 32 2>/dev/null | tail -1 > $out/catalogue_pipeline.json
 rm -rf $out/prof $out/prof_c3 $out/prof_c5
 ls -la $out
