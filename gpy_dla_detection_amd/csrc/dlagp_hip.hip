@@ -168,6 +168,11 @@ static void pool_flush() {
     (void)hipSetDevice(current);
 }
 
+// buffers above the pool's size limit (sweep workspaces: partial sums, profile cache) that were allocated / freed since the
+// library was loaded; a free synchronises the device (options "big_allocs", "big_frees": read-only diagnostics)
+static Option g_stat_big_allocs = 0;
+static Option g_stat_big_frees = 0;
+
 struct DeviceBuffer {
     void *ptr = nullptr;
     size_t bytes = 0;
@@ -199,6 +204,7 @@ struct DeviceBuffer {
             }
         }
         HIP_TRY(hipMalloc(&ptr, want));
+        if (want > kPoolMaxBuffer) g_stat_big_allocs.v.fetch_add(1, std::memory_order_relaxed);
         bytes = want;
         return DLAGP_OK;
     }
@@ -216,7 +222,10 @@ struct DeviceBuffer {
                 }
             }
         }
-        if (!parked) (void)hipFree(ptr);
+        if (!parked) {
+            (void)hipFree(ptr);  // synchronises the device
+            if (bytes > kPoolMaxBuffer) g_stat_big_frees.v.fetch_add(1, std::memory_order_relaxed);
+        }
         ptr = nullptr;
         bytes = 0;
     }
@@ -2066,6 +2075,8 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spare_workspaces")) *value = g_opt_spare_workspaces;
     else if (!strcmp(name, "shared_work_stream")) *value = g_opt_shared_work_stream;
     else if (!strcmp(name, "shared_rows")) *value = g_opt_shared_rows;
+    else if (!strcmp(name, "big_allocs")) *value = g_stat_big_allocs;
+    else if (!strcmp(name, "big_frees")) *value = g_stat_big_frees;
     else if (!strcmp(name, "last_launch_path")) *value = g_last_launch_path;
     else if (!strcmp(name, "last_launch_items")) *value = g_last_launch_items;
     else if (!strcmp(name, "last_launch_parts")) *value = g_last_launch_parts;

@@ -316,7 +316,9 @@ int dlagp_set_option(const char *name, int64_t value);
  * (1 = the last dlagp_batch_sweep* used the profile cache), "last_launch_patch" (how the last MFMA launch handled
  * the line cores: 0 tested inside the sample loop, 1 repaired once per wave, 2 repaired pass by pass),
  * "last_launch_groups" (homogeneous launch groups the last call ran as: > 1 for a batch that mixes line counts,
- * broadening or Lyman-limit flags). */
+ * broadening or Lyman-limit flags), "big_allocs" / "big_frees" (sweep-workspace buffers above the pool's 64 MB
+ * limit allocated / freed since the library was loaded -- a free synchronises the device; a pipelined run in its steady
+ * state shows neither). */
 int dlagp_get_option(const char *name, int64_t *value);
 /* The work decomposition the MFMA path would choose for `groups` blocks of 16 samples of sightlines with `chunks`
  * chunks of 8 pixel slots each (pure host arithmetic, no device needed): every block is cut into `full` pieces of

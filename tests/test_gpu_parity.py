@@ -557,6 +557,38 @@ def test_cached_levels_read_a_shared_row_once(restore_options):
     batch.close()
 
 
+def test_sweep_workspaces_are_recycled_between_batches():
+    """
+    A destroyed batch leaves its sweep workspace (partial sums, profile cache: buffers above the pool's size limit) to the
+    next batch created: a sequence of batches of the same shape allocates its big buffers once and never frees one (a
+    free synchronises the device) -- read back through the `big_allocs` / `big_frees` diagnostics.
+    """
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch, get_option
+
+    sights = [make_sightline(40 + i, n_unmasked=900, n_masked=4) for i in range(4)]
+    S = 6000
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    uniforms = parallel.resampling_uniforms(4, 3, S, seed=1)
+
+    def one_batch():
+        devs = [device_sightline(s) for s in sights]
+        batch = DeviceBatch(devs)
+        out = batch.sweep(zs, nhi, 3, 0.003, uniforms)
+        batch.close()
+        for d in devs:
+            d.close()
+        return out
+
+    first = one_batch()  # whatever this one had to allocate
+    allocs, frees = get_option("big_allocs"), get_option("big_frees")
+    for _ in range(3):
+        again = one_batch()
+        np.testing.assert_array_equal(again[0], first[0])
+    assert get_option("big_allocs") == allocs and get_option("big_frees") == frees
+
+
 def test_full_size_properties():
     """BASELINE config 2 (n = 3000, k = 20, S = 10 000): size-independent properties"""
     sight = make_sightline(1)

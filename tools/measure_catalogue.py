@@ -69,13 +69,22 @@ def main():
     # warm-up through the pipeline itself: every workspace it keeps in flight gets its buffers (pinned staging, GBs of cache)
     warm = min(num, 6 * batch_size)
     process_qso(spectra[:warm], z_qsos[:warm], params, FixedPrior(), dla, sub, learned, batch_size=batch_size)
+    from gpy_dla_detection_amd.sightline import get_option
+
+    allocs_before = (get_option("big_allocs"), get_option("big_frees"))
+    free_before = torch.cuda.mem_get_info()[0]
     t0 = time.perf_counter()
     res = process_qso(spectra, z_qsos, params, FixedPrior(), dla, sub, learned, batch_size=batch_size)
     t = time.perf_counter() - t0
+    free_after = torch.cuda.mem_get_info()[0]
     out = {
         "spectra": num, "S": S, "max_dlas": 4, "batch_size": batch_size, "seconds": t,
         "spectra_per_s": num / t, "evals_per_s": num * (1 + 5 * S) / t,
         "argmax_counts": np.bincount(np.argmax(res["model_posteriors"], axis=1), minlength=6).tolist(),
+        # device memory held by the library's pools after the warm-up, and what the timed run added to it
+        "hbm_in_use_gb": round((torch.cuda.mem_get_info()[1] - free_after) / 2 ** 30, 2),
+        "hbm_growth_during_run_gb": round((free_before - free_after) / 2 ** 30, 3),
+        "workspace_allocs_frees_during_run": [get_option("big_allocs") - allocs_before[0], get_option("big_frees") - allocs_before[1]],
     }
     if os.environ.get("DLAGP_PROFILE"):
         import cProfile
