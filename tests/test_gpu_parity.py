@@ -484,6 +484,23 @@ def test_model_evidences_in_one_call_equal_the_three_calls(restore_options):
         for d in devs:
             d.close()
 
+    # the smallest shapes: one level (no uniforms, no base indices), one sample
+    devs = [device_sightline(s) for s in sights[:2]]
+    small = DeviceBatch(devs)
+    for S1, levels in ((S, 1), (1, 2), (17, 1)):
+        u1 = parallel.resampling_uniforms(2, levels, S1, seed=5)
+        got_nulls, got_sub, got_dla = small.model_evidences(z_sub[:2, :S1], nhi_sub[:S1], zs[:2, :S1], nhi[:S1], levels, min_sep,
+                                                            u1 if levels > 1 else None)
+        np.testing.assert_array_equal(got_nulls, small.nulls())
+        want_dla = small.sweep(zs[:2, :S1], nhi[:S1], levels, min_sep, u1 if levels > 1 else None)
+        for a, b in zip(got_dla, want_dla):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(got_sub[1], small.sweep(z_sub[:2, :S1], nhi_sub[:S1], 1, min_sep)[1])
+        assert got_dla[2].shape == (2, levels - 1, S1)
+    small.close()
+    for d in devs:
+        d.close()
+
     # two host threads, a batch each, many calls: every call's results are its own
     devs = [device_sightline(s) for s in sights]
     halves = [DeviceBatch(devs[:2]), DeviceBatch(devs[2:])]
