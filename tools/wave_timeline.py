@@ -56,3 +56,15 @@ counts = np.array([len(v) for v in per_simd.values()])
 print("items per SIMD: " + ", ".join("%d x %d" % (c, (counts == c).sum()) for c in sorted(set(counts))))
 ends = np.sort(end)
 print("ends: 10%% %.1f us, 50%% %.1f, 90%% %.1f, 99%% %.1f, last %.1f" % tuple(np.percentile(ends, [10, 50, 90, 99, 100]) / 1e3))
+# full-length items: how their duration depends on where they ran
+full = passes == np.max(passes)
+dur = (end - start) / 1e3
+print("full items: duration percentiles 1/10/50/90/99: %.1f %.1f %.1f %.1f %.1f us" % tuple(np.percentile(dur[full], [1, 10, 50, 90, 99])))
+for name, arr in (("xcc", xcc), ("se", se), ("simd", simd)):
+    print("  by %s: " % name + "  ".join("%d: %.1f (n=%d)" % (v, dur[full & (arr == v)].mean(), (full & (arr == v)).sum()) for v in sorted(set(arr[full]))))
+# does a SIMD's other slot matter?  full items whose SIMD also ran remainder items against those paired with another full item
+count_on = {k: len(v) for k, v in per_simd.items()}
+paired = np.array([count_on[(int(k), int(s_))] for k, s_ in zip(key, simd)])
+print("  full item beside another full item: %.1f us; beside remainder items: %.1f us" % (dur[full & (paired == 2)].mean(), dur[full & (paired > 2)].mean()))
+blk = np.arange(items)
+print("  by dispatch order (blockIdx quartiles): " + "  ".join("%.1f" % dur[full & (blk * 4 // items == q)].mean() for q in range(4) if (full & (blk * 4 // items == q)).any()))
