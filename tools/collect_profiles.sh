@@ -11,6 +11,7 @@ for c in 3 4 5; do python3 bench.py --config $c > $out/bench_config$c.json 2>> $
 python3 bench.py --strong --no-cpu-baseline > $out/bench_strong_n1.json 2>> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2>&1
 cp $out/prof/*/*_kernel_stats.csv $out/kernel_stats.csv
+python3 tools/timed_region_average.py $out/prof/*/*_kernel_trace.csv 200 > $out/kernel_timed_region.json
 for c in 3 5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_c$c -- python3 bench.py --no-cpu-baseline --config $c --steps 3 > $out/bench_config${c}_under_rocprof.json 2>&1
   cp $out/prof_c$c/*/*_kernel_stats.csv $out/kernel_stats_config$c.csv
