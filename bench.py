@@ -87,8 +87,13 @@ def measured_hbm_traffic(config: int):
 _CPU_STATE = None
 
 
-def _cpu_worker_init(sight):
+def _cpu_worker_init(sight, core_queue=None):
     global _CPU_STATE
+    if core_queue is not None:  # one worker per core: pinned, so that chunks are not migrated or stacked
+        try:
+            os.sched_setaffinity(0, {core_queue.get()})
+        except (OSError, AttributeError):
+            pass
     try:
         from threadpoolctl import threadpool_limits
 
@@ -107,9 +112,10 @@ def _cpu_worker_init(sight):
 def _cpu_worker_eval(args):
     zs, ns = args
     ref_like, st = _CPU_STATE
+    t0 = time.perf_counter()
     for zi, ni in zip(zs, ns):
         ref_like.sample_log_likelihood_k_dlas(st, np.atleast_1d(zi), np.atleast_1d(ni))
-    return len(zs)
+    return len(zs), time.perf_counter() - t0
 
 
 def _single_process_rate(evals, seconds):
@@ -121,30 +127,141 @@ def _single_process_rate(evals, seconds):
     return done / (time.perf_counter() - t0), done
 
 
-def cpu_baseline(sight, evals, cpu_seconds: float = 18.0, single_seconds: float = 4.0):
+def host_cpu_share():
+    """
+    (cores to use, how that number was arrived at).  The affinity mask of a one-GPU box of the pool shows every CPU of
+    the 8-GPU host; what this job may actually use is its cgroup's CPU quota when one is set, and otherwise the
+    pool's stated share of 16 cores per GPU (worker pools beyond it are killed by the box's process guard).  One
+    worker per PHYSICAL core: SMT siblings of a core already taken are skipped.
+    """
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    physical, seen = [], set()
+    for cpu in allowed:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu) as f:
+                key = f.read().strip()
+        except OSError:
+            key = str(cpu)
+        if key not in seen:
+            seen.add(key)
+            physical.append(cpu)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            limit, period = f.read().split()[:2]
+        if limit != "max":
+            quota = float(limit) / float(period)
+    except (OSError, ValueError):
+        pass
+    physical = _idlest_first(physical)
+    if quota is not None:
+        count = max(1, min(len(physical), int(quota)))
+        why = "cgroup cpu.max quota %.1f CPUs (affinity mask: %d CPUs, %d physical cores)" % (quota, len(allowed), len(physical))
+    elif len(physical) > 16:
+        count = 16
+        why = ("the pool's share of 16 cores per GPU (affinity mask: %d CPUs = the whole 8-GPU host, %d physical cores, "
+               "no cgroup quota)" % (len(allowed), len(physical)))
+    else:
+        count = len(physical)
+        why = "every physical core of the affinity mask (%d CPUs)" % len(allowed)
+    return physical[:count], why
+
+
+def _idlest_first(cpus, interval: float = 0.25):
+    """
+    `cpus` ordered by how busy each was over `interval` seconds (/proc/stat), idlest first, ties in index order: the
+    host is shared with the jobs of its other GPUs, and pinning to cores another tenant is using is what makes a
+    baseline irreproducible.
+    """
+    def snapshot():
+        busy = {}
+        try:
+            with open("/proc/stat") as f:
+                for ln in f:
+                    if ln.startswith("cpu") and ln[3].isdigit():
+                        parts = ln.split()
+                        ticks = [int(x) for x in parts[1:9]]
+                        busy[int(parts[0][3:])] = sum(ticks) - ticks[3] - ticks[4]  # all but idle and iowait
+        except (OSError, ValueError, IndexError):
+            pass
+        return busy
+
+    before = snapshot()
+    time.sleep(interval)
+    after = snapshot()
+    return sorted(cpus, key=lambda c: (after.get(c, 0) - before.get(c, 0), c))
+
+
+def host_description():
+    info = {"numpy": np.__version__}
+    try:
+        import scipy
+
+        info["scipy"] = scipy.__version__
+    except ImportError:
+        pass
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    info["cpu_model"] = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        from threadpoolctl import threadpool_info
+
+        import scipy.linalg  # noqa: F401  (maps scipy's BLAS so that it is listed)
+
+        info["blas"] = sorted({"%s %s (%s, %s)" % (p.get("internal_api"), p.get("version"), p.get("threading_layer"),
+                                                  p.get("architecture")) for p in threadpool_info()
+                               if p.get("user_api") == "blas"})
+    except Exception:
+        pass
+    return info
+
+
+def cpu_baseline(sight, evals, chunks: int = 5, chunk_seconds: float = 3.5, single_seconds: float = 4.0):
     """
     BASELINE.md §3 on a bounded sample of the step's evals (`evals`: parameter sets drawn from the workload):
-      (iii) one process per core of this job's share (16 on a one-GPU box), BLAS pinned to 1 thread: `value`
+      (iii) one process per core of this job's share (`host_cpu_share`), each PINNED to its own physical core, BLAS
+            limited to 1 thread: `value` = the MEDIAN over `chunks` equal chunks of (evals of the chunk / wall time
+            of the chunk); per-chunk rates, the per-core rate from the workers' own clocks and the spread are listed
       (i)   1 process x 1 BLAS thread, (ii) 1 process x default BLAS threads: under `variants`
-    About cpu_seconds + 2 x single_seconds of CPU work in total.
+    About chunks x chunk_seconds + 2 x single_seconds of wall time in total.
     """
     import multiprocessing as mp
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    workers = max(1, min(cores, 16))  # a one-GPU box gives this job a 16-core share
+    cores, why = host_cpu_share()
+    workers = len(cores)
     ctx = mp.get_context("fork")
-    with ctx.Pool(workers, initializer=_cpu_worker_init, initargs=(sight,)) as pool:
-        pool.map(_cpu_worker_eval, [([evals[0][0]], [evals[0][1]])] * workers)  # imports, BLAS init
-        done, elapsed, cursor = 0, 0.0, 0
-        while elapsed * workers < cpu_seconds:
-            chunks = []
-            for w in range(workers):
-                take = [evals[(cursor + w * 128 + i) % len(evals)] for i in range(128)]
-                chunks.append(([t[0] for t in take], [t[1] for t in take]))
-            cursor += 128 * workers
+    queue = ctx.Queue()
+    for core in cores:
+        queue.put(core)
+
+    def chunk_args(per_worker, cursor):
+        out = []
+        for w in range(workers):
+            take = [evals[(cursor + w * per_worker + i) % len(evals)] for i in range(per_worker)]
+            out.append(([t[0] for t in take], [t[1] for t in take]))
+        return out
+
+    with ctx.Pool(workers, initializer=_cpu_worker_init, initargs=(sight, queue)) as pool:
+        pool.map(_cpu_worker_eval, chunk_args(1, 0), chunksize=1)  # imports, BLAS init
+        # size a chunk from a short calibration: the same number of evals for every worker and every chunk
+        t0 = time.perf_counter()
+        pool.map(_cpu_worker_eval, chunk_args(16, 0), chunksize=1)
+        per_worker = max(16, int(16 * chunk_seconds / max(time.perf_counter() - t0, 1e-3)))
+        rates, busy, done, cursor = [], [], 0, 0
+        for _ in range(chunks):
             t0 = time.perf_counter()
-            done += sum(pool.map(_cpu_worker_eval, chunks))
-            elapsed += time.perf_counter() - t0
+            results = pool.map(_cpu_worker_eval, chunk_args(per_worker, cursor), chunksize=1)
+            wall = time.perf_counter() - t0
+            cursor += per_worker * workers
+            count = sum(r[0] for r in results)
+            done += count
+            rates.append(count / wall)
+            busy.extend(r[0] / r[1] for r in results)  # each worker's own rate while it ran
     variants = {}
     _cpu_worker_init(sight)  # this process: BLAS limited to one thread ...
     rate_i, n_i = _single_process_rate(evals, single_seconds)
@@ -153,21 +270,27 @@ def cpu_baseline(sight, evals, cpu_seconds: float = 18.0, single_seconds: float 
         from threadpoolctl import threadpool_info, threadpool_limits
 
         default_threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-        with threadpool_limits(limits=cores):
+        with threadpool_limits(limits=workers):
             rate_ii, n_ii = _single_process_rate(evals, single_seconds)
-        variants["ii_one_process_default_blas_threads"] = {"value": rate_ii, "cores": cores, "evals": n_ii,
+        variants["ii_one_process_default_blas_threads"] = {"value": rate_ii, "cores": workers, "evals": n_ii,
                                                            "blas_threads_seen": default_threads}
     except Exception:
         pass
+    rates_sorted = sorted(rates)
     return {
-        "value": done / elapsed,
+        "value": float(np.median(rates)),
         "unit": "evals/s",
         "cores": workers,
         "kind": "port",
-        "sample": "%d evals drawn from the %d parameter sets of one step's workload, %d processes x 1 BLAS thread, %.1f s wall"
-                  % (done, len(evals), workers, elapsed),
+        "sample": "%d evals drawn from the %d parameter sets of one step's workload: %d chunks of %d evals on each of %d "
+                  "pinned processes x 1 BLAS thread; value = median chunk rate" % (done, len(evals), chunks, per_worker, workers),
+        "chunk_rates": rates,
+        "spread": (rates_sorted[-1] - rates_sorted[0]) / float(np.median(rates)),
+        "per_core": float(np.median(busy)),
+        "cores_why": why,
         "variants": variants,
         "host_cpus": os.cpu_count(),
+        "host": host_description(),
     }
 
 
@@ -187,7 +310,7 @@ def baseline_sample(config, sight, z, nhi_dla, nhi_sub):
     return evals
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
@@ -198,61 +321,322 @@ def main() -> None:
     ap.add_argument("--samples", type=int, default=NUM_SAMPLES, help=argparse.SUPPRESS)
     ap.add_argument("--sightlines", type=int, default=0, help=argparse.SUPPRESS)  # tuning: override the batch width
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-other-configs", action="store_true", help=argparse.SUPPRESS)  # headline measurement only
     ap.add_argument("--splits", type=int, default=0, help=argparse.SUPPRESS)  # tuning: force the pixel-split count
     ap.add_argument("--option", action="append", default=[], help=argparse.SUPPRESS)  # tuning: library option name=value
     ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)  # 2: per-phase cycle stamps (diagnostic)
     # rehearsal of the N > 1 code path on a one-GPU box: every rank on device 0, gloo instead of RCCL
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help=argparse.SUPPRESS)
-    args = ap.parse_args()
-    config = args.config
-    if args.strong and config != 2:
+    args = ap.parse_args(argv)
+    if args.strong and args.config != 2:
         raise SystemExit("--strong splits the samples of configs[1]'s single sightline: use --config 2")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    return args
+
+
+def self_launch(args, argv) -> int:
+    """
+    Plain `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as a CHILD
+    `python -m torch.distributed.run` (never an exec: this process may not be replaced once anything has touched the
+    GPU, and nothing here has -- torch is not imported yet), relay rank 0's one JSON line and return the child's exit
+    code.  Under torch.distributed.run (WORLD_SIZE set) this is never reached.
+    """
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    try:
+        for raw in child.stdout:
+            # rank 0's line goes to stdout untouched; anything else a rank printed is kept out of the one-line contract
+            (sys.stdout if raw.startswith("{") else sys.stderr).write(raw)
+            (sys.stdout if raw.startswith("{") else sys.stderr).flush()
+        return child.wait()
+    except BaseException:
+        child.terminate()  # the exact child we started; torch.distributed.run forwards the signal to its ranks
+        try:
+            child.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            child.kill()
+        raise
+
+
+class Env:
+    """what every measurement of this process shares: its rank, its device, the process group"""
+
+    def __init__(self, args):
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.rehearse = bool(args.rehearse_on_one_gpu)
+        self.local_rank = 0 if self.rehearse else int(os.environ.get("LOCAL_RANK", "0"))
+        # launched through torch.distributed.run: the process group and every collective run even with one rank (a
+        # one-GPU box then exercises the RCCL calls of the N > 1 path); plain `python bench.py` has no group
+        self.dist_on = self.world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+        self.torch = self.dist = self.device = None
+
+    def start(self):
+        import torch
+        import torch.distributed as dist
+
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        torch.cuda.set_device(self.local_rank)
+        self.torch, self.dist = torch, dist
+        self.device = torch.device("cuda", self.local_rank)
+        if self.dist_on:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.rehearse:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.device)
+
+    def all_gather(self, out, mine):
+        if self.dist_on and self.rehearse:  # gloo has no all_gather_into_tensor for device tensors
+            self.dist.all_gather(list(out.view(self.world, -1).unbind(0)), mine)
+        elif self.dist_on:
+            self.dist.all_gather_into_tensor(out, mine)
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.dist_on:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        """element-wise maximum of a short list of floats over the ranks (NaN-free inputs)"""
+        if not self.dist_on:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=self.torch.float64,
+                              device="cpu" if self.rehearse else self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
+
+class Workload:
+    """
+    One configuration's sightlines, sample tables and output slots resident on this rank's GPU, and `step()`: one
+    pass of the hot path over them, enqueued on torch's current stream.
+    """
+
+    def __init__(self, env, config, S, nb, strong, slots):
+        from gpy_dla_detection_amd import sightline as sl
+        from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline
+
+        torch = env.torch
+        self.env, self.config, self.S, self.nb, self.strong, self.slots, self.sl = env, config, S, nb, strong, slots, sl
+        first = 0 if strong else env.rank * nb  # weak scaling: every rank has its own sightlines
+        self.sights = [make_sightline(first + i, n_unmasked=N_UNMASKED, n_masked=N_MASKED, k=RANK_K) for i in range(nb)]
+        self.z_host = np.stack([make_qmc_samples(s, S)[0] for s in self.sights])
+        self.nhi_dla_host = make_qmc_samples(self.sights[0], S)[2]
+        self.nhi_sub_host = make_qmc_samples(self.sights[0], S, sub_dla=True)[2]
+        self.devs = self.batch = None
+        self.max_dlas = 4 if config == 5 else 1
+        # Every step's evidences land in their own slot; the ranks exchange them with ONE all-gather at the end of
+        # the timed region -- the communication pattern of a sharded catalogue run (parallel.model_evidences_sharded).
+        self.per_step = {2: 1, 3: 2 * nb, 4: 3 * nb, 5: 4 * nb}[config]
+        self.counter = 0
+        self.lo, self.hi = 0, S
+        if strong:
+            per_rank = -(-S // env.world)
+            self.lo, self.hi = min(env.rank * per_rank, S), min((env.rank + 1) * per_rank, S)
+            self.per_rank = per_rank
+        self.evals_per_step = {2: float(self.hi - self.lo), 3: 2.0 * nb * S, 4: nb * (1.0 + 2 * S), 5: 4.0 * nb * S}[config]
+        self.mfma_evals_per_step = {2: self.evals_per_step, 3: 2.0 * nb * S, 4: 2.0 * nb * S, 5: 4.0 * nb * S}[config]
+        self.flops = algorithmic_flops_per_eval(self.sights[0].n, self.sights[0].k)
+
+    def upload(self):
+        env, sl, torch, S, nb = self.env, self.sl, self.env.torch, self.S, self.nb
+        f64 = dict(dtype=torch.float64, device=env.device)
+        self.devs = [sl.DeviceSightline.from_state(s, device=env.local_rank) for s in self.sights]
+        self.batch = sl.DeviceBatch(self.devs) if self.config != 2 else None
+        self.z = torch.from_numpy(self.z_host).to(env.device)
+        self.nhi_dla = torch.from_numpy(self.nhi_dla_host).to(env.device).contiguous()
+        self.nhi_sub = torch.from_numpy(self.nhi_sub_host).to(env.device)
+        self.evidences = torch.zeros(self.slots * self.per_step, **f64)
+        self.gathered = torch.zeros(env.world * self.slots * self.per_step, **f64) if env.dist_on else None
+        if self.config == 2:
+            self.out = torch.empty(S, **f64)
+            if self.strong:
+                self.local = torch.zeros(self.per_rank, **f64)
+                self.everything = torch.zeros(env.world * self.per_rank, **f64)
+        else:
+            from gpy_dla_detection_amd import parallel
+
+            self.uniforms = (torch.from_numpy(parallel.resampling_uniforms(nb, self.max_dlas, S, seed=0)).to(env.device)
+                             if self.max_dlas > 1 else None)
+            self.sample_ll = torch.empty((nb, self.max_dlas, S), **f64)
+            self.base = torch.zeros((nb, max(self.max_dlas - 1, 1), S), dtype=torch.int32, device=env.device)
+        return self
+
+    def step(self):
+        env, sl, torch, S, nb, config = self.env, self.sl, self.env.torch, self.S, self.nb, self.config
+        slot = self.counter % self.slots
+        self.counter += 1
+        stream = torch.cuda.current_stream().cuda_stream
+        if config == 2:
+            z, nhi = self.z, self.nhi_dla
+            if not self.strong:
+                self.devs[0].eval_device(S, 1, z.data_ptr(), nhi.data_ptr(), self.out.data_ptr(), stream)
+                target = self.out
+            else:  # this rank's slice, then all S log-likelihoods on every rank (S / N doubles per rank over RCCL)
+                lo, hi = self.lo, self.hi
+                self.devs[0].eval_device(hi - lo, 1, z.data_ptr() + 8 * lo, nhi.data_ptr() + 8 * lo,
+                                         self.local.data_ptr(), stream)
+                if env.dist_on:
+                    env.all_gather(self.everything, self.local)
+                else:
+                    self.everything.copy_(self.local)
+                target = self.everything
+            # "- log S" and the log-mean-exp model evidence of the level (reference dla_gp.py:155-190)
+            sl.level_evidence_device(target.data_ptr(), 1, S, 0, self.evidences.data_ptr() + 8 * slot,
+                                     device=env.local_rank, stream=stream)
+            return
+        ev = self.evidences.data_ptr() + 8 * slot * self.per_step
+        z, batch = self.z.data_ptr(), self.batch
+        if config == 5:
+            batch.sweep_device(S, 4, z, self.nhi_dla.data_ptr(), 0, MIN_Z_SEPARATION, self.uniforms.data_ptr(), ev,
+                               self.sample_ll.data_ptr(), self.base.data_ptr(), stream)
+            return
+        batch.sweep_device(S, 1, z, self.nhi_sub.data_ptr(), 0, MIN_Z_SEPARATION, 0, ev, self.sample_ll.data_ptr(), 0, stream)
+        batch.sweep_device(S, 1, z, self.nhi_dla.data_ptr(), 0, MIN_Z_SEPARATION, 0, ev + 8 * nb,
+                           self.sample_ll.data_ptr(), 0, stream)
+        if config == 4:  # NullGP.log_model_evidence of every member: one launch, host-pointer entry
+            self.evidences[slot * self.per_step + 2 * nb: slot * self.per_step + 3 * nb] = \
+                torch.from_numpy(batch.nulls()).to(env.device)
+
+    def exchange(self):
+        self.env.all_gather(self.gathered, self.evidences)
+
+    def gathered_matches(self) -> bool:
+        """every rank holds every rank's evidences after the exchange: rank r's slots must equal its own"""
+        torch = self.env.torch
+        mine = self.gathered.view(self.env.world, -1)[self.env.rank]
+        return bool(torch.equal(torch.nan_to_num(mine), torch.nan_to_num(self.evidences)))
+
+    def total_evals_per_step(self) -> float:
+        return float(self.S) if self.strong else self.evals_per_step * self.env.world
+
+    def close(self):
+        if self.batch is not None:
+            self.batch.close()
+        for dev in self.devs or []:
+            dev.close()
+        self.devs = self.batch = None
+        for name in ("z", "nhi_dla", "nhi_sub", "evidences", "gathered", "out", "local", "everything", "uniforms",
+                     "sample_ll", "base"):
+            if hasattr(self, name):
+                delattr(self, name)
+
+
+def timed_region(env, work, steps):
+    """
+    EXACTLY `steps` steps between two fences (synchronize + barrier + synchronize on both sides), the evidences
+    exchanged once inside it; returns (elapsed seconds of this rank, accumulate-kernel ms, accumulate launches).
+    """
+    sl = work.sl
+    env.fence()
+    work.counter = 0
+    sl.set_option("timing", 1)
+    sl.timing_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        work.step()
+    work.exchange()
+    env.fence()
+    elapsed = time.perf_counter() - t0
+    sl.set_option("timing", 0)
+    kernel_ms, launches = sl.timing_read(reset=True)
+    return elapsed, kernel_ms, launches
+
+
+def measure_side_config(env, config, steps, warmup, strong=False):
+    """
+    One of the other BASELINE configurations (or the by-sample split of configs[1]) at full size, measured after the
+    headline: `warmup` untimed steps (the first one builds the launch plan and the workspaces), then `steps` steps
+    under the headline's own timing rule.  Every rank reaches every collective whatever happens on another rank: a
+    failed set-up is agreed on (max-reduce of a flag) BEFORE any step runs, and reported instead of raised -- the
+    headline measurement above is already taken and must not be lost to a side measurement.
+    """
+    S, nb = NUM_SAMPLES, WORKLOADS[config]["sightlines"]
+    work, error = None, None
+    try:
+        work = Workload(env, config, S, nb, strong, slots=max(steps, warmup, 1)).upload()
+        for _ in range(warmup):
+            work.step()
+        env.torch.cuda.synchronize()
+    except Exception as exc:  # noqa: BLE001 -- reported in the line
+        error = "%s: %s" % (type(exc).__name__, exc)
+    failed = env.max_over_ranks([1.0 if error else 0.0])[0] > 0
+    result = {"workload": "configs[%d]%s: %s" % (WORKLOADS[config]["baseline_index"], " --strong" if strong else "",
+                                                "S/N samples of the one sightline per rank, one all-gather of the "
+                                                "log-likelihoods per step" if strong else WORKLOADS[config]["what"]),
+              "n_gpus": env.world, "steps": steps, "warmup": warmup}
+    if failed:
+        result["error"] = error or "set-up failed on another rank"
+    else:
+        elapsed, kernel_ms, launches = timed_region(env, work, steps)
+        elapsed, kernel_s = env.max_over_ranks([elapsed, kernel_ms / 1e3])
+        value = work.total_evals_per_step() * steps / elapsed
+        achieved = work.mfma_evals_per_step * steps * work.flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
+        result.update({
+            "ms_per_step": elapsed / steps * 1e3,
+            "evals_per_s": value,
+            "spectra_per_s": nb * env.world * steps / elapsed if config in (4, 5) else None,
+            "sightlines_per_gpu": nb if not strong else 1.0 / env.world,
+            "scaling": "strong" if strong else "weak",
+            "accumulate_ms_per_step": kernel_s * 1e3 / steps,
+            "accumulate_launches": launches,
+            "accumulate_tflops": achieved,
+            "accumulate_frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+            "evidence": float(work.evidences[0].item()),
+        })
+        if env.dist_on and not work.gathered_matches():
+            result["error"] = "rank %d: the gathered evidences differ from the local ones" % env.rank
+    if work is not None:
+        work.close()
+    del work
+    env.torch.cuda.empty_cache()
+    return result
+
+
+def main(argv=None) -> None:
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, argv))
+    config = args.config
     steps = args.steps if args.steps is not None else (200 if config == 2 else 5)
     warmup = args.warmup if args.warmup is not None else (20 if config == 2 else 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
-    # launched through torch.distributed.run: the process group and every collective below run even with one rank
-    # (a one-GPU box then exercises the RCCL calls of the N > 1 path); plain `python bench.py` has no group
-    dist_on = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-
-    from gpy_dla_detection_amd import sightline as sl
-    from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline
+    env = Env(args)
+    if env.world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, env.world))
+    world, rank = env.world, env.rank
 
     S = args.samples
     nb = args.sightlines or WORKLOADS[config]["sightlines"]
-    first = 0 if args.strong else rank * nb  # weak scaling: every rank has its own sightlines
-    sights = [make_sightline(first + i, n_unmasked=N_UNMASKED, n_masked=N_MASKED, k=RANK_K) for i in range(nb)]
-    z_host = np.stack([make_qmc_samples(s, S)[0] for s in sights])
-    nhi_dla_host = make_qmc_samples(sights[0], S)[2]
-    nhi_sub_host = make_qmc_samples(sights[0], S, sub_dla=True)[2]
+    work = Workload(env, config, S, nb, args.strong, slots=max(steps, warmup, 1))
+    sights = work.sights
 
     # the CPU baseline forks worker processes: do it before this process touches the GPU
     baseline = None
     if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
-        baseline = cpu_baseline(sights[0], baseline_sample(config, sights[0], z_host[0], nhi_dla_host, nhi_sub_host))
+        baseline = cpu_baseline(sights[0], baseline_sample(config, sights[0], work.z_host[0], work.nhi_dla_host,
+                                                           work.nhi_sub_host))
 
-    import torch
-    import torch.distributed as dist
-
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch --gpus %d through torch.distributed.run (one process per GPU)" % args.gpus)
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if dist_on:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
-
-    devs = [sl.DeviceSightline.from_state(s, device=local_rank) for s in sights]
-    batch = sl.DeviceBatch(devs) if config != 2 else None
+    env.start()
+    torch, dist, sl = env.torch, env.dist, work.sl
+    work.upload()
     if args.splits:
         sl.set_option("pixel_splits", args.splits)
     if args.debug:
@@ -260,82 +644,7 @@ def main() -> None:
     for item in args.option:
         name, value = item.split("=")
         sl.set_option(name, int(value))
-
-    f64 = dict(dtype=torch.float64, device=device)
-    z = torch.from_numpy(z_host).to(device)
-    nhi_dla = torch.from_numpy(nhi_dla_host).to(device)
-    nhi_sub = torch.from_numpy(nhi_sub_host).to(device)
-    max_dlas = 4 if config == 5 else 1
-    # Every step's evidences land in their own slot; the ranks exchange them with ONE all-gather at the end of the
-    # timed region -- the communication pattern of a sharded catalogue run (parallel.model_evidences_sharded).
-    per_step = {2: 1, 3: 2 * nb, 4: 3 * nb, 5: 4 * nb}[config]
-    slots = max(steps, warmup, 1)
-    evidences = torch.zeros(slots * per_step, **f64)
-    gathered = torch.zeros(world * slots * per_step, **f64) if dist_on else None
-    counter = [0]
-
-    if config == 2:
-        lo, hi = (0, S)
-        if args.strong:
-            per_rank = -(-S // world)
-            lo, hi = min(rank * per_rank, S), min((rank + 1) * per_rank, S)
-            local = torch.zeros(per_rank, **f64)
-            everything = torch.zeros(world * per_rank, **f64)
-        out = torch.empty(S, **f64)
-        nhi_col = nhi_dla.contiguous()
-
-        def step():
-            slot = counter[0] % slots
-            counter[0] += 1
-            stream = torch.cuda.current_stream().cuda_stream
-            if not args.strong:
-                devs[0].eval_device(S, 1, z.data_ptr(), nhi_col.data_ptr(), out.data_ptr(), stream)
-                target = out
-            else:  # this rank's slice, then all S log-likelihoods on every rank (S / N doubles per rank over RCCL)
-                devs[0].eval_device(hi - lo, 1, z.data_ptr() + 8 * lo, nhi_col.data_ptr() + 8 * lo, local.data_ptr(), stream)
-                if dist_on and args.rehearse_on_one_gpu:
-                    dist.all_gather(list(everything.view(world, -1).unbind(0)), local)
-                elif dist_on:
-                    dist.all_gather_into_tensor(everything, local)
-                else:
-                    everything.copy_(local)
-                target = everything
-            # "- log S" and the log-mean-exp model evidence of the level (reference dla_gp.py:155-190)
-            sl.level_evidence_device(target.data_ptr(), 1, S, 0, evidences.data_ptr() + 8 * slot, device=local_rank,
-                                     stream=stream)
-    else:
-        from gpy_dla_detection_amd import parallel
-
-        uniforms = torch.from_numpy(parallel.resampling_uniforms(nb, max_dlas, S, seed=0)).to(device) if max_dlas > 1 else None
-        sample_ll = torch.empty((nb, max_dlas, S), **f64)
-        base = torch.zeros((nb, max(max_dlas - 1, 1), S), dtype=torch.int32, device=device)
-
-        def step():
-            slot = counter[0] % slots
-            counter[0] += 1
-            stream = torch.cuda.current_stream().cuda_stream
-            ev = evidences.data_ptr() + 8 * slot * per_step
-            if config == 5:
-                batch.sweep_device(S, 4, z.data_ptr(), nhi_dla.data_ptr(), 0, MIN_Z_SEPARATION, uniforms.data_ptr(), ev,
-                                   sample_ll.data_ptr(), base.data_ptr(), stream)
-                return
-            batch.sweep_device(S, 1, z.data_ptr(), nhi_sub.data_ptr(), 0, MIN_Z_SEPARATION, 0, ev, sample_ll.data_ptr(), 0, stream)
-            batch.sweep_device(S, 1, z.data_ptr(), nhi_dla.data_ptr(), 0, MIN_Z_SEPARATION, 0, ev + 8 * nb,
-                               sample_ll.data_ptr(), 0, stream)
-            if config == 4:  # NullGP.log_model_evidence of every member: one launch, host-pointer entry
-                evidences[slot * per_step + 2 * nb: slot * per_step + 3 * nb] = torch.from_numpy(batch.nulls()).to(device)
-
-    def exchange():
-        if dist_on and args.rehearse_on_one_gpu:  # gloo has no all_gather_into_tensor for device tensors
-            dist.all_gather(list(gathered.view(world, -1).unbind(0)), evidences)
-        elif dist_on:
-            dist.all_gather_into_tensor(gathered, evidences)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
+    step = work.step
 
     def timed(count):
         sl.set_option("timing", 1)
@@ -349,10 +658,7 @@ def main() -> None:
         kernel_ms, launches = sl.timing_read(reset=True)
         return elapsed, kernel_ms, launches
 
-    flops = algorithmic_flops_per_eval(sights[0].n, sights[0].k)
-    evals_per_step = {2: float(hi - lo) if config == 2 and args.strong else float(S), 3: 2.0 * nb * S,
-                      4: nb * (1.0 + 2 * S), 5: 4.0 * nb * S}[config]
-    mfma_evals_per_step = {2: evals_per_step, 3: 2.0 * nb * S, 4: 2.0 * nb * S, 5: 4.0 * nb * S}[config]
+    flops = work.flops
 
     # Cold figure: the device leaves its idle power state only after tens of milliseconds of load, so the first ~40
     # launches after idle run ~12 % slower than the sustained rate.  One untimed step creates the launch plan and
@@ -369,7 +675,7 @@ def main() -> None:
     # Untimed steps until the device has been busy for --ramp-ms, then the W warmup steps the contract asks for, then
     # exactly K timed steps.  (local work only when not --strong -- the loop is time-based, so ranks may run different
     # numbers of iterations; --strong communicates per step, so there the ramp is a fixed number of steps)
-    if args.strong and dist_on:
+    if args.strong and env.dist_on:
         for _ in range(60):
             step()
         torch.cuda.synchronize()
@@ -381,36 +687,34 @@ def main() -> None:
             torch.cuda.synchronize()
     for _ in range(warmup):
         step()
-    exchange()
-    fence()
-    counter[0] = 0
-    sl.set_option("timing", 1)
-    sl.timing_read(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    exchange()
-    fence()
-    elapsed = time.perf_counter() - t0
-    sl.set_option("timing", 0)
-    kernel_ms, launches = sl.timing_read(reset=True)
+    work.exchange()
+    elapsed, kernel_ms, launches = timed_region(env, work, steps)
     if args.debug & 2:
         st = sl.debug_read()
         if rank == 0 and st[5]:
             names = ["voigt", "conv", "mfma_loop", "epilogue", "passes+epilogue", None, "prologue"]
             print("stamps: waves=%d  " % st[5] + "  ".join("%s=%.0f" % (n, st[i] / st[5]) for i, n in enumerate(names) if n) + "  (cycles per wave)", file=sys.stderr)
 
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # every rank holds every rank's evidences after the exchange: rank r's slots must equal its own
-        mine = gathered.view(world, -1)[rank]
-        if not torch.equal(torch.nan_to_num(mine), torch.nan_to_num(evidences)):
+    if env.dist_on:
+        elapsed = env.max_over_ranks([elapsed])[0]
+        if not work.gathered_matches():
             raise SystemExit("rank %d: the gathered evidences differ from the local ones" % rank)
+    evidence = float(work.evidences[0].item())
+    evals_per_step, mfma_evals_per_step = work.evals_per_step, work.mfma_evals_per_step
+    total_evals = work.total_evals_per_step() * steps
+    n_pixels, rank_k = sights[0].n, sights[0].k
+    work.close()
+
+    # The other BASELINE configurations at their one-GPU widths and the by-sample split of configs[1], measured after
+    # the headline (whose figures above are final by now) so that the driver's one run carries them too: one warm-up
+    # step + two timed steps each (config 3: 36 ms, config 4: 73 ms, config 5: 38 ms per step).
+    others = None
+    if (config == 2 and not args.strong and not args.no_other_configs and S == NUM_SAMPLES and not args.sightlines
+            and not args.splits and not args.option and not args.debug):
+        others = {str(c): measure_side_config(env, c, steps=2, warmup=1) for c in (3, 4, 5)}
+        strong = measure_side_config(env, 2, steps=50, warmup=10, strong=True)
 
     if rank == 0:
-        total_evals = (float(S) if args.strong else evals_per_step * world) * steps
         value = total_evals / elapsed
         kernel_s_total = kernel_ms / 1e3
         # timed accumulate launches of this rank: all MFMA-path launches of the step (config 4's null launch is the
@@ -432,8 +736,8 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": "configs[%d] (SURVEY 8d config %d): %s; S=%d QMC samples, n=%d pixels (n_u=%d), rank k=%d, 3 Lyman lines"
-                            % (WORKLOADS[config]["baseline_index"], config, WORKLOADS[config]["what"], S, sights[0].n,
-                               N_UNMASKED, sights[0].k),
+                            % (WORKLOADS[config]["baseline_index"], config, WORKLOADS[config]["what"], S, n_pixels,
+                               N_UNMASKED, rank_k),
                 "sightlines_per_gpu": nb if not args.strong else 1.0 / world,
                 "samples_per_sightline": S,
                 "evals_per_step_per_gpu": evals_per_step,
@@ -457,13 +761,16 @@ def main() -> None:
                 "kernel_launches": launches,
                 "flop_per_eval": flops,
             },
-            "evidence": float(evidences[0].item()),
+            "evidence": evidence,
         }
+        if others is not None:
+            line["other_configs"] = others
+            line["strong_n%d" % world] = strong
         if baseline is not None:
             line["cpu_baseline"] = baseline
         print(json.dumps(line), flush=True)
 
-    if dist_on:
+    if env.dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

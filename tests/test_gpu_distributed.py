@@ -72,6 +72,45 @@ def test_two_ranks_on_one_gpu_rehearse_the_exchanges():
     assert abs(strong["evidence"] - plain["evidence"]) <= 1e-11 * abs(plain["evidence"])
 
 
+def test_plain_bench_invocation_launches_its_own_ranks():
+    """
+    `python bench.py --gpus 2` with NO launcher around it (how the driver has invoked bench.py so far): the parent
+    starts torch.distributed.run itself as a child, before it touches the GPU, and relays rank 0's one line.
+    """
+    small = ["--steps", "3", "--warmup", "1", "--ramp-ms", "5", "--samples", "2000", "--rehearse-on-one-gpu"]
+    plain = run_bench(0, "--gpus", "1", *small[:-1])
+    own = run_bench(0, "--gpus", "2", *small)
+    assert own["n_gpus"] == 2 and own["steps"] == 3 and own["value"] > 0
+    assert own["config"]["evals_per_step_per_gpu"] == 2000.0 and own["evidence"] == plain["evidence"]
+    strong = run_bench(0, "--gpus", "2", "--strong", *small)
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong"
+
+
+def test_default_line_carries_the_other_configurations():
+    """
+    The default run (BASELINE configs[1]) also measures configs[2..4] at their one-GPU widths and the by-sample split,
+    after the headline: each entry reproduces the evidence of its own `--config N` run, none reports an error.
+    """
+    line = run_bench(0, "--gpus", "1", "--steps", "20", "--warmup", "5")
+    assert line["config"]["workload"].startswith("configs[1]") and line["roofline"]["kernel_launches"] == 20
+    others = line["other_configs"]
+    assert sorted(others) == ["3", "4", "5"]
+    for key, entry in others.items():
+        assert "error" not in entry, entry
+        assert entry["ms_per_step"] > 0 and entry["evals_per_s"] > 1e6 and 0.2 < entry["accumulate_frac"] < 1.0
+        alone = run_bench(0, "--gpus", "1", "--config", key, "--steps", "1", "--warmup", "1", "--ramp-ms", "5")
+        assert entry["evidence"] == alone["evidence"]
+    assert others["4"]["spectra_per_s"] > 0 and others["5"]["spectra_per_s"] > 0 and others["3"]["spectra_per_s"] is None
+    strong = line["strong_n1"]
+    assert "error" not in strong and strong["scaling"] == "strong" and strong["evidence"] == line["evidence"]
+    # two ranks on the one card: the side measurements run their collectives on every rank
+    two = run_bench(0, "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "5", "--warmup", "2", timeout=1100)
+    assert two["n_gpus"] == 2 and sorted(two["other_configs"]) == ["3", "4", "5"]
+    for entry in list(two["other_configs"].values()) + [two["strong_n2"]]:
+        assert "error" not in entry and entry["n_gpus"] == 2
+    assert two["other_configs"]["4"]["sightlines_per_gpu"] == 128
+
+
 WORKER = r"""
 import os, sys
 import numpy as np
