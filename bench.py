@@ -322,6 +322,7 @@ def parse_args(argv=None):
     ap.add_argument("--sightlines", type=int, default=0, help=argparse.SUPPRESS)  # tuning: override the batch width
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-other-configs", action="store_true", help=argparse.SUPPRESS)  # headline measurement only
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)  # print that object and leave
     ap.add_argument("--splits", type=int, default=0, help=argparse.SUPPRESS)  # tuning: force the pixel-split count
     ap.add_argument("--option", action="append", default=[], help=argparse.SUPPRESS)  # tuning: library option name=value
     ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)  # 2: per-phase cycle stamps (diagnostic)
@@ -571,6 +572,17 @@ def measure_side_config(env, config, steps, warmup, strong=False):
     work, error = None, None
     try:
         work = Workload(env, config, S, nb, strong, slots=max(steps, warmup, 1)).upload()
+        # the device idled while this workload was built: the same untimed clock ramp as in front of the headline
+        # (time-based on local work; --strong communicates per step, so there a fixed number of steps)
+        if strong and env.dist_on:
+            for _ in range(300):
+                work.step()
+        else:
+            ramp_start = time.perf_counter()
+            while (time.perf_counter() - ramp_start) * 1e3 < env.args.ramp_ms:
+                for _ in range(10 if config == 2 else 1):
+                    work.step()
+                env.torch.cuda.synchronize()
         for _ in range(warmup):
             work.step()
         env.torch.cuda.synchronize()
@@ -634,6 +646,9 @@ def main(argv=None) -> None:
         baseline = cpu_baseline(sights[0], baseline_sample(config, sights[0], work.z_host[0], work.nhi_dla_host,
                                                            work.nhi_sub_host))
 
+    if args.cpu_baseline_only:
+        print(json.dumps(baseline), flush=True)
+        return
     env.start()
     torch, dist, sl = env.torch, env.dist, work.sl
     work.upload()
@@ -706,13 +721,13 @@ def main(argv=None) -> None:
     work.close()
 
     # The other BASELINE configurations at their one-GPU widths and the by-sample split of configs[1], measured after
-    # the headline (whose figures above are final by now) so that the driver's one run carries them too: one warm-up
-    # step + two timed steps each (config 3: 36 ms, config 4: 73 ms, config 5: 38 ms per step).
+    # the headline (whose figures above are final by now) so that the driver's one run carries them too: clock ramp, one
+    # warm-up step and three timed steps each (config 3: 36 ms, config 4: 73 ms, config 5: 38 ms per step).
     others = None
     if (config == 2 and not args.strong and not args.no_other_configs and S == NUM_SAMPLES and not args.sightlines
             and not args.splits and not args.option and not args.debug):
-        others = {str(c): measure_side_config(env, c, steps=2, warmup=1) for c in (3, 4, 5)}
-        strong = measure_side_config(env, 2, steps=50, warmup=10, strong=True)
+        others = {str(c): measure_side_config(env, c, steps=3, warmup=1) for c in (3, 4, 5)}
+        strong = measure_side_config(env, 2, steps=100, warmup=20, strong=True)
 
     if rank == 0:
         value = total_evals / elapsed

@@ -62,6 +62,10 @@ SIGNATURES = {
     "dlagp_level_evidence_device": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "dlagp_set_option": (c_int, [c_char_p, c_int64]),
     "dlagp_plan_cut": (c_int, [c_int64, c_double, c_int64, POINTER(c_int), _dp]),
+    "dlagp_plan_debug": (c_int, [c_int, POINTER(c_int), POINTER(POINTER(ctypes.c_ubyte)), c_int, c_int64,
+                                 POINTER(c_int64), POINTER(c_int64), POINTER(ctypes.c_int32), POINTER(ctypes.c_int32),
+                                 c_int64, POINTER(ctypes.c_int32), c_int64, POINTER(ctypes.c_int32), c_int64,
+                                 POINTER(ctypes.c_ubyte), c_int64]),
     "dlagp_get_option": (c_int, [c_char_p, POINTER(c_int64)]),
     "dlagp_timing_read": (c_int, [_dp, POINTER(c_int64), c_int]),
     "dlagp_debug_voigt": (c_int, [c_int, c_int, c_int64, _dp, _dp, c_int]),

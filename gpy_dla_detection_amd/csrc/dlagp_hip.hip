@@ -420,151 +420,16 @@ struct dlagp_batch {
 static std::mutex g_membership_mutex;
 
 // ------------------------------------------------------------------------------------------------
-// planning (MFMA path)
-//   slots   the kept pixels in order, padded so that every chunk of 8 slots has its convolution windows inside
-//           64 consecutive entries (a mask gap of more than ~50 pixels closes the chunk with zero-weight slots)
-//   passes  runs of <= 7 chunks whose windows fit in 64 consecutive entries (kernels_mfma.h)
-//   items   one wave each: 16 samples x a range of chunks of one sightline
+// planning (MFMA path): plan_host.h -- pure host code, also built alone under ASan/UBSan and fuzzed on the CPU
 // ------------------------------------------------------------------------------------------------
-static void plan_slots(const std::vector<int> &pos, int n, int ntaps, std::vector<int> &slot_pixel,
-                       std::vector<int> &slot_pos) {
-    slot_pixel.clear();
-    slot_pos.clear();
-    int i = 0;
-    while (i < n) {
-        const int first = pos[i];
-        int filled = 0;
-        while (i < n && filled < DLAGP_CHUNK_PIXELS && pos[i] + ntaps <= first + DLAGP_PASS_ENTRIES) {
-            slot_pixel.push_back(i);
-            slot_pos.push_back(pos[i]);
-            ++i;
-            ++filled;
-        }
-        for (; filled < DLAGP_CHUNK_PIXELS; ++filled) {  // zero-weight slots: they re-read the last pixel's window
-            slot_pixel.push_back(-1);
-            slot_pos.push_back(slot_pos.back());
-        }
-    }
-}
-
-// passes of the chunk range [c0, c1) of one sightline, appended to `passes`
-static void plan_passes(const std::vector<int> &slot_pos, int ntaps, int c0, int c1, std::vector<PassDesc> &passes) {
-    int c = c0;
-    while (c < c1) {
-        PassDesc pd{slot_pos[c * DLAGP_CHUNK_PIXELS], c, 1, 0};  // a single chunk always fits (plan_slots)
-        while (c + pd.nchunks < c1 && pd.nchunks < DLAGP_MAX_PASS_CHUNKS &&
-               slot_pos[(c + pd.nchunks) * DLAGP_CHUNK_PIXELS + DLAGP_CHUNK_PIXELS - 1] + ntaps <=
-                   pd.entry_start + DLAGP_PASS_ENTRIES)
-            ++pd.nchunks;
-        passes.push_back(pd);
-        c += pd.nchunks;
-    }
-}
-
-// Work items of one launch.  A wave owns 16 samples ("group") of one sightline over a range of its chunks; the
-// chip holds 2048 such waves at a time (256 CUs x 4 SIMDs x 2, register-limited), and a SIMD's FP64 pipe is
-// busy for the sum of its waves' work.  Every group of a sightline is cut at the SAME chunk positions: the waves
-// then sweep the sightline's operand Pm (6 MB, more than one XCD's L2) as a few coherent fronts that stay
-// L2-resident -- cutting the (group, chunk) space into 2048 equal intervals balances perfectly but puts every wave
-// at a different position and came out 10 % slower (profiles/r02_work_decomposition.txt).  Two shapes of cut are
-// priced with a simple model (time of the busiest wave slot, in chunks; `o` = fixed cost of an item) and the
-// cheaper one is taken:
-//   (A) h equal pieces per group, h = 1..8:            ceil(groups h / 2048) (C / h + o)   [+ finalisation, ~ groups h]
-//   (B) f = floor(2048 / groups) full pieces of F chunks plus a remainder piece R = C - f F; the 2048 - f groups
-//       slots left over work through the remainder pieces, m = ceil(groups / slots left) each:
-//                                                        F + o = m (R + o)
-//       One sightline x 10 000 samples = 625 groups: (A) h = 3 leaves 173 of the 2048 slots empty (129 chunks per
-//       slot); (B) f = 3, F = 117, R = 24 fills them (122).
-// Items are dispatched in index order as slots free up: full pieces first, then the remainders; the order affects
-// only the balance, never the results.  Every block of 16 samples adds its pieces' partial sums in piece order
-// (finalize kernels, `counts`), so results are deterministic.  Option pixel_splits = h forces (A) with that h.
-// Modelled time of one work item, in units of one chunk's weights + MFMA work (measured with the per-wave trace of
-// tools/wave_timeline.py: 7.2 us per item + 6.6 us per pass + 1.3 us per chunk): the Voigt profiles, the convolution
-// and the set-up of a pass cost the same whether the pass holds 7 chunks or 1.
-static double item_cost(const std::vector<int> &slot_pos, int ntaps, int c0, int c1) {
-    if (c1 <= c0) return 0.0;
-    std::vector<PassDesc> passes;
-    plan_passes(slot_pos, ntaps, c0, c1, passes);
-    constexpr double per8 = 8.0 / DLAGP_CHUNK_PIXELS;  // the constants below were measured per 8 slots
-    return per8 * (0.1 * (double)g_opt_plan_item_cost + 5.1 * (double)passes.size()) + (double)(c1 - c0);
-}
-
-// Moves the cuts of one sightline (edge[0] = 0 < edge[1] < ... < edge[last] = chunks) by up to 24 chunks each so that
-// the busiest wave slot gets as little as possible: in practice onto pass boundaries, so that no piece pays the
-// fixed cost of a pass for a handful of chunks.  The last piece is the remainder when `remainder`; a left-over
-// slot works through `rest_per_slot` of those.
-static void refine_cuts(const std::vector<int> &slot_pos, int ntaps, std::vector<int> &edge, bool remainder,
-                        long rest_per_slot) {
-    const int npieces = (int)edge.size() - 1;
-    if (npieces < 2) return;
-    auto piece_cost = [&](int j) {
-        const double c = item_cost(slot_pos, ntaps, edge[j], edge[j + 1]);
-        return remainder && j == npieces - 1 ? c * (double)rest_per_slot : c;
-    };
-    std::vector<double> cost(npieces);
-    for (int j = 0; j < npieces; ++j) cost[j] = piece_cost(j);
-    for (int round = 0; round < 3; ++round) {
-        bool moved = false;
-        for (int j = 1; j < npieces; ++j) {  // cut between pieces j - 1 and j
-            const int at = edge[j];
-            int best_at = at;
-            double best = std::max(cost[j - 1], cost[j]), best_sum = cost[j - 1] + cost[j];
-            for (int d = -24; d <= 24; ++d) {
-                const int cand = at + d;
-                if (d == 0 || cand <= edge[j - 1] || cand >= edge[j + 1]) continue;
-                edge[j] = cand;
-                const double a = piece_cost(j - 1), bb = piece_cost(j);
-                const double worst = std::max(a, bb);
-                if (worst < best - 1e-9 || (worst < best + 1e-9 && a + bb < best_sum - 1e-9)) {
-                    best = worst;
-                    best_sum = a + bb;
-                    best_at = cand;
-                }
-            }
-            edge[j] = best_at;
-            if (best_at != at) {
-                moved = true;
-                cost[j - 1] = piece_cost(j - 1);
-                cost[j] = piece_cost(j);
-            }
-        }
-        if (!moved) break;
-    }
-}
-
-// the cut, as fractions of a sightline's chunks: `full` pieces of `frac` each, then a remainder if frac * full < 1
-static void choose_cut(long groups, double C, int64_t forced, int *full_out, double *frac_out) {
-    const long slots = g_opt_plan_slots;
-    // prologue + epilogue of an item, and the pass it adds by starting a new one, in chunks' worth of work
-    const double o = 0.1 * (double)g_opt_plan_item_cost * 8.0 / DLAGP_CHUNK_PIXELS;
-    // every piece of a block is one more set of partial sums the finalisation reads: ~25 ns per (block, piece) in a
-    // large launch, in units of a wave slot's time per chunk (4.9 us per 8 slots)
-    const double finalize_per_piece = 0.005 * 8.0 / DLAGP_CHUNK_PIXELS;
-    int full = 1;
-    double frac = 1.0, best = 1e300;
-    const int h_max = (int)std::max(1.0, std::min(8.0, std::floor(C / DLAGP_MAX_PASS_CHUNKS)));
-    for (int h = 1; h <= h_max; ++h) {
-        if (forced > 0 && h != std::min<int64_t>(forced, h_max)) continue;
-        const double cost = (double)((groups * h + slots - 1) / slots) * (C / h + o) + finalize_per_piece * groups * h;
-        if (cost < best) {
-            best = cost;
-            full = h;
-            frac = 1.0 / h;
-        }
-    }
-    // at most 254 full pieces + the remainder: the finalize kernels count a block's pieces in a byte (`counts`)
-    const long f = std::min<long>(slots / std::max<long>(groups, 1), 254);
-    if (forced <= 0 && f >= 1 && slots - f * groups > 0) {
-        const long m = (groups + (slots - f * groups) - 1) / (slots - f * groups);
-        const double F = (m * (C + o) - o) / (1.0 + (double)m * f);
-        const double R = C - f * F;
-        if (R >= DLAGP_MAX_PASS_CHUNKS && F + o + finalize_per_piece * groups * (f + 1) < best) {
-            full = (int)f;
-            frac = F / C;
-        }
-    }
-    *full_out = full;
-    *frac_out = frac;
+static plan::Options planner_options() {
+    plan::Options opt;
+    opt.pixel_splits = g_opt_pixel_splits;
+    opt.item_cost = g_opt_plan_item_cost;
+    opt.rest_first = g_opt_plan_rest_first;
+    opt.slots = g_opt_plan_slots;
+    opt.xcd_affine = g_opt_plan_xcd_affine;
+    return opt;
 }
 
 static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
@@ -575,76 +440,13 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
         *out = it->second.get();
         return DLAGP_OK;
     }
-    const int nb = (int)g.ctxs.size();
-    const long ngroups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
-    const long groups = (long)nb * ngroups;
-    std::vector<long> chunks(nb);
-    double mean_chunks = 0.0;
-    for (int b = 0; b < nb; ++b) {
-        chunks[b] = g.ctxs[b]->sl.n_slots / DLAGP_CHUNK_PIXELS;
-        mean_chunks += (double)chunks[b] / nb;
-    }
-    int full = 1;
-    double frac = 1.0;
-    choose_cut(groups, mean_chunks, g_opt_pixel_splits, &full, &frac);
-    struct Piece {
-        int b, group, part, pass_begin, pass_end;
-        bool rest;
-    };
-    std::vector<Piece> pieces;
-    pieces.reserve((size_t)groups * (full + 1));
-    std::vector<PassDesc> passes;
-    const bool remainder = frac * full < 1.0 - 1e-9;
-    std::vector<unsigned char> counts((size_t)groups, 1);
-    int max_parts = 1;
-    // remainder items a left-over wave slot works through (shape (B)); 1 otherwise
-    const long slots_total = g_opt_plan_slots, left = slots_total - (long)full * groups;
-    const long rest_per_slot = remainder && left > 0 ? (groups + left - 1) / left : 1;
-    for (int b = 0; b < nb; ++b) {
-        // cut positions of sightline b (the same for all of its groups); empty pieces are dropped
-        const int npieces = full + (remainder ? 1 : 0);
-        std::vector<int> edge(npieces + 1, (int)chunks[b]);
-        edge[0] = 0;
-        for (int j = 1; j < npieces; ++j) edge[j] = (int)std::min<long>(chunks[b], std::llround(j * frac * chunks[b]));
-        refine_cuts(g.ctxs[b]->h_slot_pos, g.ctxs[b]->sl.ntaps, edge, remainder, rest_per_slot);
-        std::vector<Piece> cuts;
-        for (int j = 0; j < npieces; ++j)
-            if (edge[j + 1] > edge[j]) {
-                const int begin = (int)passes.size();  // the pass list of a piece is shared by all groups
-                plan_passes(g.ctxs[b]->h_slot_pos, g.ctxs[b]->sl.ntaps, edge[j], edge[j + 1], passes);
-                cuts.push_back({b, 0, (int)cuts.size(), begin, (int)passes.size(), remainder && j == npieces - 1});
-            }
-        if (cuts.size() > 255) return fail(DLAGP_EINVAL, "internal: %zu pieces per block exceed the byte-sized piece count", cuts.size());
-        max_parts = std::max(max_parts, (int)cuts.size());
-        for (long grp = 0; grp < ngroups; ++grp) {
-            counts[b * ngroups + grp] = (unsigned char)cuts.size();
-            for (Piece pc : cuts) {
-                pc.group = (int)grp;
-                pieces.push_back(pc);
-            }
-        }
-    }
-    // dispatch order: the full pieces in (sightline, group, piece) order, then the remainders
-    const bool rest_first = g_opt_plan_rest_first != 0;
-    if (remainder) std::stable_partition(pieces.begin(), pieces.end(), [=](const Piece &x) { return x.rest == rest_first; });
-    // XCD affinity (batches, one piece per block): workgroups are dealt round-robin over the 8 XCDs (observed, for speed
-    // only), each with its own 4 MB L2, and a sightline's MFMA operand is 6 MB.  In (sightline, group) order every XCD
-    // has waves of the ~3 sightlines that are in flight at a time; dealt so that workgroup i works on a sightline
-    // b = i (mod 8), every XCD sweeps ONE sightline's operand with all of its waves.  Option "plan_xcd_affine".
-    if (g_opt_plan_xcd_affine != 0 && !remainder && full == 1 && nb >= 8) {
-        std::vector<Piece> dealt;
-        dealt.reserve(pieces.size());
-        // pieces are in (b, group) order, ngroups each: rounds of 8 sightlines, inside a round group-major
-        for (int b0 = 0; b0 < nb; b0 += 8) {
-            const int width = std::min(8, nb - b0);
-            for (long grp = 0; grp < ngroups; ++grp)
-                for (int x = 0; x < width; ++x) dealt.push_back(pieces[(size_t)(b0 + x) * ngroups + grp]);
-        }
-        pieces.swap(dealt);
-    }
-    std::vector<WorkItem> items;
-    items.reserve(pieces.size());
-    for (const Piece &pc : pieces) items.push_back(WorkItem{pc.b, pc.group, pc.part, pc.pass_begin, pc.pass_end, 0, 0, 0});
+    std::vector<plan::Sightline> members;
+    members.reserve(g.ctxs.size());
+    for (const dlagp_ctx *c : g.ctxs)
+        members.push_back(plan::Sightline{&c->h_slot_pos, c->sl.ntaps, (long)(c->sl.n_slots / DLAGP_CHUNK_PIXELS)});
+    plan::HostPlan host;
+    std::string err;
+    if (plan::build(members, S, planner_options(), host, err)) return fail(DLAGP_EINVAL, "%s", err.c_str());
     // One plan per distinct (S, planner options): a by-sample run adds one per slice size, a tuning session one per
     // option set.  Beyond kMaxPlans the cache starts over -- after draining the group's stream, since a launch in
     // flight still reads its plan.
@@ -658,16 +460,16 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
         g.plans.clear();
     }
     std::unique_ptr<LaunchPlan> plan(new LaunchPlan());
-    int rc = plan->passes.reserve(std::max<size_t>(1, passes.size()) * sizeof(PassDesc));
-    if (!rc) rc = plan->items.reserve(std::max<size_t>(1, items.size()) * sizeof(WorkItem));
-    if (!rc) rc = plan->counts.reserve(std::max<size_t>(1, counts.size()));
+    int rc = plan->passes.reserve(std::max<size_t>(1, host.passes.size()) * sizeof(PassDesc));
+    if (!rc) rc = plan->items.reserve(std::max<size_t>(1, host.items.size()) * sizeof(WorkItem));
+    if (!rc) rc = plan->counts.reserve(std::max<size_t>(1, host.counts.size()));
     if (rc) return rc;
     // planning runs on the launching thread, ahead of the launch on the caller's stream: blocking copies
-    HIP_TRY(hipMemcpy(plan->passes.ptr, passes.data(), passes.size() * sizeof(PassDesc), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(plan->items.ptr, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(plan->counts.ptr, counts.data(), counts.size(), hipMemcpyHostToDevice));
-    plan->nitems = (int)items.size();
-    plan->max_parts = max_parts;
+    HIP_TRY(hipMemcpy(plan->passes.ptr, host.passes.data(), host.passes.size() * sizeof(PassDesc), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(plan->items.ptr, host.items.data(), host.items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(plan->counts.ptr, host.counts.data(), host.counts.size(), hipMemcpyHostToDevice));
+    plan->nitems = (int)host.items.size();
+    plan->max_parts = host.max_parts;
     *out = plan.get();
     g.plans[key] = std::move(plan);
     return DLAGP_OK;
@@ -1301,7 +1103,7 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     ctx->mfma_ok = k_eff == DLAGP_MFMA_RANK;
     if (ctx->mfma_ok) {
         std::vector<int> real_pos(hpos.begin(), hpos.begin() + n);
-        plan_slots(real_pos, n, sl.ntaps, slot_pixel, ctx->h_slot_pos);
+        plan::plan_slots(real_pos, n, sl.ntaps, slot_pixel, ctx->h_slot_pos);
     }
     sl.n_slots = (int)slot_pixel.size();
     sl.nsteps_m = sl.n_slots / DLAGP_STEP_PIXELS;
@@ -2053,8 +1855,19 @@ int dlagp_set_option(const char *name, int64_t value) {
 
 int dlagp_plan_cut(int64_t groups, double chunks, int64_t forced_splits, int *full, double *frac) {
     if (!full || !frac || groups < 1 || !(chunks >= 1.0)) return fail(DLAGP_EINVAL, "bad argument");
-    choose_cut((long)groups, chunks, forced_splits, full, frac);
+    plan::Options opt = planner_options();
+    opt.pixel_splits = forced_splits;
+    plan::choose_cut((long)groups, chunks, opt, full, frac);
     return DLAGP_OK;
+}
+
+int dlagp_plan_debug(int nb, const int *n_u, const uint8_t *const *keep, int ntaps, int64_t S, const int64_t *options,
+                     int64_t *summary, int32_t *slot_pixel, int32_t *slot_pos, int64_t slots_cap, int32_t *passes,
+                     int64_t passes_cap, int32_t *items, int64_t items_cap, uint8_t *counts, int64_t counts_cap) {
+    std::string err;
+    const int rc = plan::debug(nb, n_u, keep, ntaps, S, options, summary, slot_pixel, slot_pos, slots_cap, passes,
+                               passes_cap, items, items_cap, counts, counts_cap, err);
+    return rc ? fail(rc, "%s", err.c_str()) : DLAGP_OK;
 }
 
 int dlagp_get_option(const char *name, int64_t *value) {

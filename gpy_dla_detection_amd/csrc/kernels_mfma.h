@@ -38,6 +38,7 @@
 #include "dlagp_device.h"
 #include "fastmath_device.h"
 #include "kernels_common.h"
+#include "plan_host.h"
 #include "voigt_device.h"
 
 namespace dlagp {
@@ -47,35 +48,14 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define DLAGP_MFMA_RANK 20
 #define DLAGP_MFMA_NTW DLAGP_MFMA_W_TILES    // 13 full tiles weighted by w
 #define DLAGP_MFMA_NT DLAGP_MFMA_BIG_TILES   // 14 full tiles; two 4x4x4 MFMAs carry the remaining 2 + 4 columns
-#define DLAGP_MFMA_GROUP 16      // samples per wave / workgroup
 #define DLAGP_MFMA_THREADS 64
-#define DLAGP_PASS_ENTRIES 64
 #define DLAGP_RAW_STRIDE 67      // doubles per sample row in LDS; odd -> conflict-free ds_read2_b64 windows
-#ifndef DLAGP_CHUNK_PIXELS
-// planning granule ("chunk") = two steps.  One step (4) was tried: the same number of passes on the bench workload,
-// 1 % slower (profiles/r02_work_decomposition.txt)
-#define DLAGP_CHUNK_PIXELS 8
-#endif
-#define DLAGP_MAX_PASS_STEPS 14  // 56 pixels
-#define DLAGP_CHUNK_STEPS (DLAGP_CHUNK_PIXELS / DLAGP_STEP_PIXELS)
-#define DLAGP_MAX_PASS_CHUNKS (DLAGP_MAX_PASS_STEPS / DLAGP_CHUNK_STEPS)
 #define DLAGP_AUX_FIELDS 8       // per-pixel record: y, mu, omega2, v, window start, 3 spare
 #define DLAGP_BUFFER_FLAGS 0x00020000  // word 3 of a raw buffer resource on gfx9-family targets
 #define DLAGP_LAUNCH_KEEP_STATUS 0x10000   // launch_flags: do not clear the non-PD flag (see accumulate_mfma)
 #define DLAGP_LAUNCH_GENERAL_ROWS 0x20000  // cached levels: 16 row reads per pass even where one would do (option shared_rows = 0)
-
-struct PassDesc {
-    int entry_start;  // first entry computed by phase 1
-    int chunk_begin;  // first chunk (DLAGP_CHUNK_PIXELS slots) consumed by phase 2
-    int nchunks;      // 1..DLAGP_MAX_PASS_CHUNKS
-    int pad;
-};
-
-// One wave's work: 16 samples (`group`) of sightline `b` over the passes [pass_begin, pass_end) of the launch
-// plan's pass list; its sums go to partial slot `part` of the block (dlagp_hip.hip: build_plan).
-struct WorkItem {
-    int b, group, part, pass_begin, pass_end, pad0, pad1, pad2;
-};
+// DLAGP_MFMA_GROUP (16 samples per wave), DLAGP_PASS_ENTRIES, DLAGP_CHUNK_PIXELS, DLAGP_MAX_PASS_STEPS / _CHUNKS and the
+// PassDesc / WorkItem records of the launch plan: plan_host.h (shared with the host-only planner build)
 
 // Per-(sample, absorber) constants, computed by each wave for its 16 samples into LDS:
 //   m'_l = c / (lambda_l (1 + z)) / 1e8 / (sqrt2 sigma)   so that  x_l = lam m'_l - c / (sqrt2 sigma)

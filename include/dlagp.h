@@ -324,6 +324,21 @@ int dlagp_get_option(const char *name, int64_t *value);
  * chunks of 8 pixel slots each (pure host arithmetic, no device needed): every block is cut into `full` pieces of
  * `frac` of its chunks each, plus one remainder piece when full * frac < 1.  forced_splits as option "pixel_splits". */
 int dlagp_plan_cut(int64_t groups, double chunks, int64_t forced_splits, int *full, double *frac);
+/* The launch planner of the MFMA path on a batch of pixel masks, pure host code (no device needed; the same function
+ * is exported by the host-only sanitizer build libdlagp_plan_host.so, csrc/plan_host_debug.cpp).  keep[b] is the mask
+ * of sightline b over its n_u[b] unmasked pixels (= ~pixel_mask[ind_unmasked], reference null_gp.py:139-152), ntaps 7
+ * with instrumental broadening and 1 without, S the samples per sightline, options NULL (the library's current values
+ * are NOT used: defaults) or {pixel_splits, plan_item_cost, plan_rest_first, plan_slots, plan_xcd_affine}.
+ *   summary[8]  {slots of all sightlines, passes, work items, blocks, most pieces per block, full pieces, remainder
+ *               piece 0/1, fraction of a sightline per full piece x 1e9}
+ *   slot_pixel / slot_pos [slots]   per sightline, concatenated: kept pixel of every slot (-1 = padding slot) and
+ *               first entry of its convolution window
+ *   passes [passes][3]  {entry_start, chunk_begin, nchunks};  items [items][5]  {sightline, block, piece, pass_begin,
+ *               pass_end} in dispatch order;  counts [blocks]  pieces of block b * ceil(S / 16) + group
+ * Every output array may be NULL or too small (its *_cap says how many records fit): the summary then tells the sizes. */
+int dlagp_plan_debug(int nb, const int *n_u, const uint8_t *const *keep, int ntaps, int64_t S, const int64_t *options,
+                     int64_t *summary, int32_t *slot_pixel, int32_t *slot_pos, int64_t slots_cap, int32_t *passes,
+                     int64_t passes_cap, int32_t *items, int64_t items_cap, uint8_t *counts, int64_t counts_cap);
 int dlagp_timing_read(double *total_ms, int64_t *launches, int reset);
 /* Diagnostic build aid: with option "debug" bit 1 set the MFMA kernel sums shader-clock stamps per
  * phase over all waves (current device): [0] Voigt loop, [1] convolution, [2] weights + MFMA loop,
