@@ -8,9 +8,13 @@ The reference processes one spectrum at a time in a single Python process
     every level (separation mask, evidence, `np.random.choice` resampling) runs per sightline
     with the reference's seeding (`np.random.seed(0)` per spectrum, run_bayes_select.py:144) by
     saving and restoring the legacy global RNG state around each sightline's turn;
-  * shards sightlines over ranks in contiguous blocks (one process per GPU, no data-path
-    collective) and gathers the per-sightline log-evidences to every rank with one all-gather --
-    RCCL over xGMI when the process group is `nccl`, `gloo` in the CPU tests;
+  * shards sightlines over ranks (one process per GPU, no data-path collective) by COST, not by count: the work of
+    a spectrum goes with its kept pixels n, which follow z_qso through the modelled window (reference
+    null_gp.py:139-152, set_parameters.py:125-159: ~200 pixels at z = 2.15, 1250 from z = 3), so equal counts of a
+    redshift-ordered catalogue leave the low-z ranks idle.  `balanced_assignment` is a deterministic
+    longest-processing-time assignment every rank computes identically from the inputs; the per-sightline
+    log-evidences return to every rank, in catalogue order, with one padded all-gather -- RCCL over xGMI when the
+    process group is `nccl`, `gloo` in the CPU tests;
   * splits the samples of ONE sightline over the ranks (`sweep_sharded_samples*`, the single-spectrum
     scaling point): the S samples of an occupation level are independent (reference dla_gp.py:132-159;
     MATLAB parallelises this axis, multi_dlas/process_qsos_multiple_dlas_meanflux.m:333), the
@@ -41,10 +45,60 @@ def shard_range(num_items: int, world_size: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_rows(local_rows: np.ndarray, total_rows: int, group=None, device=None) -> np.ndarray:
+def spectrum_cost(n_pixels, num_samples: int, max_dlas: int, sub_dla: bool = True):
     """
-    All-gather row blocks distributed by `shard_range` into the full (total_rows, m) array on every
-    rank.  Blocks are padded to the largest shard so that one fixed-size collective suffices.
+    Modelled cost of the model-evidence sweeps of one spectrum, in pixel-evaluations: n kept pixels x (1 null
+    evaluation + S samples x (sub-DLA model + max_dlas occupation levels)).  Every term of an evaluation is linear
+    in n (Voigt profile, weights, the n k (k + 1) contraction: SURVEY.md 8d).  Levels a sweep skips after a NaN
+    evidence (reference dla_gp.py:200-206) are not known in advance and are charged in full.
+    """
+    n = np.asarray(n_pixels, dtype=np.float64)
+    return n * (1.0 + float(num_samples) * ((1.0 if sub_dla else 0.0) + float(max_dlas)))
+
+
+def balanced_assignment(costs, world_size: int) -> List[np.ndarray]:
+    """
+    Longest-processing-time assignment of items to ranks: items in order of decreasing cost (ties: catalogue order),
+    each to the rank with the least cost so far (ties: lowest rank).  Deterministic, so every rank computes the same
+    table from the same inputs and no broadcast is needed.  Returns, per rank, its item indices in catalogue order.
+    Greedy LPT is within 4/3 - 1/(3 ranks) of the optimum in the worst case and within a fraction of the smallest item
+    for catalogues of many more items than ranks.
+    """
+    import heapq
+
+    costs = np.asarray(costs, dtype=np.float64)
+    if costs.ndim != 1 or world_size < 1:
+        raise ValueError("costs must be 1-d and world_size >= 1")
+    if not np.all(np.isfinite(costs)) or np.any(costs < 0):
+        raise ValueError("costs must be finite and non-negative")
+    order = np.lexsort((np.arange(costs.shape[0]), -costs))
+    heap = [(0.0, r) for r in range(world_size)]
+    owner = np.empty(costs.shape[0], dtype=np.int64)
+    for item in order:
+        load, r = heapq.heappop(heap)
+        owner[item] = r
+        heapq.heappush(heap, (load + float(costs[item]), r))
+    return [np.flatnonzero(owner == r) for r in range(world_size)]
+
+
+def contiguous_assignment(num_items: int, world_size: int) -> List[np.ndarray]:
+    """`shard_range` as an assignment table (equal counts of consecutive items)"""
+    return [np.arange(*shard_range(num_items, world_size, r)) for r in range(world_size)]
+
+
+def assignment_imbalance(costs, assignment: Sequence[np.ndarray]) -> float:
+    """busiest rank's cost / mean cost per rank (1.0 = perfect balance)"""
+    costs = np.asarray(costs, dtype=np.float64)
+    loads = np.array([costs[idx].sum() for idx in assignment])
+    return float(loads.max() / loads.mean()) if loads.mean() > 0 else 1.0
+
+
+def gather_rows(local_rows: np.ndarray, total_rows: int, group=None, device=None,
+                assignment: Optional[Sequence[np.ndarray]] = None) -> np.ndarray:
+    """
+    All-gather the row blocks of the ranks into the full (total_rows, m) array, in catalogue order, on every rank.
+    `assignment[r]` = the rows rank r holds, in the order it holds them (default: `shard_range` blocks).  Blocks
+    are padded to the largest shard so that one fixed-size collective suffices.
     Without an initialised process group this is the identity (single process).
     """
     import torch
@@ -53,10 +107,21 @@ def gather_rows(local_rows: np.ndarray, total_rows: int, group=None, device=None
     local_rows = np.ascontiguousarray(local_rows, dtype=np.float64)
     if not (dist.is_available() and dist.is_initialized()):
         assert local_rows.shape[0] == total_rows
+        if assignment is not None:
+            out = np.empty_like(local_rows)
+            out[np.asarray(assignment[0])] = local_rows
+            return out
         return local_rows
     world = dist.get_world_size(group)
+    if assignment is None:
+        assignment = contiguous_assignment(total_rows, world)
+    if len(assignment) != world or sum(len(idx) for idx in assignment) != total_rows:
+        raise ValueError("assignment does not cover %d rows over %d ranks" % (total_rows, world))
+    if local_rows.shape[0] != len(assignment[dist.get_rank(group)]):
+        raise ValueError("this rank holds %d rows, its assignment lists %d"
+                         % (local_rows.shape[0], len(assignment[dist.get_rank(group)])))
     m = local_rows.shape[1]
-    largest = shard_range(total_rows, world, 0)[1]
+    largest = max(len(idx) for idx in assignment)
     if device is None:
         if dist.get_backend(group) == "nccl":
             _require_torch_gpu(torch)
@@ -69,8 +134,8 @@ def gather_rows(local_rows: np.ndarray, total_rows: int, group=None, device=None
     dist.all_gather(recv, send, group=group)
     out = np.empty((total_rows, m), dtype=np.float64)
     for r in range(world):
-        lo, hi = shard_range(total_rows, world, r)
-        out[lo:hi] = recv[r][: hi - lo].cpu().numpy()
+        idx = np.asarray(assignment[r])
+        out[idx] = recv[r][: len(idx)].cpu().numpy()
     return out
 
 
@@ -338,19 +403,29 @@ def model_evidences_sharded(
     world_size: int = 1,
     group=None,
     make_batch: Optional[Callable] = None,
+    partition: str = "cost",
 ) -> np.ndarray:
     """
     log-evidences [null, sub-DLA, DLA(1..max_dlas)] of every sightline in `sightlines` (objects with
     the post-set_data attributes, e.g. synthetic.SyntheticSightline), computed by the rank that owns
-    the sightline and all-gathered: returns (len(sightlines), 2 + max_dlas) on every rank.
+    the sightline and all-gathered: returns (len(sightlines), 2 + max_dlas) on every rank, rows in the order of
+    `sightlines`.  `partition`: "cost" (default) balances the ranks' modelled work (`balanced_assignment` on
+    `spectrum_cost` of the kept pixels), "contiguous" cuts equal counts of consecutive sightlines.
 
     `make_batch(list of sightlines, device)` must return an object with `.eval(z, nhi)` and
     `.nulls()` (and optionally `.sweep(...)`); the default builds DeviceSightline / DeviceBatch (GPU).
     """
     total = len(sightlines)
-    lo, hi = shard_range(total, world_size, rank)
-    runner = ShardRunner(sightlines[lo:hi], num_samples, max_dlas, min_z_separation_kms, device, make_batch)
-    return gather_rows(runner.run(), total, group=group)
+    if partition == "cost":
+        costs = spectrum_cost([s.n for s in sightlines], num_samples, max_dlas)
+        assignment = balanced_assignment(costs, world_size)
+    elif partition == "contiguous":
+        assignment = contiguous_assignment(total, world_size)
+    else:
+        raise ValueError("partition must be 'cost' or 'contiguous'")
+    mine = [sightlines[i] for i in assignment[rank]]
+    runner = ShardRunner(mine, num_samples, max_dlas, min_z_separation_kms, device, make_batch)
+    return gather_rows(runner.run(), total, group=group, assignment=assignment)
 
 
 class _DeviceBatchAdapter:

@@ -14,8 +14,9 @@ comes back under the same dataset name and shape.  What differs is the execution
     per spectrum (:144), so `base_sample_inds` are the reference's.
 
 Spectra arrive as arrays -- reading SDSS FITS files (`read_spec`, :147) is outside this package.
-Multi-GPU: `rank` / `world_size` shard the catalogue in contiguous blocks (one process per GPU);
-every rank returns the full arrays after one all-gather per output (`parallel.gather_rows`).
+Multi-GPU: `rank` / `world_size` shard the catalogue over one process per GPU, balanced by the spectra's kept pixels
+(`parallel.balanced_assignment`: a spectrum's work follows z_qso through the modelled window, null_gp.py:139-152);
+every rank returns the full arrays, in catalogue order, after one all-gather per output (`parallel.gather_rows`).
 """
 from collections import namedtuple
 from concurrent.futures import ThreadPoolExecutor
@@ -144,6 +145,19 @@ class DeviceEngine:
         self.model.close()
 
 
+def kept_pixel_counts(params: Parameters, spectra, z_qso_list) -> np.ndarray:
+    """
+    n of every spectrum -- the pixels `set_data` keeps: inside the modelled rest-frame window and not masked
+    (reference null_gp.py:139-152) -- without preparing the spectrum: what the sharding's cost model needs of the
+    whole catalogue on every rank.
+    """
+    counts = np.empty(len(spectra), dtype=np.int64)
+    for q, (wavelengths, _, _, pixel_mask) in enumerate(spectra):
+        rest = params.emitted_wavelengths(np.asarray(wavelengths), z_qso_list[q])
+        counts[q] = np.count_nonzero((rest >= params.min_lambda) & (rest <= params.max_lambda) & ~np.asarray(pixel_mask))
+    return counts
+
+
 def process_qso(
     spectra: Sequence[Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]],
     z_qso_list: Sequence[float],
@@ -164,6 +178,7 @@ def process_qso(
     qso_list: Optional[Sequence[str]] = None,
     engine=None,
     prefetch: bool = True,
+    partition: str = "cost",
 ) -> Dict[str, np.ndarray]:
     """
     :param spectra: per quasar (observed wavelengths, flux, noise_variance, pixel_mask) -- what the
@@ -173,26 +188,39 @@ def process_qso(
     :param prefetch: prepare the next batch in a worker thread while the current one is swept
     :param engine: back end (default `DeviceEngine(learned, params, device)`)
     :param seed: the reference re-seeds the global RNG with 0 before every spectrum (:144)
+    :param partition: how `world_size` > 1 ranks divide the catalogue: "cost" (default) balances the modelled work
+        (`kept_pixel_counts` -> `parallel.spectrum_cost` -> `parallel.balanced_assignment`, identical on every rank),
+        "contiguous" gives every rank an equal count of consecutive spectra
     :return: dict keyed by the dataset names of processed_qsos_multi_meanflux.h5 (:248-295)
     """
     learned = LearnedModel(*learned)
     num = len(spectra)
     assert len(z_qso_list) == num
     S = params.num_dla_samples
-    lo, hi = parallel.shard_range(num, world_size, rank)
-    local = _empty_results(hi - lo, S, max_dlas)
+    if world_size == 1:
+        assignment = [np.arange(num)]
+    elif partition == "cost":
+        costs = parallel.spectrum_cost(kept_pixel_counts(params, spectra, z_qso_list), S, max_dlas)
+        assignment = parallel.balanced_assignment(costs, world_size)
+    elif partition == "contiguous":
+        assignment = parallel.contiguous_assignment(num, world_size)
+    else:
+        raise ValueError("partition must be 'cost' or 'contiguous'")
+    mine = assignment[rank]  # this rank's spectra, in catalogue order; local row i <-> spectrum mine[i]
+    local = _empty_results(len(mine), S, max_dlas)
     min_sep = params.kms_to_z(min_z_separation)
 
-    own_engine = engine is None and hi > lo
+    own_engine = engine is None and len(mine) > 0
     if own_engine:
         engine = DeviceEngine(learned, params, device)
     nhi_dla = np.asarray(dla_samples.nhi_samples, dtype=np.float64)
     nhi_sub = np.asarray(subdla_samples.nhi_samples, dtype=np.float64)
 
     def prepare(start: int, stop: int):
-        """host index logic + device contexts of spectra [start, stop): everything a sweep needs"""
+        """host index logic + device contexts of local rows [start, stop): everything a sweep needs"""
         sightlines, z_dla, z_lls = [], [], []
-        for q in range(start, stop):
+        for i in range(start, stop):
+            q = int(mine[i])
             wavelengths, flux, noise_variance, pixel_mask = spectra[q]
             z_qso = z_qso_list[q]
             rest_wavelengths = params.emitted_wavelengths(wavelengths, z_qso)
@@ -200,13 +228,19 @@ def process_qso(
             sightlines.append(engine.sightline(st, z_qso, broadening))
             z_dla.append(dla_samples.sample_z_dlas(st["this_wavelengths"], z_qso))
             z_lls.append(subdla_samples.sample_z_lls(st["this_wavelengths"], z_qso))
-            local["min_z_dlas"][q - lo] = params.min_z_dla(wavelengths, z_qso)
-            local["max_z_dlas"][q - lo] = params.max_z_dla(wavelengths, z_qso)
-        return sightlines, engine.batch(sightlines), np.stack(z_dla), np.stack(z_lls)
+            local["min_z_dlas"][i] = params.min_z_dla(wavelengths, z_qso)
+            local["max_z_dlas"][i] = params.max_z_dla(wavelengths, z_qso)
+        try:
+            return sightlines, engine.batch(sightlines), np.stack(z_dla), np.stack(z_lls)
+        except BaseException:
+            for s in sightlines:  # a batch that could not be built must not leave its contexts behind
+                if hasattr(s, "close"):
+                    s.close()
+            raise
 
     def finish(start, stop, sightlines, batch, z_dla, nulls, ev_sub, ll_sub, ev_dla, ll_dla, base):
-        """priors, posteriors, MAP values of spectra [start, stop) into the result arrays; frees their contexts"""
-        rows = slice(start - lo, stop - lo)
+        """priors, posteriors, MAP values of local rows [start, stop) into the result arrays; frees their contexts"""
+        rows = slice(start, stop)
         # the big per-sample arrays: one copy per batch
         local["sample_log_likelihoods_dla"][rows] = ll_dla
         local["base_sample_inds"][rows] = base.transpose(0, 2, 1)
@@ -218,8 +252,8 @@ def process_qso(
         if np.isneginf(masked.max(axis=1)).any():
             raise ValueError("All-NaN slice encountered")  # what np.nanargmax says about a level without a finite sample
         log_nhi = dla_samples.log_nhi_samples
-        for b, q in enumerate(range(start, stop)):
-            i = q - lo
+        for b, i in enumerate(range(start, stop)):
+            q = int(mine[i])
             log_priors = occupation_log_priors(prior, z_qso_list[q], max_dlas, dla_samples, subdla_samples)
             log_likelihoods = np.concatenate([[nulls[b]], ev_sub[b], ev_dla[b]])
             log_posteriors = log_likelihoods + log_priors
@@ -237,7 +271,6 @@ def process_qso(
             local["model_posteriors"][i] = posteriors
             local["p_dlas"][i] = np.sum(posteriors[-max_dlas:])
             local["p_no_dlas"][i] = 1 - local["p_dlas"][i]
-        engine.release(batch, sightlines)
 
     def sweeps(sightlines, batch, z_dla, z_lls):
         """the three models of one batch: null evidences, sub-DLA sweep, DLA sweep"""
@@ -261,20 +294,48 @@ def process_qso(
     # posteriors, MAP, freeing contexts).  At most `in_flight` batches exist at a time.
     # `prefetch=False` -- and seed=None, whose draws come from the global RNG in catalogue order -- runs everything in
     # this thread, in order.
-    bounds = [(start, min(start + batch_size, hi)) for start in range(lo, hi, batch_size)]
+    bounds = [(start, min(start + batch_size, len(mine))) for start in range(0, len(mine), batch_size)]
+
+    def sweep_and_finish(start, stop, sightlines, batch, z_dla, z_lls):
+        """whatever happens in the sweeps or the bookkeeping, the batch's contexts and workspace go back"""
+        try:
+            finish(start, stop, sightlines, batch, z_dla, *sweeps(sightlines, batch, z_dla, z_lls))
+        finally:
+            engine.release(batch, sightlines)
+
     if prefetch and len(bounds) > 1 and seed is not None:
         import threading
 
         in_flight = threading.Semaphore(5)
         prepare_pool, sweep_pool, finish_pool = (ThreadPoolExecutor(max_workers=w) for w in (1, 3, 1))
+        failed = threading.Event()
+
+        def stage_prepare(start, stop):
+            if failed.is_set():
+                raise RuntimeError("skipped: an earlier batch failed")
+            return prepare(start, stop)
 
         def stage_sweep(start, stop, prepared):
             sightlines, batch, z_dla, z_lls = prepared.result()
-            return (start, stop, sightlines, batch, z_dla) + sweeps(sightlines, batch, z_dla, z_lls)
+            try:
+                if failed.is_set():
+                    raise RuntimeError("skipped: an earlier batch failed")
+                return (start, stop, sightlines, batch, z_dla) + sweeps(sightlines, batch, z_dla, z_lls)
+            except BaseException:
+                failed.set()
+                engine.release(batch, sightlines)
+                raise
 
         def stage_finish(swept):
             try:
-                finish(*swept.result())
+                result = swept.result()
+                try:
+                    finish(*result)
+                finally:
+                    engine.release(result[3], result[2])
+            except BaseException:
+                failed.set()
+                raise
             finally:
                 in_flight.release()
 
@@ -282,18 +343,27 @@ def process_qso(
         try:
             for start, stop in bounds:
                 in_flight.acquire()
-                prepared = prepare_pool.submit(prepare, start, stop)
+                if failed.is_set():  # the first failure ends the run: nothing further is started
+                    in_flight.release()
+                    break
+                prepared = prepare_pool.submit(stage_prepare, start, stop)
                 swept = sweep_pool.submit(stage_sweep, start, stop, prepared)
                 finishing.append(finish_pool.submit(stage_finish, swept))
+            errors = []
             for future in finishing:
-                future.result()
+                try:
+                    future.result()
+                except BaseException as exc:  # noqa: BLE001 -- the first one is re-raised below
+                    errors.append(exc)
+            real = [e for e in errors if "skipped: an earlier batch failed" not in str(e)]
+            if errors:
+                raise (real or errors)[0]
         finally:
             for pool in (prepare_pool, sweep_pool, finish_pool):
-                pool.shutdown()
+                pool.shutdown(wait=True, cancel_futures=True)
     else:
         for start, stop in bounds:
-            sightlines, batch, z_dla, z_lls = prepare(start, stop)
-            finish(start, stop, sightlines, batch, z_dla, *sweeps(sightlines, batch, z_dla, z_lls))
+            sweep_and_finish(start, stop, *prepare(start, stop))
     if own_engine:
         engine.close()
 
@@ -302,8 +372,8 @@ def process_qso(
         if world_size == 1:
             results[name] = local[name]  # no copy: the per-sample arrays are 80 KB x (2 max_dlas) per quasar
             continue
-        rows = local[name].reshape(hi - lo, int(np.prod(local[name].shape[1:])))
-        full = parallel.gather_rows(rows, num, group=group)
+        rows = local[name].reshape(len(mine), int(np.prod(local[name].shape[1:])))
+        full = parallel.gather_rows(rows, num, group=group, assignment=assignment)
         results[name] = full.reshape((num,) + local[name].shape[1:]).astype(local[name].dtype)
     # model settings and bookkeeping the reference stores next to the results (:250-268, :293-295)
     for name in ("prior_z_qso_increase", "k", "normalization_min_lambda", "normalization_max_lambda",

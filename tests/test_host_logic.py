@@ -223,7 +223,8 @@ class OracleBatch:
 
 
 def test_sharded_evidences_gloo_world_size_2(tmp_path):
-    """N > 1 path: contiguous shards (5 sightlines over 2 ranks: 3 + 2), padded all-gather"""
+    """N > 1 path: cost-balanced shards (5 sightlines over 2 ranks: {0, 1, 4} + {2, 3}), padded all-gather, rows back
+    in catalogue order"""
     env = dict(os.environ, DLAGP_REPO=REPO, DLAGP_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1",
                OMP_NUM_THREADS="1")
     script = tmp_path / "worker.py"
@@ -361,6 +362,99 @@ def test_process_qso_matches_reference_driver_golden(tmp_path):
         back = np.load(path)
         np.testing.assert_array_equal(back["base_sample_inds"], results["base_sample_inds"])
         assert list(back["qso_list"]) == ["spec-0", "spec-1", "spec-2"]
+
+
+def dr12q_like_kept_pixels(num, rng):
+    """
+    kept pixels of `num` spectra with a DR12Q-like redshift spread, through the package's own window logic: BOSS
+    spectra start at ~3600 A observed, the model covers 911.75-1215.75 A rest (set_parameters.py:33-34), so the
+    window is entered at z_qso ~ 2.0 and fully covered from z_qso ~ 2.95 (n = 1250); most quasars sit at z = 2.2-2.6.
+    """
+    params = Parameters()
+    z_qsos = np.clip(2.15 + rng.gamma(2.0, 0.22, size=num), 2.15, 5.5)
+    observed = 10.0 ** np.arange(np.log10(3600.0), np.log10(10400.0), 1e-4)  # the BOSS grid: 1e-4 dex pixels
+    spectra = []
+    for z in z_qsos:
+        mask = rng.random(observed.shape[0]) < rng.choice([0.0, 0.02, 0.1])
+        spectra.append((observed, None, None, mask))
+    from gpy_dla_detection_amd.run_bayes_select import kept_pixel_counts
+
+    return z_qsos, kept_pixel_counts(params, spectra, z_qsos)
+
+
+def test_cost_balanced_partition_of_a_redshift_ordered_catalogue():
+    """
+    A spectrum's work follows its kept pixels n, and n follows z_qso through the modelled window (reference
+    null_gp.py:139-152, set_parameters.py:125-159).  Equal COUNTS of a redshift-sorted catalogue -- the natural order
+    of a catalogue file -- leave the low-z ranks with a fraction of the work; the LPT assignment on the cost model
+    balances the ranks to a few parts in a thousand, deterministically.
+    """
+    rng = np.random.default_rng(7)
+    z_qsos, n = dr12q_like_kept_pixels(1024, rng)
+    assert n.min() < 400 and n.max() >= 1200  # the window is entered and fully covered within the sample
+    order = np.argsort(z_qsos)
+    costs = parallel.spectrum_cost(n[order], 10000, 4)
+    for world in (2, 4, 8):
+        contiguous = parallel.contiguous_assignment(len(costs), world)
+        balanced = parallel.balanced_assignment(costs, world)
+        assert sorted(np.concatenate(balanced).tolist()) == list(range(len(costs)))  # every spectrum exactly once
+        assert all(np.all(np.diff(idx) > 0) for idx in balanced)  # each rank keeps catalogue order
+        assert parallel.assignment_imbalance(costs, balanced) <= 1.05
+        if world == 8:
+            assert parallel.assignment_imbalance(costs, contiguous) > 1.25  # the counter-example
+            assert parallel.assignment_imbalance(costs, balanced) <= 1.005
+        again = parallel.balanced_assignment(costs.copy(), world)
+        assert all(np.array_equal(a, b) for a, b in zip(balanced, again))  # every rank computes the same table
+    # few, equal items: ties go to the lowest rank and to catalogue order
+    assert [idx.tolist() for idx in parallel.balanced_assignment(np.ones(5), 2)] == [[0, 2, 4], [1, 3]]
+    assert [idx.tolist() for idx in parallel.balanced_assignment([], 3)] == [[], [], []]
+    with pytest.raises(ValueError):
+        parallel.balanced_assignment([1.0, np.nan], 2)
+
+
+def test_kept_pixel_counts_equal_what_set_data_keeps():
+    from gpy_dla_detection_amd.null_gp import prepare_data
+    from gpy_dla_detection_amd.run_bayes_select import kept_pixel_counts
+
+    learned, spectra, z_qsos, params, _, _ = catalogue_inputs(8)
+    counts = kept_pixel_counts(params, spectra, z_qsos)
+    for q, (wavelengths, flux, noise_variance, pixel_mask) in enumerate(spectra):
+        rest = params.emitted_wavelengths(wavelengths, z_qsos[q])
+        state = prepare_data(params, rest, flux, noise_variance, pixel_mask, z_qsos[q])
+        assert counts[q] == state["y"].shape[0]
+
+
+def test_a_failing_batch_ends_the_catalogue_run_and_frees_every_context():
+    """the driver's pipeline: the first failure is re-raised, nothing further starts, every prepared batch is released"""
+    from gpy_dla_detection_amd.run_bayes_select import process_qso
+
+    learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(16)
+    spectra, z_qsos = spectra * 4, list(z_qsos) * 4  # 12 spectra, batches of 2
+
+    class Flaky(OracleEngine):
+        def __init__(self, *a):
+            super().__init__(*a)
+            self.made, self.released, self.sweeps = 0, 0, 0
+
+        def batch(self, sightlines):
+            self.made += 1
+            return super().batch(sightlines)
+
+        def sweep(self, *a):
+            self.sweeps += 1
+            if self.sweeps == 3:  # the DLA sweep of the second batch
+                raise RuntimeError("device fell over")
+            return super().sweep(*a)
+
+        def release(self, batch, sightlines):
+            self.released += 1
+
+    for prefetch in (True, False):
+        engine = Flaky(learned, params)
+        with pytest.raises(RuntimeError, match="device fell over"):
+            process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=2,
+                        batch_size=2, engine=engine, prefetch=prefetch)
+        assert engine.made == engine.released and engine.made < 6, (prefetch, engine.made, engine.released)
 
 
 def test_occupation_log_priors_match_reference_model_selection():
