@@ -11,8 +11,9 @@ from typing import List
 import numpy as np
 from scipy.special import logsumexp
 
-from .dla_gp import DLAGP
+from .dla_gp import DLAGP, _AbsorberGP, settle_rng_after_sweep
 from .null_gp import NullGP
+from .subdla_gp import SubDLAGP
 
 
 class BayesModelSelect:
@@ -42,18 +43,67 @@ class BayesModelSelect:
         log_priors[0] = np.log(1 - np.exp(logsumexp(log_priors[1:])))
 
         # evidences: this is where the GPU sweep runs (reference :84-96)
-        evidences = []
-        for model, num in zip(model_list, self.all_max_dlas):
-            if num == 0:
-                evidences.append(model.log_model_evidence())
-            else:
-                evidences.extend(model.log_model_evidences(num))
-        log_likelihoods = np.array(evidences)
+        log_likelihoods = self._evidences_in_one_call(model_list)
+        if log_likelihoods is None:
+            evidences = []
+            for model, num in zip(model_list, self.all_max_dlas):
+                if num == 0:
+                    evidences.append(model.log_model_evidence())
+                else:
+                    evidences.extend(model.log_model_evidences(num))
+            log_likelihoods = np.array(evidences)
 
         self.log_priors = log_priors
         self.log_likelihoods = log_likelihoods
         self.log_posteriors = log_likelihoods + log_priors
         return self.log_posteriors
+
+    def _evidences_in_one_call(self, model_list: List[NullGP]):
+        """
+        The reference driver's model list [null, sub-DLA (1), DLA (1..k)] on ONE spectrum (run_bayes_select.py:189):
+        when the three stock models share one HBM-resident sightline (`null_gp.SharedSightline` -- equal learned
+        model, settings and spectrum by content), the loop above is one call into the library
+        (dlagp_batch_model_evidences: null evidence, sub-DLA sweep and occupation sweep enqueued back to back, one
+        wait).  Same numbers bit for bit, same side effects on the models (`sample_log_likelihoods`,
+        `base_sample_inds`), same use of the legacy global RNG.  None when the shape does not apply.
+        """
+        if len(model_list) != 3 or list(self.all_max_dlas[:2]) != [0, 1] or len(self.all_max_dlas) != 3:
+            return None
+        null, sub, dla = model_list
+        max_dlas = self.all_max_dlas[2]
+        if not (type(null).log_model_evidence is NullGP.log_model_evidence and isinstance(sub, SubDLAGP)
+                and type(sub).log_model_evidences is SubDLAGP.log_model_evidences
+                and type(dla).log_model_evidences is DLAGP.log_model_evidences and 1 <= max_dlas <= 8):
+            return None
+        for model in (sub, dla):
+            if model.host_levels or not model._stock_absorption() or type(model)._sweep is not _AbsorberGP._sweep:
+                return None
+        S = dla.params.num_dla_samples
+        if sub.params.num_dla_samples != S or sub.min_z_separation != dla.min_z_separation:
+            return None
+        try:
+            devs = [m.device_sightline() for m in model_list]
+        except AttributeError:  # a model without data: let the plain loop raise what the reference raises
+            return None
+        shared = dla._shared
+        if shared is None or any(d is not devs[0] for d in devs) or sub._shared is not shared or null._shared is not shared:
+            return None
+        z_lls = np.asarray(sub._sample_redshifts(), dtype=np.float64)
+        z_dla = np.asarray(dla._sample_redshifts(), dtype=np.float64)
+        nhi_sub = np.asarray(sub.dla_samples.nhi_samples, dtype=np.float64)
+        nhi_dla = np.asarray(dla.dla_samples.nhi_samples, dtype=np.float64)
+        if not (z_lls.shape == z_dla.shape == nhi_sub.shape == nhi_dla.shape == (S,)):
+            return None
+        # the sub-DLA sweep (one level) draws nothing; the occupation sweep draws one random_sample(S) per resampled
+        # level, exactly as in DLAGP.log_model_evidences
+        rng_before = np.random.get_state()
+        uniforms = np.random.random_sample((1, max(max_dlas - 1, 0), S))
+        nulls, (ev_sub, ll_sub, _), (ev_dla, ll_dla, base) = shared.batch.model_evidences(
+            z_lls[None, :], nhi_sub, z_dla[None, :], nhi_dla, max_dlas, dla.min_z_separation, uniforms)
+        sub.sample_log_likelihoods = ll_sub[0]
+        dla.sample_log_likelihoods, dla.base_sample_inds = ll_dla[0], base[0]
+        settle_rng_after_sweep(ev_dla[0], max_dlas, S, rng_before)
+        return np.concatenate([nulls, ev_sub[0], ev_dla[0]])
 
     @property
     def dla_model_posterior_ind(self) -> np.ndarray:

@@ -90,27 +90,35 @@ class _AbsorberGP(NullGP):
         return self._sweep_on_device(sample_z, sample_nhi, max_dlas, S)
 
     def _sweep_on_device(self, sample_z: np.ndarray, sample_nhi: np.ndarray, max_dlas: int, S: int):
-        from .sightline import DeviceBatch
-
         # np.random.choice(S, S, p=...) draws random_sample(S) once per call (reference dla_gp.py:213-218):
         # draw what a full sweep would draw, and give back what an early stop would not have drawn
         rng_before = np.random.get_state()
         uniforms = np.random.random_sample((1, max(max_dlas - 1, 0), S))
-        batch = DeviceBatch([self.device_sightline()])
+        batch, own = self.device_batch()  # the spectrum's shared sightline keeps ONE batch for all its sweeps
         try:
             evidences, sample_ll, base = batch.sweep(sample_z[None, :], sample_nhi, max_dlas,
                                                      self.min_z_separation, uniforms)
         finally:
-            batch.close()
+            if own:
+                batch.close()
         evidences, sample_ll, base = evidences[0], sample_ll[0], base[0]
-        nan_levels = np.flatnonzero(np.isnan(evidences))
-        if nan_levels.size and nan_levels[0] + 1 < max_dlas:  # reference :200-206: the sweep stopped there
-            stopped = int(nan_levels[0])
-            print("Finish the loop earlier because NaN value in log p(D | z_QSO, {} DLAs)".format(stopped))
-            np.random.set_state(rng_before)
-            for _ in range(stopped):  # the levels before it did resample
-                np.random.random_sample(S)
+        settle_rng_after_sweep(evidences, max_dlas, S, rng_before)
         return evidences, sample_ll, base
+
+
+def settle_rng_after_sweep(evidences: np.ndarray, max_dlas: int, S: int, rng_before) -> None:
+    """
+    The device sweep was handed the uniforms of a FULL sweep; the reference stops at the first level whose evidence
+    is NaN (dla_gp.py:200-206) and has then drawn only the levels before it.  Prints the reference's message and
+    leaves the legacy global RNG where the reference would have left it.
+    """
+    nan_levels = np.flatnonzero(np.isnan(evidences))
+    if nan_levels.size and nan_levels[0] + 1 < max_dlas:
+        stopped = int(nan_levels[0])
+        print("Finish the loop earlier because NaN value in log p(D | z_QSO, {} DLAs)".format(stopped))
+        np.random.set_state(rng_before)
+        for _ in range(stopped):  # the levels before it did resample
+            np.random.random_sample(S)
 
 
 def level_parameters(sample_z: np.ndarray, sample_nhi: np.ndarray, base_sample_inds: np.ndarray, level: int):

@@ -8,6 +8,8 @@ Same constructor, `set_data` and attribute surface as the reference class
 evidence itself goes through libdlagp_hip.so (`log_model_evidence` ->
 dlagp_null, `log_mvnpdf_low_rank` -> dlagp_mvnpdf).
 """
+import threading
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -66,14 +68,16 @@ class _LinearInterpolant:
     `scipy.interpolate.interp1d(grid, values)` (kind "linear", bounds_error) as the reference builds it
     (null_gp.py:67-71), without the per-object set-up: the reference's driver constructs three GP objects per
     spectrum, 22 interpolants each, which was a quarter of the per-spectrum time of the drop-in route.  Same
-    arithmetic -- interp1d's linear path is `np.interp` on a sorted grid -- and the same ValueError outside the grid.
+    arithmetic -- interp1d's linear path is `np.interp` on a sorted grid -- the same ValueError outside the grid, and,
+    like interp1d (copy=True), its own copies of grid and values: an in-place edit of the learned arrays after the GP
+    object was built does not change its interpolation.
     """
 
     __slots__ = ("x", "y")
 
-    def __init__(self, grid: np.ndarray, values: np.ndarray):
-        self.x = np.asarray(grid, dtype=np.float64)
-        self.y = np.asarray(values, dtype=np.float64)
+    def __init__(self, grid: np.ndarray, values: np.ndarray, copy: bool = True):
+        self.x = np.array(grid, dtype=np.float64, copy=copy) if copy else grid
+        self.y = np.array(values, dtype=np.float64, copy=copy) if copy else values
         if self.x.ndim != 1 or self.x.shape != self.y.shape:
             raise ValueError("x and y arrays must be equal in length along interpolation axis.")
 
@@ -87,37 +91,186 @@ class _LinearInterpolant:
         return np.interp(x_new, self.x, self.y)
 
 
+class _LearnedModel:
+    """
+    One learned GP model as the GP objects built from it share it: private copies of (rest grid, mu, M, log omega)
+    taken when the first GP object was constructed from arrays of that CONTENT, the interpolants over those copies,
+    and the HBM-resident `DeviceModel`s made from them (one per device and set of Lyman-series scalars).
+    """
+
+    _tokens = iter(range(1, 1 << 62))
+
+    def __init__(self, grid, mu, M, log_omega):
+        self.token = next(_LearnedModel._tokens)  # stands for the content in cache keys
+        self.grid, self.mu, self.log_omega = grid, mu, log_omega
+        self.M_columns = M  # (k, n_grid), C order: one learned eigen-spectrum per row
+        self.mu_interpolator = _LinearInterpolant(grid, mu, copy=False)
+        self.log_omega_interpolator = _LinearInterpolant(grid, log_omega, copy=False)
+        self.list_M_interpolators = [_LinearInterpolant(grid, column, copy=False) for column in M]
+        self.device_models = {}
+        self.lock = threading.Lock()
+
+    def matches(self, grid, mu, M, log_omega) -> bool:
+        return (grid.shape == self.grid.shape and mu.shape == self.mu.shape and log_omega.shape == self.log_omega.shape
+                and M.shape == self.M_columns.shape[::-1] and np.array_equal(M.T, self.M_columns)
+                and np.array_equal(mu, self.mu) and np.array_equal(log_omega, self.log_omega)
+                and np.array_equal(grid, self.grid))
+
+    def device_model(self, scalars: tuple, device: int) -> "_sl.DeviceModel":
+        """the model in HBM; `scalars` = (log_c_0, log_tau_0, log_beta, prev_tau_0, prev_beta, num_forest_lines)"""
+        key = scalars + (int(device),)
+        with self.lock:
+            model = self.device_models.get(key)
+            if model is None:
+                if len(self.device_models) >= 4:  # scalars that keep changing (a fit in progress): do not pile up
+                    self.device_models.pop(next(iter(self.device_models)))  # GP objects using it keep it alive
+                model = _sl.DeviceModel(self.grid, self.mu, self.M_columns.T, self.log_omega, *scalars, device=device)
+                self.device_models[key] = model
+            return model
+
+
+class _LearnedRegistry:
+    """
+    The learned models GP objects were recently built from, recognised by CONTENT: the reference's driver constructs
+    three GP objects per spectrum from the same learned arrays (run_bayes_select.py:151-186; the *MAT factories even
+    re-read the file each time, so the array objects differ while their content is the same).  A constructor's arrays
+    are compared with the known models element by element (20 us for a 1217 x 20 factor) -- exact, so an array edited
+    in place between two constructions is a different model, as it is for the reference's interp1d copies.
+    """
+
+    def __init__(self, size: int = 4):
+        self.size = size
+        self.entries = []  # most recent last
+        self.lock = threading.Lock()
+
+    def lookup(self, rest_wavelengths, mu, M, log_omega) -> Optional[_LearnedModel]:
+        try:
+            grid, mu, M, log_omega = (np.asarray(a) for a in (rest_wavelengths, mu, M, log_omega))
+            if (grid.ndim != 1 or M.ndim != 2 or mu.ndim != 1 or log_omega.ndim != 1 or M.shape[0] != grid.shape[0]
+                    or any(a.dtype.kind not in "fiu" for a in (grid, mu, M, log_omega))):
+                return None
+            if grid.shape[0] < 2 or not np.all(np.diff(grid) > 0):
+                return None  # unsorted grid: scipy's interp1d sorts, np.interp does not -- the general path serves
+            with self.lock:
+                for i in range(len(self.entries) - 1, -1, -1):
+                    if self.entries[i].matches(grid, mu, M, log_omega):
+                        entry = self.entries.pop(i)
+                        self.entries.append(entry)
+                        return entry
+                entry = _LearnedModel(np.array(grid, dtype=np.float64), np.array(mu, dtype=np.float64),
+                                      np.array(M.T, dtype=np.float64, order="C"), np.array(log_omega, dtype=np.float64))
+                self.entries.append(entry)
+                del self.entries[: -self.size]
+                return entry
+        except (TypeError, ValueError):
+            return None
+
+
+_LEARNED = _LearnedRegistry()
+
+
 class _InterpCache:
     """
     The reference's driver builds three GP objects per spectrum (null, sub-DLA, DLA model; run_bayes_select.py:151-186)
     and calls `set_data` on each, so `get_interp` interpolates the same learned model onto the same pixels three times
-    (22 interpolations and two effective-optical-depth tables: 0.5 ms, a third of the drop-in route's time per
-    spectrum).  The last few results are kept, keyed by the identity of the learned arrays (held here, so an id cannot
-    be reused), their scalars, and the CONTENT of the spectrum's pixels; every caller gets its own copies.
+    (22 interpolations and two effective-optical-depth tables: 0.5 ms).  The last few results are kept, keyed by the
+    learned model's content token (`_LearnedRegistry`), its scalars, and the CONTENT of the spectrum's pixels; every
+    caller gets its own copies.
     """
 
     def __init__(self, size: int = 4):
-        import threading
-
         self.size = size
-        self.entries = []  # [(key, held arrays, (this_mu, this_M, this_omega2))], most recent last
+        self.entries = []  # [(key, (this_mu, this_M, this_omega2))], most recent last
         self.lock = threading.Lock()
 
     def get(self, key):
         with self.lock:
-            for i, (k, _, value) in enumerate(self.entries):
+            for i, (k, value) in enumerate(self.entries):
                 if k == key:
                     self.entries.append(self.entries.pop(i))
                     return tuple(a.copy(order="K") for a in value)
         return None
 
-    def put(self, key, held, value):
+    def put(self, key, value):
         with self.lock:
-            self.entries.append((key, held, tuple(a.copy(order="K") for a in value)))
+            self.entries.append((key, tuple(a.copy(order="K") for a in value)))
             del self.entries[: -self.size]
 
 
 _INTERP_CACHE = _InterpCache()
+
+
+class SharedSightline:
+    """
+    One HBM-resident sightline (context + the one-member batch the sweeps launch through) serving every GP object
+    whose learned model, scalars, settings and spectrum are equal by content -- the three GP objects the reference's
+    driver builds per spectrum.  Closed when the last of them lets go.
+    """
+
+    def __init__(self, dev: "_sl.DeviceSightline"):
+        self.dev = dev
+        self._batch = None
+        self.lock = threading.Lock()
+
+    @property
+    def batch(self) -> "_sl.DeviceBatch":
+        with self.lock:
+            if self._batch is None:
+                self._batch = _sl.DeviceBatch([self.dev])
+            return self._batch
+
+    def close(self) -> None:
+        with self.lock:
+            if self._batch is not None:
+                self._batch.close()
+                self._batch = None
+            self.dev.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _SharedSightlines:
+    """weakly held: the GP objects own the sightlines, this table only lets a new GP object find an equal one"""
+
+    def __init__(self, size: int = 8):
+        self.size = size
+        self.entries = []  # [(key, weakref to SharedSightline)]
+        self.lock = threading.Lock()
+
+    def find_or_make(self, key, make) -> SharedSightline:
+        with self.lock:
+            alive = []
+            found = None
+            for k, ref in self.entries:
+                shared = ref()
+                if shared is None:
+                    continue
+                alive.append((k, ref))
+                if found is None and k == key:
+                    found = shared
+            self.entries = alive[-self.size:]
+            if found is None:
+                found = SharedSightline(make())
+                self.entries.append((key, weakref.ref(found)))
+            return found
+
+
+_SHARED = _SharedSightlines()
+
+
+def _content(*arrays) -> tuple:
+    """the arrays' dtype, shape and bytes: a cache key that notices in-place edits (comparison is a memcmp)"""
+    out = []
+    for a in arrays:
+        a = np.asarray(a)
+        out.append((a.dtype.str, a.shape, (a if a.flags["C_CONTIGUOUS"] else a.T if a.flags["F_CONTIGUOUS"]
+                                           else np.ascontiguousarray(a)).tobytes(),
+                    bool(a.flags["C_CONTIGUOUS"])))
+    return tuple(out)
 
 
 class NullGP:
@@ -133,6 +286,14 @@ class NullGP:
     :param log_c_0, log_tau_0, log_beta: Lyman-series noise model parameters
     :param prev_tau_0, prev_beta: effective optical depth used for mean-flux suppression
     :param device: HIP device ordinal the evidence is evaluated on (extension; default 0)
+
+    Where the model half of `set_data` happens.  The reference interpolates the learned model onto the spectrum's
+    pixels inside `set_data` (`get_interp`, :179-242) and leaves `this_mu`, `this_M`, `this_omega2` on the instance.
+    Here they are produced on demand: the first evidence call builds the HBM-resident sightline straight from the
+    learned model on the device (`dlagp_create_from_model`; shared by the GP objects of a spectrum, `SharedSightline`),
+    and the three attributes are computed on the host -- the reference's arithmetic, golden-checked to 1e-14 -- when
+    somebody reads them.  Once they exist on the host (read, assigned, or an explicit `get_interp` call), THEY are what
+    the device evaluates: the sightline is rebuilt from them, and again whenever their content changes.
     """
 
     def __init__(
@@ -167,15 +328,25 @@ class NullGP:
         self.device = device
         self._device_sightline: Optional[_sl.DeviceSightline] = None
         self._device_key = None
+        self._shared: Optional[SharedSightline] = None
+        self._model_host = None      # [this_mu, this_M, this_omega2] once they exist on the host
+        self._model_pending = False  # set_data(build_model=True) has run and the model half has not been needed yet
 
-        # linear interpolants of the learned model (reference :67-71; scipy's interp1d when the grid is unsorted)
-        if np.all(np.diff(np.asarray(rest_wavelengths, dtype=np.float64)) > 0):
-            make = _LinearInterpolant
+        # linear interpolants of the learned model (reference :67-71; scipy's interp1d when the grid is unsorted),
+        # over copies taken now, as interp1d's are.  GP objects built from equal learned arrays share them.
+        self._learned = _LEARNED.lookup(rest_wavelengths, mu, M, log_omega)
+        if self._learned is not None:
+            self.mu_interpolator = self._learned.mu_interpolator
+            self.log_omega_interpolator = self._learned.log_omega_interpolator
+            self.list_M_interpolators = self._learned.list_M_interpolators
         else:
-            make = interpolate.interp1d
-        self.mu_interpolator = make(rest_wavelengths, mu)
-        self.log_omega_interpolator = make(rest_wavelengths, log_omega)
-        self.list_M_interpolators = [make(rest_wavelengths, column) for column in np.asarray(M).T]
+            if np.all(np.diff(np.asarray(rest_wavelengths, dtype=np.float64)) > 0):
+                make = _LinearInterpolant
+            else:
+                make = interpolate.interp1d
+            self.mu_interpolator = make(rest_wavelengths, mu)
+            self.log_omega_interpolator = make(rest_wavelengths, log_omega)
+            self.list_M_interpolators = [make(rest_wavelengths, column) for column in np.asarray(M).T]
 
     # ------------------------------------------------------------------------------------------
     # data / model preparation (host; reference :73-242)
@@ -212,8 +383,30 @@ class NullGP:
         state = prepare_data(self.params, X, Y, noise_variance, pixel_mask, z_qso, normalize)
         for name, value in state.items():
             setattr(self, name, value)
+        self._model_host = None
+        self._model_pending = False
         if build_model:
-            self.get_interp(self.x, self.y, self.this_wavelengths, self.z_qso)
+            if type(self).get_interp is NullGP.get_interp:
+                # the stock model half is deferred: the device builds it from the learned model at the first
+                # evidence call, the host when `this_mu` / `this_M` / `this_omega2` are read.  What an out-of-grid
+                # pixel raises (interp1d's ValueError) is raised here, where the reference raises it.
+                self._check_interpolation_range(self.x)
+                self._model_pending = True
+            else:  # a subclass with its own model half: run it now, as the reference does
+                self.get_interp(self.x, self.y, self.this_wavelengths, self.z_qso)
+
+    def _check_interpolation_range(self, x: np.ndarray) -> None:
+        grid = getattr(self.mu_interpolator, "x", None)
+        if grid is None or not np.size(x):
+            return
+        if np.min(x) < grid[0]:
+            raise ValueError("A value in x_new is below the interpolation range's minimum value ({}).".format(grid[0]))
+        if np.max(x) > grid[-1]:
+            raise ValueError("A value in x_new is above the interpolation range's maximum value ({}).".format(grid[-1]))
+
+    def _model_scalars(self) -> tuple:
+        return (float(self.log_c_0), float(self.log_tau_0), float(self.log_beta), float(self.prev_tau_0),
+                float(self.prev_beta), int(self.params.num_forest_lines))
 
     def get_interp(self, x: np.ndarray, y: np.ndarray, wavelengths: np.ndarray, z_qso: float) -> None:
         """
@@ -221,21 +414,16 @@ class NullGP:
         mean-flux suppression and noise scaling (reference :179-242).
         """
         self._invalidate_device()
-        learned = (self.rest_wavelengths, self.mu, self.M, self.log_omega)
         x = np.asarray(x)
         wavelengths = np.asarray(wavelengths)
         key = None
-        if type(self).M_interpolator is NullGP.M_interpolator and all(isinstance(a, np.ndarray) for a in learned):
-            key = (
-                tuple(id(a) for a in learned), tuple(a.shape for a in learned),
-                float(self.mu.sum()), float(self.M.sum()), float(self.log_omega.sum()),  # edits in place
-                float(self.log_c_0), float(self.log_tau_0), float(self.log_beta), float(self.prev_tau_0),
-                float(self.prev_beta), int(self.params.num_forest_lines), int(self.params.k), float(z_qso),
-                x.dtype.str, x.tobytes(), wavelengths.dtype.str, wavelengths.tobytes(),
-            )
+        if type(self).M_interpolator is NullGP.M_interpolator and self._learned is not None and \
+                self.mu_interpolator is self._learned.mu_interpolator:
+            key = (self._learned.token, self._model_scalars(), int(self.params.k), float(z_qso),
+                   _content(x, wavelengths))
             hit = _INTERP_CACHE.get(key)
             if hit is not None:
-                self.this_mu, self.this_M, self.this_omega2 = hit
+                self._model_host, self._model_pending = list(hit), False
                 return
         this_mu = self.mu_interpolator(x)
         this_M = self.M_interpolator(x)
@@ -258,11 +446,31 @@ class NullGP:
         this_omega2 = this_omega2 * scaling ** 2
         this_omega2 = this_omega2 * lya_absorption ** 2
 
-        self.this_mu = this_mu
-        self.this_M = this_M
-        self.this_omega2 = this_omega2
+        self._model_host, self._model_pending = [this_mu, this_M, this_omega2], False
         if key is not None:
-            _INTERP_CACHE.put(key, learned, (this_mu, this_M, this_omega2))
+            _INTERP_CACHE.put(key, (this_mu, this_M, this_omega2))
+
+    # the model half on the host, on demand ----------------------------------------------------
+    def _model(self, index: int, name: str):
+        if self._model_host is None:
+            if not self._model_pending:
+                raise AttributeError("'{}' object has no attribute '{}' (set_data(build_model=True) or get_interp first)"
+                                     .format(type(self).__name__, name))
+            NullGP.get_interp(self, self.x, self.y, self.this_wavelengths, self.z_qso)
+        return self._model_host[index]
+
+    def _set_model(self, index: int, value) -> None:
+        if self._model_host is None:
+            if self._model_pending:
+                NullGP.get_interp(self, self.x, self.y, self.this_wavelengths, self.z_qso)
+            else:
+                self._model_host = [None, None, None]
+        self._model_host[index] = value
+        self._model_pending = False
+
+    this_mu = property(lambda self: self._model(0, "this_mu"), lambda self, value: self._set_model(0, value))
+    this_M = property(lambda self: self._model(1, "this_M"), lambda self, value: self._set_model(1, value))
+    this_omega2 = property(lambda self: self._model(2, "this_omega2"), lambda self, value: self._set_model(2, value))
 
     # ------------------------------------------------------------------------------------------
     # views (reference :244-292)
@@ -303,41 +511,74 @@ class NullGP:
     # device residency
     # ------------------------------------------------------------------------------------------
     def _invalidate_device(self) -> None:
-        if self._device_sightline is not None:
+        if self._device_sightline is not None and self._shared is None:
             self._device_sightline.close()
         self._device_sightline = None
         self._device_key = None
+        self._shared = None  # the sightline itself goes when the last GP object sharing it lets go
 
     def _keep_flags(self) -> np.ndarray:
         return ~self.pixel_mask[self.ind_unmasked]  # reference dla_gp.py:360
 
+    def _device_settings(self) -> tuple:
+        return (int(self.params.num_lines), bool(getattr(self, "broadening", True)), int(self.device),
+                bool(getattr(self, "lls_break", False)))
+
+    def _model_on_device_only(self) -> bool:
+        """the model half is still pending and everything about it is stock: the device can build it from the learned model"""
+        return (self._model_host is None and self._model_pending and self._learned is not None
+                and type(self).M_interpolator is NullGP.M_interpolator
+                and type(self).get_interp is NullGP.get_interp
+                and self.mu_interpolator is self._learned.mu_interpolator
+                and self.log_omega_interpolator is self._learned.log_omega_interpolator
+                and self.list_M_interpolators is self._learned.list_M_interpolators
+                and int(self.params.k) == self._learned.M_columns.shape[0])
+
     def device_sightline(self) -> _sl.DeviceSightline:
         """
-        The HBM-resident copy of this instance's post-set_data state.  Rebuilt when the arrays the
-        sweep reads were replaced (set_data / get_interp / attribute assignment) or when
-        `params.num_lines` / `broadening` changed.
+        The HBM-resident copy of this instance's post-set_data state.  What the sweep reads is compared by CONTENT on
+        every call (a memcmp of a few tens of KB), so replacing an array and editing one in place are both noticed
+        and the sightline is rebuilt: the device evaluates the instance's live arrays, as the reference does.
         """
-        broadening = bool(getattr(self, "broadening", True))
-        # identity (not equality) of the arrays: in-place edits of a loaded array are not tracked
-        arrays = (
-            self.y, self.v, self.this_mu, self.this_M, self.this_omega2, self.padded_wavelengths,
-            self.unmasked_wavelengths, self.pixel_mask, self.ind_unmasked,
-        )
-        settings = (int(self.params.num_lines), broadening, int(self.device), bool(getattr(self, "lls_break", False)))
-        stale = (
-            self._device_sightline is None
-            or self._device_key[1] != settings
-            or any(a is not b for a, b in zip(self._device_key[0], arrays))
-        )
-        if stale:
+        settings = self._device_settings()
+        broadening = settings[1]
+        grid = self.padded_wavelengths if broadening else self.unmasked_wavelengths
+        keep = self._keep_flags()
+        if self._model_on_device_only():
+            # built on the device from the learned model (dlagp_create_from_model), one sightline for every GP
+            # object of equal content: the reference's driver makes three per spectrum
+            key = (self._learned.token, self._model_scalars(), settings, float(self.z_qso),
+                   _content(self.x, self.y, self.v, self.this_wavelengths, grid, keep))
+            if self._shared is None or self._device_key != key:
+                self._invalidate_device()
+                model = self._learned.device_model(self._model_scalars(), settings[2])
+                x, y, v, wavelengths, z_qso = self.x, self.y, self.v, self.this_wavelengths, float(self.z_qso)
+                self._shared = _SHARED.find_or_make(key, lambda: _sl.DeviceSightline.from_model(
+                    model, x, y, v, wavelengths, z_qso, grid, keep, num_lines=settings[0], broadening=broadening,
+                    lls_break=settings[3]))
+                self._device_sightline = self._shared.dev
+                self._device_key = key
+            return self._device_sightline
+        # the model half exists on the host (read, assigned, computed by get_interp): that is what gets evaluated
+        key = (settings, _content(self.y, self.v, self.this_mu, self.this_M, self.this_omega2, grid, keep))
+        if self._device_sightline is None or self._shared is not None or self._device_key != key:
             self._invalidate_device()
-            grid = self.padded_wavelengths if broadening else self.unmasked_wavelengths
             self._device_sightline = _sl.DeviceSightline(
-                self.y, self.this_mu, self.this_M, self.this_omega2, self.v, grid, self._keep_flags(),
+                self.y, self.this_mu, self.this_M, self.this_omega2, self.v, grid, keep,
                 num_lines=settings[0], broadening=broadening, device=settings[2], lls_break=settings[3],
             )
-            self._device_key = (arrays, settings)
+            self._device_key = key
         return self._device_sightline
+
+    def device_batch(self):
+        """
+        (one-member DeviceBatch of `device_sightline()`, whether the caller must close it): the shared sightline keeps
+        one batch -- launch plans, partial-sum scratch, profile cache -- for all the sweeps of its GP objects.
+        """
+        dev = self.device_sightline()
+        if self._shared is not None:
+            return self._shared.batch, False
+        return _sl.DeviceBatch([dev]), True
 
     # ------------------------------------------------------------------------------------------
     # model evidence (reference :294-360) -- GPU

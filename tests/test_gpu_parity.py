@@ -1276,6 +1276,135 @@ def test_reference_driver_loop_with_swapped_imports_matches_golden():
     assert_catalogue_matches_golden(out, g, rtol=RTOL_LL)
 
 
+def route_a_models(spectrum, z_qso, S, learned=None, device=0):
+    """the reference driver's three GP objects for one spectrum (run_bayes_select.py:151-186), imports swapped"""
+    from gpy_dla_detection_amd.dla_gp import DLAGP
+    from gpy_dla_detection_amd.null_gp import NullGP
+    from gpy_dla_detection_amd.subdla_gp import SubDLAGP
+    from tests.test_host_logic import FixedPrior, catalogue_inputs
+
+    stock, _, _, param, dla_samples, subdla_samples = catalogue_inputs(S)
+    learned = tuple(stock)[:7] if learned is None else learned
+    prior = FixedPrior()
+    wavelengths, flux, noise_variance, pixel_mask = spectrum
+    rest = param.emitted_wavelengths(wavelengths, z_qso)
+    gp = NullGP(param, prior, *learned)
+    dla_gp = DLAGP(param, prior, dla_samples, *learned, min_z_separation=3000.0, broadening=True)
+    subdla_gp = SubDLAGP(param, prior, subdla_samples, *learned, min_z_separation=3000.0, broadening=True)
+    for model in (gp, dla_gp, subdla_gp):
+        model.set_data(rest, flux, noise_variance, pixel_mask, z_qso, build_model=True)
+    return gp, subdla_gp, dla_gp
+
+
+def test_the_three_gp_objects_of_a_spectrum_share_one_sightline_and_one_call():
+    """
+    Route A's per-spectrum cost: the three GP objects find ONE HBM-resident sightline (built on the device from the
+    learned model), and `BayesModelSelect.model_selection` sweeps the three models with one call into the library --
+    the same numbers, side effects and RNG state, bit for bit, as the model-by-model loop, and as three objects that
+    do not share (the model half read on the host first).
+    """
+    from gpy_dla_detection_amd import sightline as sl
+    from gpy_dla_detection_amd.bayesian_model_selection import BayesModelSelect
+    from tests.test_host_logic import catalogue_inputs
+
+    S, max_dlas = 512, 4
+    _, spectra, z_qsos, _, _, _ = catalogue_inputs(S)
+    calls = {"model_evidences": 0, "sweep": 0}
+    real_me, real_sweep = sl.DeviceBatch.model_evidences, sl.DeviceBatch.sweep
+
+    def counted(name, fn):
+        def wrapper(self, *a, **k):
+            calls[name] += 1
+            return fn(self, *a, **k)
+        return wrapper
+
+    sl.DeviceBatch.model_evidences = counted("model_evidences", real_me)
+    sl.DeviceBatch.sweep = counted("sweep", real_sweep)
+    try:
+        for spectrum, z_qso in zip(spectra, z_qsos):
+            models = route_a_models(spectrum, z_qso, S)
+            np.random.seed(0)
+            fused = BayesModelSelect([0, 1, max_dlas], 2)
+            fused.model_selection(list(models), z_qso)
+            state_fused = np.random.get_state()[1].copy()
+            assert models[0].device_sightline() is models[1].device_sightline() is models[2].device_sightline()
+            assert models[0]._shared is models[2]._shared and models[0]._shared.batch is models[1]._shared.batch
+            ll_fused = (models[1].sample_log_likelihoods.copy(), models[2].sample_log_likelihoods.copy(),
+                        models[2].base_sample_inds.copy())
+            assert ll_fused[1].shape == (S, max_dlas) and ll_fused[2].shape == (max_dlas - 1, S)
+            # the plain loop of the reference's model_selection on the same objects
+            np.random.seed(0)
+            loop = [models[0].log_model_evidence()] + list(models[1].log_model_evidences(1)) + \
+                list(models[2].log_model_evidences(max_dlas))
+            np.testing.assert_array_equal(fused.log_likelihoods, np.array(loop))
+            np.testing.assert_array_equal(np.random.get_state()[1], state_fused)
+            np.testing.assert_array_equal(models[1].sample_log_likelihoods, ll_fused[0])
+            np.testing.assert_array_equal(models[2].sample_log_likelihoods, ll_fused[1])
+            np.testing.assert_array_equal(models[2].base_sample_inds, ll_fused[2])
+            # objects whose model half was read on the host first: private sightlines from the host arrays, no fused call
+            private = route_a_models(spectrum, z_qso, S)
+            for m in private:
+                assert m.this_M.shape[1] == 20
+            np.random.seed(0)
+            apart = BayesModelSelect([0, 1, max_dlas], 2)
+            apart.model_selection(list(private), z_qso)
+            assert private[0].device_sightline() is not private[2].device_sightline() and private[0]._shared is None
+            np.testing.assert_allclose(apart.log_likelihoods, fused.log_likelihoods, rtol=1e-11)
+            np.testing.assert_array_equal(private[2].base_sample_inds, ll_fused[2])
+    finally:
+        sl.DeviceBatch.model_evidences, sl.DeviceBatch.sweep = real_me, real_sweep
+    assert calls["model_evidences"] == len(spectra) and calls["sweep"] == 4 * len(spectra)
+
+
+def test_in_place_edits_reach_the_device():
+    """
+    The reference reads live arrays at every call.  Here the sightline lives in HBM, so what the sweep reads is
+    compared by content on every call: an in-place edit of the spectrum (`gp.y[:] = ...`), of the model half, or of
+    the learned arrays between two constructions is evaluated, never a stale copy.
+    """
+    from tests.test_host_logic import catalogue_inputs
+
+    S = 256
+    learned, spectra, z_qsos, _, _, _ = catalogue_inputs(S)
+    learned = tuple(learned)[:7]
+    gp, sub, dla = route_a_models(spectra[0], z_qsos[0], S)
+    before = gp.log_model_evidence()
+    shared = gp._shared
+    assert shared is not None and dla.device_sightline() is gp.device_sightline()
+    gp.y[:] = 0.9 * gp.y  # in place: same array object
+    after = gp.log_model_evidence()
+    assert after != before and gp._shared is not shared
+    assert dla._shared is None or dla.device_sightline() is not gp.device_sightline()  # dla's own y is untouched
+    fresh, _, _ = route_a_models(spectra[0], z_qsos[0], S)
+    fresh.y = 0.9 * fresh.y  # the same data as a new array
+    assert fresh.log_model_evidence() == after
+    # the model half on the host: edits in place are seen too
+    mu = gp.this_mu  # materialised on the host now -> private sightline from these arrays
+    host = gp.log_model_evidence()
+    np.testing.assert_allclose(host, after, rtol=1e-12)
+    mu *= 1.01
+    edited = gp.log_model_evidence()
+    assert edited != host
+    twin, _, _ = route_a_models(spectra[0], z_qsos[0], S)
+    twin.y = 0.9 * twin.y
+    twin.this_mu = 1.01 * twin.this_mu
+    assert twin.log_model_evidence() == edited
+    # the learned factor edited in place between two constructions: the second object is another model on the device
+    rest_grid, mu_l, M_l, log_omega = (np.array(a, copy=True) for a in learned[:4])
+    mine = (rest_grid, mu_l, M_l, log_omega) + learned[4:]
+    first = route_a_models(spectra[1], z_qsos[1], S, learned=mine)[2]
+    ev_first = first.log_model_evidences(2)
+    M_l[[100, 200]] = M_l[[200, 100]]  # sum-preserving, same array object
+    M_l[:, 3] *= 1.5
+    second = route_a_models(spectra[1], z_qsos[1], S, learned=mine)[2]
+    np.random.seed(0)
+    ev_second = second.log_model_evidences(2)
+    assert not np.array_equal(ev_first, ev_second)
+    copy = route_a_models(spectra[1], z_qsos[1], S, learned=tuple(np.array(a, copy=True) for a in mine[:4]) + mine[4:])[2]
+    np.random.seed(0)
+    np.testing.assert_array_equal(copy.log_model_evidences(2), ev_second)
+
+
 def test_overridden_this_dla_gp_is_honoured_sample_by_sample():
     """
     The hook of reference examples/gp_find_lls.py:159-224: a subclass that overrides `this_dla_gp` changes

@@ -45,9 +45,10 @@ def test_set_data_and_get_interp_match_reference_golden():
 
 def test_get_interp_is_shared_between_the_gp_objects_of_a_spectrum():
     """
-    The driver's three GP objects per spectrum interpolate the same model onto the same pixels: the second and third
-    take the first one's result (their own copies, same layout, golden G7 to the last digit), and nothing is shared
-    across different pixels, redshifts, learned arrays or in-place edits of the model.
+    The driver's three GP objects per spectrum interpolate the same model onto the same pixels.  The model half is
+    produced on demand (first read of this_mu / this_M / this_omega2); the second and third object take the first
+    one's result (their own copies, same layout, golden G7 to the last digit), and nothing is shared across different
+    pixels, redshifts, learned arrays or in-place edits of the model.
     """
     from gpy_dla_detection_amd import null_gp
     from gpy_dla_detection_amd.null_gp import NullGP
@@ -57,15 +58,18 @@ def test_get_interp_is_shared_between_the_gp_objects_of_a_spectrum():
     params = Parameters()
     null_gp._INTERP_CACHE.entries.clear()
     gps = [NullGP(params, FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb) for _ in range(3)]
+    assert gps[0]._learned is gps[1]._learned is gps[2]._learned  # one learned model, recognised by content
+    assert gps[0].list_M_interpolators is gps[2].list_M_interpolators
     for gp in gps:
         gp.set_data(rest, flux, nv, mask, z_qso, normalize=True, build_model=True)
-    assert len(null_gp._INTERP_CACHE.entries) == 1  # one computation, two hits
+    assert len(null_gp._INTERP_CACHE.entries) == 0  # nothing interpolated until somebody asks
     for gp in gps:
         for name in ("this_mu", "this_M", "this_omega2"):
             np.testing.assert_allclose(getattr(gp, name), g[name], rtol=1e-14, atol=0, err_msg=name)
             np.testing.assert_array_equal(getattr(gp, name), getattr(gps[0], name))
         assert gp.this_M.flags["F_CONTIGUOUS"]
-    assert gps[1].this_M is not gps[0].this_M
+    assert len(null_gp._INTERP_CACHE.entries) == 1  # one computation, two hits
+    assert gps[1].this_M is not gps[0].this_M and gps[1].this_M is gps[1].this_M
     gps[1].this_mu[:] = 0.0  # a caller's edit stays the caller's
     assert gps[0].this_mu[0] != 0.0 and gps[2].this_mu[0] != 0.0
     fresh = NullGP(params, FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb)
@@ -74,18 +78,85 @@ def test_get_interp_is_shared_between_the_gp_objects_of_a_spectrum():
     # other pixels / another redshift / another model: computed, not looked up
     other = NullGP(params, FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb)
     other.set_data(rest, flux, nv, mask, z_qso + 0.01)
-    assert len(null_gp._INTERP_CACHE.entries) == 2 and not np.array_equal(other.this_mu, fresh.this_mu)
+    assert not np.array_equal(other.this_mu, fresh.this_mu) and len(null_gp._INTERP_CACHE.entries) == 2
     scaled = NullGP(params, FixedPrior(), rest_grid, 2.0 * mu, M, log_omega, lc0, lt0, lb)
+    assert scaled._learned is not fresh._learned
     scaled.set_data(rest, flux, nv, mask, z_qso)
     np.testing.assert_allclose(scaled.this_mu, 2.0 * fresh.this_mu, rtol=1e-15)
-    edited = mu.copy()
-    first = NullGP(params, FixedPrior(), rest_grid, edited, M, log_omega, lc0, lt0, lb)
-    first.set_data(rest, flux, nv, mask, z_qso)
-    edited *= 3.0  # in place, same array object
-    second = NullGP(params, FixedPrior(), rest_grid, edited, M, log_omega, lc0, lt0, lb)
-    second.set_data(rest, flux, nv, mask, z_qso)
-    np.testing.assert_allclose(second.this_mu, 3.0 * first.this_mu, rtol=1e-15)
     assert len(null_gp._INTERP_CACHE.entries) <= null_gp._INTERP_CACHE.size
+
+
+def test_in_place_edits_of_the_learned_model_are_noticed_like_the_reference_does():
+    """
+    The reference's interp1d objects copy the learned arrays when a GP object is constructed (null_gp.py:67-71):
+    an edit made in place BEFORE the next construction is a different model for the next object -- also when it
+    preserves the sum (a permutation, offsetting changes), which a checksum of sums would miss -- and an edit made
+    AFTER an object's construction does not change that object's interpolation.
+    """
+    from gpy_dla_detection_amd.null_gp import NullGP
+
+    z_qso, rest, flux, nv, mask, rest_grid, mu, M, log_omega, lc0, lt0, lb = raw_spectrum_and_model()
+    params = Parameters()
+    mu, M, log_omega = mu.copy(), np.array(M, copy=True), log_omega.copy()
+
+    def this_model(*arrays):
+        gp = NullGP(params, FixedPrior(), rest_grid, *arrays, lc0, lt0, lb)
+        gp.set_data(rest, flux, nv, mask, z_qso)
+        return gp, (gp.this_mu.copy(), gp.this_M.copy(), gp.this_omega2.copy())
+
+    first, before = this_model(mu, M, log_omega)
+    M[[100, 200]] = M[[200, 100]]  # in place, same array object, same sum
+    mu[300] += 0.25
+    mu[301] -= 0.25  # offsetting changes
+    second, after = this_model(mu, M, log_omega)
+    assert second._learned is not first._learned
+    assert not np.array_equal(after[1], before[1]) and not np.array_equal(after[0], before[0])
+    np.testing.assert_array_equal(after[2], before[2])
+    fresh, want = this_model(mu.copy(), M.copy(), log_omega.copy())  # the edited content, brand-new arrays
+    assert fresh._learned is second._learned
+    for a, b in zip(after, want):
+        np.testing.assert_array_equal(a, b)
+    # an edit after construction is not seen by the existing object (interp1d copied), a new spectrum included
+    M *= 2.0
+    second.set_data(rest, flux, nv, mask, z_qso + 0.001)
+    ref, want = this_model(mu, 0.5 * M, log_omega)
+    ref.set_data(rest, flux, nv, mask, z_qso + 0.001)
+    np.testing.assert_array_equal(second.this_M, ref.this_M)
+    # rest grid edits count too
+    grid2 = rest_grid.copy()
+    third, _ = this_model(mu, M, log_omega)
+    grid2[5] += 1e-3
+    fourth = NullGP(params, FixedPrior(), grid2, mu, M, log_omega, lc0, lt0, lb)
+    assert fourth._learned is not third._learned
+
+
+def test_model_attributes_follow_the_reference_life_cycle():
+    from gpy_dla_detection_amd.null_gp import NullGP
+
+    z_qso, rest, flux, nv, mask, rest_grid, mu, M, log_omega, lc0, lt0, lb = raw_spectrum_and_model()
+    gp = NullGP(Parameters(), FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb)
+    gp.set_data(rest, flux, nv, mask, z_qso, build_model=False)
+    with pytest.raises(AttributeError):  # the reference has not created them either
+        gp.this_mu
+    gp.get_interp(gp.x, gp.y, gp.this_wavelengths, gp.z_qso)
+    want = gp.this_mu.copy()
+    gp.set_data(rest, flux, nv, mask, z_qso)
+    np.testing.assert_array_equal(gp.this_mu, want)
+    gp.this_mu = 2.0 * want  # assignment sticks, the other two are still there
+    np.testing.assert_array_equal(gp.this_mu, 2.0 * want)
+    assert gp.this_M.shape == (want.shape[0], 20) and not gp._model_on_device_only()
+    # pixels outside the learned grid fail in set_data, where interp1d fails in the reference
+    narrow = NullGP(Parameters(), FixedPrior(), rest_grid[100:], mu[100:], M[100:], log_omega[100:], lc0, lt0, lb)
+    with pytest.raises(ValueError, match="below the interpolation range"):
+        narrow.set_data(rest, flux, nv, mask, z_qso)
+
+    class OwnModelHalf(NullGP):
+        def get_interp(self, x, y, wavelengths, z_qso):
+            self.this_mu, self.this_M, self.this_omega2 = np.ones_like(x), np.zeros((x.shape[0], 20)), np.ones_like(x)
+
+    own = OwnModelHalf(Parameters(), FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb)
+    own.set_data(rest, flux, nv, mask, z_qso)
+    assert np.all(own.this_mu == 1.0) and not own._model_on_device_only()
 
 
 def test_parameters_surface():
