@@ -298,6 +298,9 @@ static std::map<int, std::vector<Workspace>> g_spare_workspace;
 static Option g_opt_spare_workspaces = 5;
 static Option g_opt_shared_work_stream = 0;
 static Option g_opt_shared_rows = 1;  // cached levels: a wave whose samples stack the same cached row reads it once
+// test hook: contexts with a negative noise variance stay on the MFMA kernel (default: they take the generic kernel, whose
+// per-pixel log(d) is NaN for any negative d as in the reference) -- the tests of that kernel's non-PD flag need them
+static Option g_opt_negative_noise_mfma = 0;
 
 // Decomposition of one MFMA launch (a launch group at one sample count) into work items, see build_plan
 struct LaunchPlan {
@@ -405,6 +408,8 @@ struct dlagp_ctx {
     DeviceBuffer dense_M;      // interpolated / uploaded factor, row-major [n][k], kept for dlagp_ctx_read_model
     DeviceBuffer scratch_a, scratch_b;  // inputs of the set-up kernels, released once the set-up stream has drained
     bool setup_pending = false;         // created with DLAGP_FLAG_DEFER_SYNC and not known to be complete yet
+    hipEvent_t setup_event = nullptr;   // ... recorded behind the set-up work on the creating thread's set-up stream
+    bool negative_noise = false;        // v or omega2 has a negative entry: d = omega2 a^2 + v may be negative
     std::vector<int> h_pos;    // host copy of pos[]
     std::vector<int> h_slot_pos;  // window start of every slot (padding slots repeat their chunk's last pixel), for planning
     bool mfma_ok = false;      // rank padded to 20
@@ -681,13 +686,60 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
 // calls of different threads then run strictly one after the other.  Measured on the catalogue driver it makes no
 // difference (the device serialises two full-size launches anyway; profiles/r03_experiments.txt item 15), so the
 // default stays 0.
-static hipStream_t work_stream(int device) {
-    static thread_local std::map<int, hipStream_t> streams;
-    auto it = streams.find(device);
-    if (it != streams.end()) return it->second;
+// Streams and staging memory of a host thread are BORROWED from process-wide free lists and handed back when the thread
+// ends (thread_local holders' destructors, which make no HIP call: at process exit the runtime may already be gone).
+// The catalogue driver starts five fresh worker threads per call; with per-thread streams and arenas that were never
+// returned, a long-lived process lost two streams and >= 4 MB of page-locked memory per thread ever started.
+struct StreamPool {
+    std::mutex mutex;
+    std::map<std::pair<int, int>, std::vector<hipStream_t>> free;  // (device, kind) -> idle streams
+};
+static StreamPool &stream_pool() {
+    static StreamPool *pool = new StreamPool();  // never destroyed: thread_local destructors may run after statics'
+    return *pool;
+}
+enum { STREAM_WORK = 0, STREAM_SETUP = 1 };
+
+static hipStream_t borrow_stream(int device, int kind) {
+    {
+        StreamPool &pool = stream_pool();
+        std::lock_guard<std::mutex> lock(pool.mutex);
+        auto &idle = pool.free[{device, kind}];
+        if (!idle.empty()) {
+            hipStream_t s = idle.back();
+            idle.pop_back();
+            return s;
+        }
+    }
     hipStream_t s = nullptr;
+    if (kind == STREAM_SETUP) {
+        // highest priority: the set-up kernels are tiny, and behind a sweep's long-running waves they otherwise wait
+        // for wave slots while a host thread sits in the synchronisation that ends every context creation
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+            hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) == hipSuccess)
+            return s;
+    }
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;  // fall back to the null stream
-    streams[device] = s;
+    return s;
+}
+
+struct ThreadStreams {
+    std::map<int, hipStream_t> streams;
+    ~ThreadStreams() {
+        StreamPool &pool = stream_pool();
+        std::lock_guard<std::mutex> lock(pool.mutex);
+        for (auto &kv : streams)
+            if (kv.second) pool.free[{kv.first, STREAM_WORK}].push_back(kv.second);
+    }
+};
+
+static hipStream_t work_stream(int device) {
+    static thread_local ThreadStreams mine;
+    auto it = mine.streams.find(device);
+    if (it != mine.streams.end()) return it->second;
+    hipStream_t s = borrow_stream(device, STREAM_WORK);
+    mine.streams[device] = s;
     return s;
 }
 
@@ -916,38 +968,89 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
 // stream: a second host thread can then build the next batch's contexts while the first is inside a sweep --
 // uploads and set-up kernels no longer queue behind the sweep's kernels, nor does hipDeviceSynchronize wait for
 // them.
-static hipStream_t setup_stream(int device) {
-    static thread_local std::map<int, hipStream_t> streams;
-    auto it = streams.find(device);
-    if (it != streams.end()) return it->second;
-    // highest priority: the set-up kernels are tiny, and behind a sweep's long-running waves they otherwise wait for
-    // wave slots while a host thread sits in the synchronisation that ends every context creation
-    hipStream_t s = nullptr;
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
-        hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) != hipSuccess)
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;  // fall back to the null stream
-    streams[device] = s;
-    return s;
+// (the stream and the page-locked arena travel together as a "lane": a thread borrows one per device, see above)
+struct SetupLane {
+    hipStream_t stream = nullptr;
+    PinnedBuffer buf;  // Host -> device staging, see upload_staged
+    size_t used = 0;
+    bool dirty = false;  // handed back with copies possibly still reading the arena: the next borrower waits first
+};
+struct LanePool {
+    std::mutex mutex;
+    std::map<int, std::vector<SetupLane *>> free;
+};
+static LanePool &lane_pool() {
+    static LanePool *pool = new LanePool();
+    return *pool;
 }
+struct ThreadLanes {
+    std::map<int, SetupLane *> lanes;
+    ~ThreadLanes() {
+        LanePool &pool = lane_pool();
+        std::lock_guard<std::mutex> lock(pool.mutex);
+        for (auto &kv : lanes) {
+            kv.second->dirty = true;
+            pool.free[kv.first].push_back(kv.second);
+        }
+    }
+};
+static SetupLane &setup_lane(int device) {
+    static thread_local ThreadLanes mine;
+    auto it = mine.lanes.find(device);
+    if (it != mine.lanes.end()) return *it->second;
+    SetupLane *lane = nullptr;
+    {
+        LanePool &pool = lane_pool();
+        std::lock_guard<std::mutex> lock(pool.mutex);
+        auto &idle = pool.free[device];
+        if (!idle.empty()) {
+            lane = idle.back();
+            idle.pop_back();
+        }
+    }
+    if (!lane) {
+        lane = new SetupLane();
+        lane->stream = borrow_stream(device, STREAM_SETUP);
+    } else if (lane->dirty) {
+        (void)hipStreamSynchronize(lane->stream);  // the previous owner's last copies have left the arena
+        lane->used = 0;
+        lane->dirty = false;
+    }
+    mine.lanes[device] = lane;
+    return *lane;
+}
+static hipStream_t setup_stream(int device) { return setup_lane(device).stream; }
 
 // Host -> device on the set-up stream WITHOUT a synchronisation per array: the bytes are copied into a page-locked
 // arena of the calling thread (so the source may be a temporary) and go out as one asynchronous copy each; the arena
 // is recycled by setup_sync(), which every set-up sequence ends with.  (Context creation used to synchronise the
 // stream eleven times -- once per array -- which was 0.6 ms per spectrum and the catalogue driver's bottleneck.)
-struct SetupArena {
-    PinnedBuffer buf;
-    size_t used = 0;
-};
-static SetupArena &setup_arena(int device) {
-    static thread_local std::map<int, SetupArena> arenas;
-    return arenas[device];
-}
+typedef SetupLane SetupArena;
+static SetupArena &setup_arena(int device) { return setup_lane(device); }
 
 // all staged uploads and kernels of the calling thread's set-up stream are complete on return
 static int setup_sync(int device) {
     HIP_TRY(hipStreamSynchronize(setup_stream(device)));
     setup_arena(device).used = 0;
+    return DLAGP_OK;
+}
+
+// A context created with DLAGP_FLAG_DEFER_SYNC carries an event recorded behind its set-up work on the CREATING thread's
+// set-up stream.  Whoever uses the context first -- a batch built from it, possibly on another thread, an evaluation,
+// dlagp_ctx_read_model, dlagp_destroy -- waits for that event; nothing rests on "the same thread synchronised its
+// stream".
+static int wait_setup(dlagp_ctx *ctx) {
+    if (!ctx->setup_pending) return DLAGP_OK;
+    if (ctx->setup_event) {
+        HIP_TRY(hipEventSynchronize(ctx->setup_event));
+        (void)hipEventDestroy(ctx->setup_event);
+        ctx->setup_event = nullptr;
+    } else {
+        HIP_TRY(hipDeviceSynchronize());  // no event could be recorded: the device-wide wait covers every stream
+    }
+    ctx->setup_pending = false;
+    ctx->scratch_a.release();
+    ctx->scratch_b.release();
     return DLAGP_OK;
 }
 
@@ -1137,6 +1240,11 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
         dlagp_destroy(ctx);
         return rc;
     }
+    // Invalid input the reference answers with NaN or LinAlgError: with a negative noise variance d = omega2 a^2 + v can
+    // be negative, and np.log(d) (null_gp.py:356) is NaN for ANY negative pixel.  The MFMA kernel's running product of
+    // d would turn an even number of negative pixels into a finite number, so such a sightline takes the generic kernel,
+    // which takes the logarithm pixel by pixel as the reference does.
+    if (ctx->negative_noise && !g_opt_negative_noise_mfma) ctx->mfma_ok = false;
     sl.y = ctx->y.as<double>();
     sl.mu = ctx->mu.as<double>();
     sl.omega2 = ctx->omega2.as<double>();
@@ -1168,6 +1276,13 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     // building (DLAGP_FLAG_DEFER_SYNC); the kernels' temporaries then stay with the context until it is destroyed
     rc = finish_group(ctx->self, nullptr, defer_sync);
     ctx->setup_pending = defer_sync;
+    if (defer_sync && !rc) {
+        if (hipEventCreateWithFlags(&ctx->setup_event, hipEventDisableTiming) != hipSuccess ||
+            hipEventRecord(ctx->setup_event, setup) != hipSuccess) {
+            if (ctx->setup_event) (void)hipEventDestroy(ctx->setup_event);
+            ctx->setup_event = nullptr;  // wait_setup falls back to a device-wide wait
+        }
+    }
     if (!defer_sync) {
         ctx->scratch_a.release();
         ctx->scratch_b.release();
@@ -1210,6 +1325,7 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
     if (!y || !mu || !M || !omega2 || !v) return fail(DLAGP_EINVAL, "NULL input array");
     return create_context(out, n, n_u, k, wavelengths, keep, num_lines, broadening, device, [&](dlagp_ctx *ctx) -> int {
         const SightlineDev &sl = ctx->sl;
+        for (int i = 0; i < n; ++i) ctx->negative_noise = ctx->negative_noise || omega2[i] < 0.0 || v[i] < 0.0;
         int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0, ctx->device);
         if (!rc) rc = upload_padded(ctx->mu, mu, n, sl.n_pad, 0.0, ctx->device);
         if (!rc) rc = upload_padded(ctx->omega2, omega2, n, sl.n_pad, 0.0, ctx->device);
@@ -1314,6 +1430,7 @@ int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, in
                           [&](dlagp_ctx *ctx) -> int {
         const SightlineDev &sl = ctx->sl;
         const hipStream_t setup = setup_stream(ctx->device);
+        for (int i = 0; i < n; ++i) ctx->negative_noise = ctx->negative_noise || v[i] < 0.0;  // omega2 = exp(..) >= 0
         int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0, ctx->device);
         if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0, ctx->device);
         if (rc) return rc;
@@ -1338,6 +1455,7 @@ int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, in
 int dlagp_ctx_read_model(dlagp_ctx *ctx, double *this_mu, double *this_M, double *this_omega2) {
     if (!ctx) return fail(DLAGP_EINVAL, "context is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = wait_setup(ctx)) return rc;
     const int n = ctx->sl.n, k = ctx->user_k, ks = ctx->sl.k;
     if (this_mu) HIP_TRY(hipMemcpy(this_mu, ctx->mu.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     if (this_omega2) HIP_TRY(hipMemcpy(this_omega2, ctx->omega2.ptr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1354,8 +1472,9 @@ void dlagp_destroy(dlagp_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     // deferred set-up (DLAGP_FLAG_DEFER_SYNC) that nobody waited for: its copies and kernels may still be writing the
-    // buffers released below.  The creating thread's stream is not known here: wait for the device.
-    if (ctx->setup_pending) (void)hipDeviceSynchronize();
+    // buffers released below
+    (void)wait_setup(ctx);
+    if (ctx->setup_event) (void)hipEventDestroy(ctx->setup_event);
     {
         // batches are meant to be destroyed before their members; if one is still alive, its launches may be using
         // this context's arrays
@@ -1411,12 +1530,14 @@ int dlagp_eval(dlagp_ctx *ctx, int64_t S, int kd, const double *z, const double 
     if (rc) return rc;
     if (S == 0) return DLAGP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = wait_setup(ctx))) return rc;
     return sweep_from_host(ctx->self, S, kd, z, nhi, out);
 }
 
 int dlagp_null(dlagp_ctx *ctx, double *out) {
     if (!ctx || !out) return fail(DLAGP_EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = wait_setup(ctx)) return rc;
     return sweep_from_host(ctx->self, 1, 0, nullptr, nullptr, out);
 }
 
@@ -1441,6 +1562,7 @@ int dlagp_absorption(dlagp_ctx *ctx, int kd, const double *z, const double *nhi,
     int rc = check_eval_args(ctx, 1, kd, z, nhi, out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = wait_setup(ctx))) return rc;
     LaunchGroup &g = ctx->self;
     Workspace &ws = g.ws;
     if ((rc = grow(g, ws.z, kd * sizeof(double)))) return rc;
@@ -1467,6 +1589,7 @@ int dlagp_eval_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, cons
     int rc = check_eval_args(ctx, S, kd, d_z, d_nhi, d_out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = wait_setup(ctx))) return rc;
     return launch_sweep(ctx->self, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0}, d_out,
                         static_cast<hipStream_t>(stream));
 }
@@ -1498,9 +1621,11 @@ int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
         std::lock_guard<std::mutex> lock(g_membership_mutex);
         for (dlagp_ctx *ctx : batch->group.ctxs) ctx->batches.push_back(batch);
     }
-    int rc = finish_group(batch->group);  // synchronises the calling thread's set-up stream: deferred members are complete
-    if (!rc)
-        for (dlagp_ctx *ctx : batch->group.ctxs) ctx->setup_pending = false;
+    // deferred members are complete once their own events have fired -- whichever thread created them
+    int rc = DLAGP_OK;
+    for (dlagp_ctx *ctx : batch->group.ctxs)
+        if (!rc) rc = wait_setup(ctx);
+    if (!rc) rc = finish_group(batch->group);  // synchronises the calling thread's set-up stream (the batch's table)
     if (!rc) rc = split_mixed_batch(batch->group);
     if (rc) {
         dlagp_batch_destroy(batch);
@@ -1849,6 +1974,7 @@ int dlagp_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "spare_workspaces")) g_opt_spare_workspaces = value;
     else if (!strcmp(name, "shared_work_stream")) g_opt_shared_work_stream = value != 0;
     else if (!strcmp(name, "shared_rows")) g_opt_shared_rows = value != 0;
+    else if (!strcmp(name, "negative_noise_mfma")) g_opt_negative_noise_mfma = value != 0;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 }
@@ -1888,6 +2014,7 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spare_workspaces")) *value = g_opt_spare_workspaces;
     else if (!strcmp(name, "shared_work_stream")) *value = g_opt_shared_work_stream;
     else if (!strcmp(name, "shared_rows")) *value = g_opt_shared_rows;
+    else if (!strcmp(name, "negative_noise_mfma")) *value = g_opt_negative_noise_mfma;
     else if (!strcmp(name, "big_allocs")) *value = g_stat_big_allocs;
     else if (!strcmp(name, "big_frees")) *value = g_stat_big_frees;
     else if (!strcmp(name, "last_launch_path")) *value = g_last_launch_path;

@@ -91,9 +91,8 @@ class DeviceSightline:
         noise are interpolated from `model` at the kept pixels' rest wavelengths `x` and suppressed by
         the Lyman-series mean flux at the observed `this_wavelengths` (reference null_gp.py:179-242).
 
-        `defer_sync` (batch drivers): do not wait for the context's set-up work; the sightline may only be used after
-        THIS thread has built a `DeviceBatch` with it (or called `setup_sync`) -- one wait per batch instead of one per
-        spectrum.
+        `defer_sync` (batch drivers): do not wait for the context's set-up work -- its first use (a `DeviceBatch`
+        built with it, an evaluation, on any thread) waits for it: one wait per batch instead of one per spectrum.
         """
         lib = _lib.load()
         x, y, v, this_wavelengths = (_lib.as_f64(a) for a in (x, y, v, this_wavelengths))

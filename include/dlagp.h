@@ -60,12 +60,13 @@ extern "C" {
                                    generic one */
 #define DLAGP_FLAG_DEFER_SYNC 4 /* batch drivers: return without waiting for the context's uploads
                                    and set-up kernels (they run on the calling thread's set-up
-                                   stream).  The context may only be USED after the same thread has
-                                   created a batch with it (dlagp_batch_create ends with the one
-                                   synchronisation that covers all its members) or called
-                                   dlagp_setup_sync; destroying it is always safe.  Creating the
-                                   contexts of a catalogue batch costs one wait instead of one per
-                                   spectrum (each wait queues behind the running sweep's waves) */
+                                   stream, and an event recorded behind them stays with the context).
+                                   Whoever uses the context first -- dlagp_batch_create with it as a
+                                   member, an evaluation, dlagp_ctx_read_model, dlagp_destroy, on ANY
+                                   host thread -- waits for that event, so no rule about threads has
+                                   to be kept.  Creating the contexts of a catalogue batch costs one
+                                   wait instead of one per spectrum (each wait queues behind the
+                                   running sweep's waves) */
 
 typedef struct dlagp_ctx dlagp_ctx;     /* one sightline's model + data, resident in HBM    */
 typedef struct dlagp_batch dlagp_batch; /* a launch group of sightlines on one device       */
@@ -141,7 +142,8 @@ void dlagp_model_destroy(dlagp_model *model);
  * num_lines / broadening as in dlagp_create.  A rest wavelength outside the model grid returns
  * DLAGP_EINVAL (scipy's interp1d raises ValueError there).  The context lives on the model's device.
  */
-/* waits for the calling thread's pending context set-up work on `device` (see DLAGP_FLAG_DEFER_SYNC) */
+/* waits for the calling thread's pending context set-up work on `device` (optional: contexts created with
+ * DLAGP_FLAG_DEFER_SYNC are waited for at their first use anyway) */
 int dlagp_setup_sync(int device);
 
 int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, int n_u,

@@ -421,8 +421,10 @@ def test_batch_of_mixed_flavours_runs_as_homogeneous_mfma_groups(restore_options
     batch.close()
     # a member whose B = I + M' D^-1 M is indefinite, in a launch group that is not the last: the later ones must not clear the flag
     bad = sights[4]
+    set_option("negative_noise_mfma", 1)  # keep the invalid member on the MFMA kernel: its non-PD flag is under test
     neg = DeviceSightline(bad.y, bad.this_mu, 10.0 * bad.this_M, bad.this_omega2, -np.abs(bad.v), bad.padded_wavelengths,
                           bad.keep)
+    set_option("negative_noise_mfma", 0)
     mixed = DeviceBatch([neg, devs[1], devs[2]])
     with pytest.raises(np.linalg.LinAlgError):
         mixed.eval(zs[[4, 1, 2]], ns[[4, 1, 2]])
@@ -534,8 +536,10 @@ def test_model_evidences_in_one_call_equal_the_three_calls(restore_options):
 
     # a member with an indefinite B: whichever model meets it first, the call reports it
     bad = sights[0]
+    set_option("negative_noise_mfma", 1)
     neg = DeviceSightline(bad.y, bad.this_mu, 10.0 * bad.this_M, bad.this_omega2, -np.abs(bad.v), bad.padded_wavelengths,
                           bad.keep)
+    set_option("negative_noise_mfma", 0)
     mixed = DeviceBatch([devs[1], neg])
     with pytest.raises(np.linalg.LinAlgError):
         mixed.model_evidences(z_sub[[1, 0]], nhi_sub, zs[[1, 0]], nhi, max_dlas, min_sep, uniforms[:2])
@@ -653,6 +657,7 @@ def restore_options():
     set_option("core_patch", 1)
     set_option("shared_work_stream", 0)
     set_option("shared_rows", 1)
+    set_option("negative_noise_mfma", 0)
 
 
 @pytest.mark.parametrize("shape", [dict(index=4, n_unmasked=1250, n_masked=28, k=20),
@@ -1181,6 +1186,110 @@ def test_deferred_context_set_up_completes_with_the_batch():
     for _ in range(20):  # never waited for: destroy must cope
         make(True).close()
     assert abs(make(False).null() - want_null[0]) <= 1e-13 * abs(want_null[0])
+
+
+def test_deferred_contexts_may_cross_threads():
+    """
+    The deferred set-up is self-enforcing: every context carries an event recorded behind its set-up work on the
+    creating thread's stream, and its first use waits for it -- a batch built on ANOTHER thread, or a plain evaluation
+    with no synchronisation call in between -- so the numbers are those of contexts created one wait at a time.
+    """
+    import threading
+
+    from gpy_dla_detection_amd.null_gp import NullGP
+    from gpy_dla_detection_amd.set_parameters import Parameters
+    from gpy_dla_detection_amd.sightline import DeviceBatch, DeviceModel, DeviceSightline
+    from tests.golden_inputs import raw_spectrum_and_model
+
+    z_qso, rest, flux, nv, mask, rest_grid, mu, M, log_omega, lc0, lt0, lb = raw_spectrum_and_model()
+    params = Parameters()
+    host = NullGP(params, FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb)
+    host.set_data(rest, flux, nv, mask, z_qso, normalize=True, build_model=False)
+    model = DeviceModel(rest_grid, mu, np.asfortranarray(M), log_omega, lc0, lt0, lb, num_forest_lines=params.num_forest_lines)
+    keep = ~host.pixel_mask[host.ind_unmasked]
+
+    def make(defer, scale):
+        return DeviceSightline.from_model(model, host.x, scale * host.y, host.v, host.this_wavelengths, z_qso,
+                                          host.padded_wavelengths, keep, defer_sync=defer)
+
+    S, nb = 200, 12
+    z = np.tile(2.2 + 0.5 * halton(S, 2), (nb, 1))
+    nhi = np.tile(10.0 ** (20.0 + 2.5 * halton(S, 3)), (nb, 1))
+    waited = DeviceBatch([make(False, 1.0 + 0.01 * i) for i in range(nb)])
+    want, want_null = waited.eval(z, nhi), waited.nulls()
+    for _ in range(5):
+        made, got = [], {}
+
+        def creator():
+            made.extend(make(True, 1.0 + 0.01 * i) for i in range(nb))
+
+        a = threading.Thread(target=creator)
+        a.start()
+        a.join()  # thread A is gone; nobody synchronised its stream
+
+        def user():
+            batch = DeviceBatch(made)
+            got["ll"], got["null"] = batch.eval(z, nhi), batch.nulls()
+            batch.close()
+
+        b = threading.Thread(target=user)
+        b.start()
+        b.join()
+        np.testing.assert_array_equal(got["ll"], want)
+        np.testing.assert_array_equal(got["null"], want_null)
+        for dev in made:
+            dev.close()
+    # a deferred context used directly: its first evaluation waits for its event
+    for i in range(10):
+        single = make(True, 1.0 + 0.01 * (i % nb))
+        assert single.null() == want_null[i % nb]
+        single.close()
+    mu_back = make(True, 1.0).read_model()[0]
+    np.testing.assert_array_equal(mu_back, make(False, 1.0).read_model()[0])
+
+
+def test_negative_noise_variance_is_nan_or_linalgerror_like_the_reference():
+    """
+    Invalid input, reference semantics: with a negative noise variance d = omega2 a^2 + v is negative at some pixels
+    and `np.log(d)` (null_gp.py:356) makes the density NaN -- for ANY number of negative pixels -- unless B stops being
+    positive definite first (LinAlgError, null_gp.py:343).  A running product of d (the MFMA kernel) would turn an even
+    number of negative pixels into a finite number, so such a sightline runs on the generic kernel.
+    """
+    import warnings
+
+    from gpy_dla_detection_amd.sightline import DeviceBatch, DeviceSightline, get_option, log_mvnpdf_low_rank
+    from oracle import ref_like as R
+
+    sight = make_sightline(3, n_unmasked=900, n_masked=20)
+    z, _, nhi = make_qmc_samples(sight, 96)
+    for count in (1, 2, 4):  # odd and even numbers of negative pixels
+        v = sight.v.copy()
+        pixels = np.arange(count) * 37 + 100
+        v[pixels] = -(sight.this_omega2[pixels] + 1.0)  # d = -1 there for the null model, B stays positive definite
+        dev = DeviceSightline(sight.y, sight.this_mu, sight.this_M, sight.this_omega2, v, sight.padded_wavelengths, sight.keep)
+        st = R.SpectrumState(sight.y, v, sight.this_mu, sight.this_M, sight.this_omega2, sight.padded_wavelengths,
+                             sight.unmasked_wavelengths, sight.keep)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want_null = R.null_log_model_evidence(st)
+            want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in range(8)])
+        assert np.isnan(want_null) and np.all(np.isnan(want))  # the reference's answer
+        assert np.isnan(dev.null())
+        got = dev.eval(z, nhi)
+        assert get_option("last_launch_path") == 1 and np.all(np.isnan(got))
+        clean = DeviceSightline.from_state(sight)
+        both = DeviceBatch([clean, dev]).eval(np.stack([z, z]), np.stack([nhi, nhi]))
+        np.testing.assert_allclose(both[0], clean.eval(z, nhi), rtol=1e-9)  # the valid member is untouched
+        assert np.all(np.isnan(both[1]))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert np.isnan(log_mvnpdf_low_rank(sight.y, sight.this_mu, sight.this_M, sight.this_omega2 + v))
+    # a negative variance large enough to make B indefinite: LinAlgError, as from np.linalg.cholesky
+    neg = DeviceSightline(sight.y, sight.this_mu, 10.0 * sight.this_M, sight.this_omega2, -np.abs(sight.v),
+                          sight.padded_wavelengths, sight.keep)
+    with pytest.raises(np.linalg.LinAlgError):
+        neg.eval(z, nhi)
+    assert get_option("last_launch_path") == 1
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1926,8 +2035,10 @@ def test_both_finalisations_give_the_same_numbers(restore_options):
     for i in (0, 17, 4999, 9999):
         want = R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]])
         assert abs(wide[i] - want) <= RTOL_LL * abs(want)
+    set_option("negative_noise_mfma", 1)
     neg = DeviceSightline(sight.y, sight.this_mu, 10.0 * sight.this_M, sight.this_omega2, -np.abs(sight.v),
                           sight.padded_wavelengths, sight.keep)
+    set_option("negative_noise_mfma", 0)
     for blocks in (default, 0):
         set_option("finalize_row16_blocks", blocks)
         try:

@@ -1,9 +1,10 @@
 set -x
 mkdir -p gpurun_out/r4
-cat /sys/fs/cgroup/cpu.max > gpurun_out/r4/cpuinfo.txt 2>&1
-nproc >> gpurun_out/r4/cpuinfo.txt; uptime >> gpurun_out/r4/cpuinfo.txt
-python bench.py --cpu-baseline-only > gpurun_out/r4/cpu_a.json 2> gpurun_out/r4/cpu_a.err
-python bench.py --cpu-baseline-only > gpurun_out/r4/cpu_b.json 2> gpurun_out/r4/cpu_b.err
-python bench.py > gpurun_out/r4/bench_default.json 2> gpurun_out/r4/bench_default.err && \
-timeout -k 10 1000 python -m pytest tests/test_gpu_distributed.py -x -q -m gpu > gpurun_out/r4/dist_tests.log 2>&1
-tail -5 gpurun_out/r4/dist_tests.log
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --memory-copy-trace --stats -d gpurun_out/r4/prof_route_a -o ra -- python3 tools/measure_route_a.py 64 > gpurun_out/r4/route_a_traced.json 2> gpurun_out/r4/route_a_traced.err
+ls gpurun_out/r4/prof_route_a/ > gpurun_out/r4/prof_ls.txt 2>&1
+f=$(ls gpurun_out/r4/prof_route_a/*kernel_trace.csv | head -1)
+python tools/trace_busy.py $f --window 0.14 > gpurun_out/r4/route_a_busy.txt 2>&1
+find gpurun_out/r4/prof_route_a -name "*trace.csv" -size +20M -delete
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/r4/gpu_tests.log 2>&1
+tail -5 gpurun_out/r4/gpu_tests.log
