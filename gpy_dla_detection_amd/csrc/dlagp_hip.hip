@@ -785,7 +785,11 @@ struct Transfers {
     hipStream_t compute, transfer;  // kernels of the call / copies of the call (may be the same stream)
     std::vector<Item> up, down;
     size_t total = 0;
-    static constexpr size_t kDirect = 64 * 1024;
+    // Every transfer, small ones included, goes through the page-locked staging buffer as an ASYNCHRONOUS copy: a
+    // blocking hipMemcpy of a few bytes costs 50-90 us of host time each, and a call made for ONE spectrum (the drop-in
+    // classes: a dozen arrays in and out per model selection) spent 0.9 ms of its 1.4 ms in them
+    // (profiles/r04_route_a_trace.txt).  One host wait per call, in run_downloads.
+    static constexpr size_t kDirect = 0;
     Transfers(PinnedBuffer &s, int dev) : stage(s), device(dev), compute(compute_stream(dev)), transfer(work_stream(dev)) {}
     void upload(void *device_ptr, const void *host, size_t bytes) {
         if (bytes) up.push_back({device_ptr, const_cast<void *>(host), bytes, 0});
@@ -862,6 +866,9 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
         tr.upload(ws.nhi.ptr, nhi, nsamp * sizeof(double));
     }
     tr.download(out, ws.out.ptr, (size_t)rows * sizeof(double));
+    int status = 0;
+    if ((rc = grow(g, ws.status, sizeof(int)))) return rc;  // the non-PD flag comes back with the results
+    tr.download(&status, ws.status.ptr, sizeof(int));
     if ((rc = tr.reserve()) || (rc = tr.run_uploads())) return rc;
     rc = launch_sweep(g, S, kd, SampleSource{ws.z.as<double>(), ws.nhi.as<double>(), nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0},
                       ws.out.as<double>(), stream);
@@ -869,9 +876,30 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
     if ((rc = tr.run_downloads())) return rc;
     g.launched = false;  // run_downloads drained the stream: nothing of this group is in flight (drain() has nothing to wait for)
     for (auto &p : g.parts) p->launched = false;
-    int status = 0;
-    HIP_TRY(hipMemcpy(&status, ws.status.ptr, sizeof(int), hipMemcpyDeviceToHost));
     if (status) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
+    return DLAGP_OK;
+}
+
+// level_finish with its cdf in LDS whenever 8 S bytes fit beside the kernel's static 8.3 KB (S <= 18 000)
+static int launch_level_finish(int nb, hipStream_t stream, const double *ll, long S, int level, int max_dlas,
+                               const SampleSource &src, double min_z_separation, const double *uniforms, double *sample_ll,
+                               double *evidences, int *base, double *cdf, int *alive, const int *status, int *sticky) {
+    const size_t lds_bytes = (size_t)S * sizeof(double);
+    if (lds_bytes <= 144 * 1024) {
+        static std::atomic<size_t> allowed{64 * 1024 - 9 * 1024};  // default dynamic LDS limit minus the static part
+        if (lds_bytes > allowed.load()) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(level_finish<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            allowed.store(144 * 1024);
+        }
+        hipLaunchKernelGGL(level_finish<true>, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS), (uint32_t)lds_bytes, stream,
+                           ll, S, level, max_dlas, src, min_z_separation, uniforms, sample_ll, evidences, base, cdf, alive,
+                           status, sticky);
+    } else {
+        hipLaunchKernelGGL(level_finish<false>, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS), 0, stream, ll, S, level,
+                           max_dlas, src, min_z_separation, uniforms, sample_ll, evidences, base, cdf, alive, status, sticky);
+    }
+    HIP_TRY(hipGetLastError());
     return DLAGP_OK;
 }
 
@@ -955,11 +983,10 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
             if (rc) return rc;
             first = false;
         }
-        hipLaunchKernelGGL(level_finish, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS), 0, stream,
-                           ws.level_ll.as<const double>(), (long)S, level, max_dlas, src0, min_z_separation, d_uniforms,
-                           d_sample_ll, d_evidences, d_base, ws.cdf.as<double>(), ws.alive.as<int>(), ws.status.as<const int>(),
-                           ws.alive.as<int>() + nb);
-        HIP_TRY(hipGetLastError());
+        if ((rc = launch_level_finish(nb, stream, ws.level_ll.as<const double>(), (long)S, level, max_dlas, src0,
+                                      min_z_separation, d_uniforms, d_sample_ll, d_evidences, d_base, ws.cdf.as<double>(),
+                                      ws.alive.as<int>(), ws.status.as<const int>(), ws.alive.as<int>() + nb)))
+            return rc;
     }
     return DLAGP_OK;
 }
@@ -1744,6 +1771,9 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
     tr.download(evidences, ws.evidences.ptr, nb * max_dlas * sizeof(double));
     tr.download(sample_ll, ws.sample_ll.ptr, rows * max_dlas * sizeof(double));
     tr.download(base_inds, ws.base.ptr, n_base * sizeof(int32_t));
+    int status = 0;
+    if ((rc = grow(g, ws.alive, (nb + 1) * sizeof(int)))) return rc;  // [nb]: the sweep's sticky non-PD flag (sweep_levels)
+    tr.download(&status, ws.alive.as<int>() + nb, sizeof(int));
     if ((rc = tr.reserve()) || (rc = tr.run_uploads())) return rc;
     rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), nhi_stride, min_z_separation,
                       ws.uniforms.as<double>(), ws.evidences.as<double>(), ws.sample_ll.as<double>(),
@@ -1752,8 +1782,6 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
     if ((rc = tr.run_downloads())) return rc;
     g.launched = false;  // as in sweep_from_host
     for (auto &p : g.parts) p->launched = false;
-    int status = 0;
-    HIP_TRY(hipMemcpy(&status, ws.alive.as<int>() + nb, sizeof(int), hipMemcpyDeviceToHost));
     if (status) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
     return DLAGP_OK;
 }
@@ -1803,6 +1831,11 @@ int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, con
     tr.download(evidences, ws.evidences.ptr, nb * max_dlas * sizeof(double));
     tr.download(sample_ll, ws.sample_ll.ptr, rows * max_dlas * sizeof(double));
     tr.download(base_inds, ws.base.ptr, n_base * sizeof(int32_t));
+    int status[2] = {0, 0};
+    if ((rc = grow(g, ws.alive, (nb + 1) * sizeof(int)))) return rc;  // [nb]: the sweeps' sticky non-PD flag
+    if ((rc = grow(g, ws.status, sizeof(int)))) return rc;            // the null launch's
+    tr.download(&status[0], ws.alive.as<int>() + nb, sizeof(int));
+    tr.download(&status[1], ws.status.ptr, sizeof(int));
     if ((rc = tr.reserve()) || (rc = tr.run_uploads())) return rc;
     // model order of the reference's model list (run_bayes_select.py:189): the one-absorber model before the DLA model
     rc = sweep_levels(g, S, 1, ws.sub_z.as<double>(), ws.sub_nhi.as<double>(), sub_nhi_stride, min_z_separation, nullptr,
@@ -1819,9 +1852,6 @@ int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, con
     if ((rc = tr.run_downloads())) return rc;
     g.launched = false;  // as in sweep_from_host
     for (auto &p : g.parts) p->launched = false;
-    int status[2] = {0, 0};
-    HIP_TRY(hipMemcpy(&status[0], ws.alive.as<int>() + nb, sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&status[1], ws.status.ptr, sizeof(int), hipMemcpyDeviceToHost));
     if (status[0] || status[1]) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
     return DLAGP_OK;
 }
@@ -1881,11 +1911,9 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
     HIP_TRY(hipSetDevice(device));
     // the kernel reads the redshifts of a sample's absorbers through the index table; column densities are not used
     const SampleSource src{d_sample_z, d_sample_z, d_base_inds, 1, 0, max_dlas - 1, nullptr, nullptr, 0, 0, 0, 0, 0};
-    hipLaunchKernelGGL(level_finish, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS), 0, static_cast<hipStream_t>(stream),
-                       d_ll, (long)S, level, max_dlas, src, min_z_separation, d_uniforms, d_sample_ll, d_evidences,
-                       d_base_inds, d_cdf_scratch, d_flags, d_flags + nb + 1, d_flags + nb);
-    HIP_TRY(hipGetLastError());
-    return DLAGP_OK;
+    return launch_level_finish(nb, static_cast<hipStream_t>(stream), d_ll, (long)S, level, max_dlas, src,
+                               min_z_separation, d_uniforms, d_sample_ll, d_evidences, d_base_inds, d_cdf_scratch, d_flags,
+                               d_flags + nb + 1, d_flags + nb);
 }
 
 int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, const uint8_t *d_too_close,

@@ -782,11 +782,17 @@ __device__ __forceinline__ double block_reduce(double x, bool take_max, double *
     return total;
 }
 
+// CDF_IN_LDS: the cdf the resampling searches lives in dynamic LDS (8 S bytes) instead of the global scratch.  Every
+// sample's binary search is ~14 DEPENDENT reads; from L2 they made the resampling the longest part of the kernel (62 us
+// per level for S = 10 000, a third of a one-spectrum model selection's kernel time), from LDS they are a tenth of that.
+// The values, and so the indices, are the same.
+template <bool CDF_IN_LDS>
 __global__ __launch_bounds__(DLAGP_LEVEL_THREADS) void level_finish(
     const double *__restrict__ ll, long S, int level, int max_dlas, SampleSource src, double min_z_separation,
     const double *__restrict__ uniforms, double *__restrict__ sample_ll, double *__restrict__ evidences,
     int *__restrict__ base, double *__restrict__ cdf_scratch, int *__restrict__ alive,
     const int *__restrict__ status, int *__restrict__ sticky_status) {
+    extern __shared__ double cdf_lds[];
     __shared__ double red[DLAGP_LEVEL_THREADS / 64];
     __shared__ double scan[DLAGP_LEVEL_THREADS];
     const int tid = threadIdx.x;
@@ -841,7 +847,7 @@ __global__ __launch_bounds__(DLAGP_LEVEL_THREADS) void level_finish(
     if (level + 1 == max_dlas || !(evidence == evidence)) return;
 
     // 3. resample: cdf of W / sum(W) by a blocked scan (each thread owns a contiguous chunk)
-    double *cdf = cdf_scratch + b * S;
+    double *cdf = CDF_IN_LDS ? cdf_lds : cdf_scratch + b * S;
     const long chunk = (S + DLAGP_LEVEL_THREADS - 1) / DLAGP_LEVEL_THREADS;
     const long lo = tid * chunk, hi = lo + chunk < S ? lo + chunk : S;
     double local = 0.0;

@@ -25,6 +25,27 @@ def report(tag, base):
               % (tag, level + 2, len(counts), np.round(counts[:4] / S, 4).tolist(), agree))
 
 
+def wave_report(tag, base):
+    """
+    base: (num, levels, S).  Per wave of the cached-level kernel (16 consecutive samples): how many DISTINCT cached
+    rows its samples stack at each level, and in total over the levels -- what a kernel that reads every distinct row
+    once per pass would have to hold.
+    """
+    num, levels, _ = base.shape
+    blocks = base[:, :, : S // 16 * 16].reshape(num, levels, -1, 16)
+    srt = np.sort(blocks, axis=3)
+    distinct = 1 + (np.diff(srt, axis=3) != 0).sum(axis=3)  # (num, levels, waves)
+    for level in range(levels):
+        hist = np.bincount(distinct[:, level].ravel(), minlength=17)[1:]
+        print("%s level %d: distinct rows per wave: mean %.2f, share with <= 1/2/4/6/8: %s"
+              % (tag, level + 2, distinct[:, level].mean(),
+                 np.round([hist[:k].sum() / hist.sum() for k in (1, 2, 4, 6, 8)], 4).tolist()))
+    for upto in range(2, levels + 1):
+        total = distinct[:, :upto].sum(axis=1).ravel()
+        print("%s level %d kernel (rows of levels 2..%d): total distinct per wave mean %.2f, share <= 4/6/8/12/16: %s"
+              % (tag, upto + 1, upto + 1, total.mean(), np.round([(total <= k).mean() for k in (4, 6, 8, 12, 16)], 4).tolist()))
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "catalogue"
     if what == "catalogue":
@@ -44,18 +65,20 @@ def main():
             report("spectrum %2d (%s)" % (q, "absorber" if q % 3 else "none"), base[q])
         distinct = np.array([[len(np.unique(row)) for row in b] for b in base])
         print("mean distinct values per level:", distinct.mean(axis=0), "max", distinct.max())
+        wave_report("catalogue", base)
     else:
         from gpy_dla_detection_amd import parallel
         from gpy_dla_detection_amd.sightline import DeviceBatch, DeviceSightline
         from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline
 
-        sights = [make_sightline(i) for i in range(4)]  # the bench's n = 3000 sightlines
+        sights = [make_sightline(i) for i in range(12)]  # the bench's n = 3000 sightlines
         batch = DeviceBatch([DeviceSightline.from_state(s, device=0) for s in sights])
         zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
         nhi = make_qmc_samples(sights[0], S)[2]
         base = parallel.sweep_batch_device(batch, zs, nhi, 4, 3000.0 * 1000.0 / 299792458.0, seed=0)[2]
         for b in range(4):
             report("sightline %d" % b, base[b])
+        wave_report("bench", base)
 
 
 if __name__ == "__main__":
