@@ -76,14 +76,14 @@ struct SampleSource {
     // one of the sightline's S QMC points, and sample s of level l stacks point base[l-1][s] on the
     // absorbers sample s had at level l-1 (reference dla_gp.py:135-150).  So level 1 keeps the convolved
     // absorption of every point on the kept pixels, cache[(b S + p) cache_stride + pixel] (cache_mode 1),
-    // and level l > 1 forms  running[s] = running[s] * cache[base[l-1][s]]  (cache_mode 2; at level 2 the
-    // running product is read from the cache itself) instead of evaluating Voigt profiles, writing the
-    // product back for the next level (cache_write).  2 x 240 MB per sightline at S = 10 000, n = 3000.
+    // and level l > 1 forms the product  cache[s] cache[base[0][s]] .. cache[base[l-2][s]]  (cache_mode 2) instead of
+    // evaluating Voigt profiles: one streamed row per sample and level, the stacked rows -- a handful of distinct ones per
+    // wave -- from L2 (kernels_mfma.h).  240 MB per sightline at S = 10 000, n = 3000.
     double *cache;
-    double *running;
+    double *running;   // unused since round 4 (no running product is kept in memory)
     long cache_stride;
     int cache_mode;    // 0 off, 1 store level-1 profiles, 2 multiply cached rows
-    int cache_write;   // mode 2: write the running product back (not needed at the last level)
+    int cache_write;   // unused since round 4
     // Indexed mode on a slice of the samples (one rank's share when ONE sightline's samples are split over several
     // GPUs): the launch evaluates samples [sample_offset, sample_offset + S) of tables that hold table_S samples
     // per sightline.  table_S == 0: the launch covers the whole table (offset 0, table_S = S).

@@ -264,13 +264,12 @@ struct Workspace {
     // device-resident occupation sweep: raw level log-likelihoods, cdf scratch, per-sightline alive flag,
     // and staging of its host-pointer variant
     DeviceBuffer level_ll, cdf, alive, uniforms, evidences, sample_ll, base;
-    DeviceBuffer cache, running;  // profile cache / running products of the multi-level sweep, [nb][S][max n_pad]
+    DeviceBuffer cache;  // profile cache of the multi-level sweep, [nb][S][max n_slots]
     DeviceBuffer sub_z, sub_nhi, sub_evidences, sub_ll;  // the one-absorber model of dlagp_batch_model_evidences
     PinnedBuffer stage;           // host staging of the host-pointer entry points
     void release() {
         stage.release();
         cache.release();
-        running.release();
         level_ll.release();
         cdf.release();
         alive.release();
@@ -606,7 +605,8 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
         double *part = ws.part.as<double>();
         const int launch_flags = (keep_status ? DLAGP_LAUNCH_KEEP_STATUS : 0) | (g_opt_shared_rows ? 0 : DLAGP_LAUNCH_GENERAL_ROWS);
         if (src.cache_mode == 2) {
-            const size_t prep_lds = (size_t)DLAGP_MFMA_GROUP * sizeof(double);
+            // [kd - 1][16] stacked rows of the wave's samples + its pool of 16 distinct rows (ints), see accumulate_mfma_body
+            const size_t prep_lds = (size_t)(DLAGP_MAX_ABSORBERS * 16) * sizeof(int);
             DLAGP_LAUNCH_MFMA(3, true, false, 2);
         } else if (g.broadening) {
             if (lines3) launch_mfma<3, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags, ev_start, ev_stop);
@@ -953,22 +953,22 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
         bool use_cache = g_opt_profile_cache != 0 && max_dlas > 1;
         for (int level = 0; level < max_dlas; ++level) use_cache = use_cache && mfma_path_serves(tg, level + 1, level > 0);
         const size_t cache_bytes = tg.ctxs.size() * (size_t)S * (size_t)tg.max_slots * sizeof(double);
-        const size_t want_bytes = cache_bytes * (max_dlas > 2 ? 2 : 1);  // profiles + running products
+        const size_t want_bytes = cache_bytes;  // the profiles; the deeper levels multiply cached rows, nothing is written back
+        // the cached levels address a sightline's rows with 32-bit byte offsets (raw buffer loads, kernels_mfma.h)
+        use_cache = use_cache && (size_t)S * (size_t)tg.max_slots * sizeof(double) < ((size_t)1 << 31);
         if (use_cache) {
-            const size_t have = tws.cache.bytes + tws.running.bytes;
+            const size_t have = tws.cache.bytes;
             if (have < want_bytes) {
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(hipMemGetInfo(&free_b, &total_b));
                 use_cache = want_bytes <= (size_t)g_opt_profile_cache_max_mb << 20 && want_bytes <= (free_b + have) / 2;
             }
             if (use_cache && (rc = grow(tg, tws.cache, cache_bytes))) return rc;
-            if (use_cache && max_dlas > 2 && (rc = grow(tg, tws.running, cache_bytes))) return rc;
         }
         t.use_cache = use_cache;
         all_cached = all_cached && use_cache;
         if (use_cache) {
             t.src.cache = tws.cache.as<double>();
-            t.src.running = tws.running.as<double>();
             t.src.cache_stride = tg.max_slots;
         }
     }
@@ -977,7 +977,6 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
         bool first = true;
         for (Target &t : targets) {
             t.src.cache_mode = t.use_cache ? (level == 0 ? 1 : 2) : 0;
-            t.src.cache_write = t.use_cache && level >= 1 && level + 1 < max_dlas;
             if (g.parts.empty()) rc = launch_one(g, S, level + 1, t.src, ws.level_ll.as<double>(), stream);
             else rc = launch_one(*t.g, S, level + 1, t.src, ws.level_ll.as<double>(), stream, ws.status.as<int>(), !first);
             if (rc) return rc;

@@ -35,6 +35,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "dlagp_device.h"
 #include "fastmath_device.h"
 #include "kernels_common.h"
@@ -242,14 +244,13 @@ __device__ __forceinline__ void lds_wave_sync() {
 // by stepping ulps around limit (1 + z), so that the in-loop test `lambda >= T` reproduces the reference's
 // `rest_wavelengths > lambda_Lyman_limit` (:280) exactly without a division per entry.
 //
-// UNIFORM (MODE 2 only, chosen per wave by the kernel below): the 16 samples of the wave stack the same cached row.
-template <int LINES, bool BROADEN, bool STAMPS, int MODE, int PATCH, bool LLS, bool UNIFORM>
+template <int LINES, bool BROADEN, bool STAMPS, int MODE, int PATCH, bool LLS>
 __device__ __forceinline__ void accumulate_mfma_body(
     const SightlineDev *__restrict__ sightlines, const PassDesc *__restrict__ passes,
     const WorkItem *__restrict__ items, int nb, long S, int kd,
     SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags) {
     constexpr bool CACHED = MODE == 2;
-    static_assert(!UNIFORM || CACHED, "only the cached levels read rows");
+    constexpr int NPOOL = 16;  // distinct cached rows a wave holds per pass (cached levels)
     constexpr int A_STRIDE = 4 * DLAGP_MAX_PASS_STEPS + 2;  // 58: stride/2 odd -> conflict-free b64 reads
     __shared__ double raw[16 * DLAGP_RAW_STRIDE];
     __shared__ double a_lds[16 * A_STRIDE];
@@ -310,14 +311,52 @@ __device__ __forceinline__ void accumulate_mfma_body(
 
     // per-sample constants of this wave -> LDS (rows beyond S repeat the last sample; never stored)
     const int wave_prep = CACHED ? 0 : 16 * kd * prep_stride;
-    if (CACHED) {
-        // the cached row each of the wave's samples stacks on its running product at this level
-        int *row_lds = reinterpret_cast<int *>(prep_lds);
-        if (lane < 16) {
-            long smp = sample0 + lane;
+    // Cached levels (MODE 2).  Sample s of level kd stacks the cached profiles of QMC point s and of the points
+    // base[0][s] .. base[kd - 2][s] (reference dla_gp.py:135-150), multiplied in that order.  Row s is streamed from HBM
+    // once per level; the stacked rows are few -- the resampled indices of a level concentrate on a handful of QMC points
+    // (profiles/r03_experiments.txt item 16; per wave and level 1.1-1.3 distinct rows on catalogue data, 2.3-3.1 on the
+    // bench's sightlines, profiles/r04_experiments.txt) -- so the wave lists the DISTINCT rows its 16 samples stack over
+    // all kd - 1 levels (the "pool", <= 16), reads each of them once per pass, from L2, and every sample picks its rows
+    // out of LDS.  No running product is kept in memory: a level costs ONE streamed row per sample and no write-back
+    // (up to round 3: the running product read, multiplied by one row and written back -- 72 KB per sample and level).
+    // A wave whose samples stack more than 16 distinct rows (flat likelihoods) reads them level by level, 16 rows at a
+    // time, at the head of every pass (`pooled` = false; also forced by launch flag DLAGP_LAUNCH_GENERAL_ROWS).
+    int *row_lds = reinterpret_cast<int *>(prep_lds);  // [kd - 1][16] cached row of (level, sample); then [NPOOL] pool rows
+    constexpr int MAXJ = DLAGP_MAX_ABSORBERS - 1;  // stacked rows per sample
+    constexpr int POOLJ = 3;                       // ... that the pool serves (the reference sweeps up to 4 absorbers)
+    int *pool_row_lds = row_lds + MAXJ * 16;
+    unsigned long long slot_bits[POOLJ] = {};  // pool slot of (level, sample): 4 bits each, wave-uniform
+    bool pooled = false;
+    if constexpr (CACHED) {
+        int npool = 0;
+        bool overflow = (launch_flags & DLAGP_LAUNCH_GENERAL_ROWS) != 0 || kd - 1 > POOLJ;
+        int pool_val = 0;  // lane t < npool: row of pool slot t
+        for (int j = 1; j < kd; ++j) {
+            long smp = sample0 + (lane & 15);
             smp = smp < S ? smp : S - 1;
-            row_lds[lane] = (int)sample_point(src, gb, smp, kd - 1, S, kd);
+            const int mine = (int)sample_point(src, gb, smp, j, S, kd);
+            if (lane < 16) row_lds[(j - 1) * 16 + lane] = mine;
+            for (int ss = 0; ss < 16; ++ss) {
+                const int v = __builtin_amdgcn_readlane(mine, ss);
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < npool && pool_val == v);
+                int slot_id;
+                if (hit) {
+                    slot_id = __builtin_ctzll(hit);
+                } else if (npool < NPOOL) {
+                    slot_id = npool;
+                    if (lane == npool) pool_val = v;
+                    ++npool;
+                } else {
+                    slot_id = 0;
+                    overflow = true;
+                }
+                if (j <= POOLJ) slot_bits[j - 1] |= (unsigned long long)slot_id << (4 * ss);
+            }
         }
+        pooled = !overflow;
+        // unused pool slots repeat slot 0's row: every pass issues the same number of row reads whatever the pool holds
+        const int first = __builtin_amdgcn_readfirstlane(pool_val);
+        if (lane < NPOOL) pool_row_lds[lane] = lane < npool ? pool_val : first;
         lds_wave_sync();
     }
     for (int i = lane; i < wave_prep; i += 64) {
@@ -482,30 +521,38 @@ __device__ __forceinline__ void accumulate_mfma_body(
         e = e < num_entries ? e : num_entries - 1;
         lam_next = lam_ptr[e];
     }
-    // cached levels (MODE 2): the row of the running product and the cached row of the new absorber, per sample, for
-    // the 64 pixel slots of a pass (lane = slot); loaded a pass ahead, see the step loop
+    // cached levels (MODE 2): per sample the cached row of its own QMC point (streamed), and the wave's pool of stacked
+    // rows, for the 64 pixel slots of a pass (lane = slot); loaded a pass ahead, see the step loop
     constexpr int NROW = CACHED ? 16 : 1;
-    double own[NROW], other[UNIFORM ? 1 : NROW];
+    double own[NROW], rowreg[CACHED ? NPOOL : 1];
+    // Row reads are raw buffer loads: ONE scalar resource over the sightline's part of the cache, the row as a scalar
+    // byte offset, the pass's pixel column as the per-lane offset -- no 64-bit vector addresses (32 of them at a time
+    // spilled a hundred registers).  The host keeps S x cache_stride x 8 bytes below 2^31.
+    const __amdgpu_buffer_rsrc_t cache_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)as_global<gptr_d>(CACHED ? src.cache + (long)b * S * src.cache_stride : nullptr), 0,
+        CACHED ? (int)(S * src.cache_stride * 8) : 0, DLAGP_BUFFER_FLAGS);
+    const int row_bytes = CACHED ? (int)src.cache_stride * 8 : 0;
+    auto pass_column = [&](const PassDesc &pd) __attribute__((always_inline)) -> int {
+        const int st0 = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd.chunk_begin);
+        const int npx = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd.nchunks) * DLAGP_STEP_PIXELS;
+        const int px = lane < npx ? lane : npx - 1;
+        return (st0 * DLAGP_STEP_PIXELS + px) * 8;  // byte offset of this lane's pixel slot within a row
+    };
     auto issue_rows = [&](const PassDesc &pd) __attribute__((always_inline)) {
         if constexpr (CACHED) {
-            typedef const __attribute__((address_space(1))) double *gcd;
-            const int *row_lds = reinterpret_cast<const int *>(prep_lds);
-            const int st0 = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd.chunk_begin);
-            const int npx = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd.nchunks) * DLAGP_STEP_PIXELS;
-            const int px = lane < npx ? lane : npx - 1;
-            const long col = (long)st0 * DLAGP_STEP_PIXELS + px;
-            const long row0 = (long)b * S;
+            const int voff = pass_column(pd);
             const long last = S - 1 - sample0;  // rows beyond S repeat the last sample (never stored)
-            gcd cache_col = (gcd)src.cache + col;
-            gcd run_col = (gcd)(kd == 2 ? src.cache : src.running) + (row0 + sample0) * src.cache_stride + col;
-            if constexpr (UNIFORM) other[0] = cache_col[(row0 + __builtin_amdgcn_readfirstlane(row_lds[0])) * src.cache_stride];
 #pragma unroll
             for (int ss = 0; ss < 16; ++ss) {
-                const long rel = ss < last ? ss : last;
-                // the running product is read once: streamed past the L2 that serves the sightline's operand
-                own[ss] = DLAGP_CACHE_STORE_NT ? __builtin_nontemporal_load(run_col + rel * src.cache_stride) : run_col[rel * src.cache_stride];
-                if constexpr (!UNIFORM) other[ss] = cache_col[(row0 + row_lds[ss]) * src.cache_stride];
+                const int rel = (int)(ss < last ? ss : last);
+                // read once per level: streamed (nt) past the L2 that serves the sightline's operand and the pool's rows
+                own[ss] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                                         cache_rsrc, voff, ((int)sample0 + rel) * row_bytes, DLAGP_CACHE_STORE_NT ? 2 : 0));
             }
+#pragma unroll
+            for (int t = 0; t < NPOOL; ++t)
+                rowreg[t] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                                           cache_rsrc, voff, __builtin_amdgcn_readfirstlane(pool_row_lds[t]) * row_bytes, 0));
         }
     };
     if constexpr (CACHED) issue_rows(pd_next);  // the first pass's rows
@@ -523,16 +570,63 @@ __device__ __forceinline__ void accumulate_mfma_body(
                                                          step0 * REC_STEP_BYTES, 0));
 
         if constexpr (CACHED) {
-            // ---------------- phase 1 (cached): running product x the new absorber's cached profile ----------------
+            // ---------------- phase 1 (cached): the product of the sample's stacked cached profiles ----------------
             // The 32 row reads of this pass were issued during the last two steps of the pass before it (below), so
-            // their trip to HBM ran beside those steps' MFMAs; what is left of it is hidden behind the other resident
-            // wave.  The products are written back (cache_write) from a_lds[] at the same point of THIS pass.
+            // their trip to HBM / L2 ran beside those steps' MFMAs; what is left of it is hidden behind the other resident
+            // wave.  Same multiplication order as the recomputing kernel: ((c_s c_b0) c_b1) c_b2 -- bit-identical.
             if (stamps) t_mark = stamp_now();
             const int npx = pass_steps * DLAGP_STEP_PIXELS;
+            double *pool_lds = raw;  // [NPOOL][64]; raw[] is otherwise unused on the cached levels
+            if (pooled) {
 #pragma unroll
-            for (int ss = 0; ss < 16; ++ss) {
-                const double prod = own[ss] * other[UNIFORM ? 0 : ss];
-                if (lane < npx) a_lds[ss * A_STRIDE + lane] = prod;
+                for (int t = 0; t < NPOOL; ++t) pool_lds[t * 64 + lane] = rowreg[t];
+                lds_wave_sync();
+                // Every sample picks its kd - 1 rows out of the pool: reads of four samples in flight, then their
+                // products.  The slot numbers are wave-uniform scalars; the lane part of the address is made opaque per
+                // pass, or the compiler keeps all 48 (slot, lane) addresses in registers across the pass loop (44 spills).
+                int lane_off = lane * 8;
+                asm volatile("" : "+v"(lane_off));
+                const char *pool_bytes = reinterpret_cast<const char *>(pool_lds);
+                auto stack = [&](auto depth) __attribute__((always_inline)) {
+                    constexpr int D = decltype(depth)::value;  // stacked rows per sample = kd - 1
+#pragma unroll
+                    for (int s0 = 0; s0 < 16; s0 += 4) {
+                        double r[4][D];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int j = 0; j < D; ++j) {
+                                const int slot_off = (int)((slot_bits[j] >> (4 * (s0 + u))) & 15) * 512;
+                                r[u][j] = *reinterpret_cast<const double *>(pool_bytes + (slot_off + lane_off));
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            double prod = own[s0 + u];
+#pragma unroll
+                            for (int j = 0; j < D; ++j) prod *= r[u][j];
+                            if (lane < npx) a_lds[(s0 + u) * A_STRIDE + lane] = prod;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                if (kd == 2) stack(std::integral_constant<int, 1>());
+                else if (kd == 3) stack(std::integral_constant<int, 2>());
+                else stack(std::integral_constant<int, 3>());
+            } else {
+                // more than NPOOL distinct rows in this wave: the stacked rows level by level, 16 reads at a time
+                const int voff = pass_column(pd_v);
+                for (int j = 1; j < kd; ++j) {
+#pragma unroll
+                    for (int ss = 0; ss < 16; ++ss)
+                        rowreg[ss] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                                                    cache_rsrc, voff, __builtin_amdgcn_readfirstlane(row_lds[(j - 1) * 16 + ss]) * row_bytes, 0));
+#pragma unroll
+                    for (int ss = 0; ss < 16; ++ss) own[ss] *= rowreg[ss];
+                }
+#pragma unroll
+                for (int ss = 0; ss < 16; ++ss)
+                    if (lane < npx) a_lds[ss * A_STRIDE + lane] = own[ss];
             }
             lds_wave_sync();
             if (stamps) t_conv += stamp_now() - t_mark;
@@ -801,30 +895,20 @@ __device__ __forceinline__ void accumulate_mfma_body(
         } else {
             // Cached levels: the last two steps are written out so that the memory traffic of the NEXT pass can start
             // between them.  Vector-memory operations complete in order and the step loop waits for its operand
-            // prefetches, so anything issued in front of it (the old place of the row reads and the write-back) holds
+            // prefetches, so anything issued in front of it (the old place of the row reads) holds
             // up its first steps for a trip to HBM; issued here, behind the last operand prefetch of the pass, the
-            // write-back of this pass's products and the 32 row reads of the next pass are in flight during two steps of
+            // 32 row reads of the next pass are in flight during two steps of
             // MFMAs and nothing waits for them before the next pass's products.  (Inside the loop, behind a condition,
             // the compiler's wait counts at the loop head would have to assume the worst of both paths.)
             for (int st = 0; st + 2 < pass_steps; ++st) DLAGP_STEP_BODY(st, true)
             DLAGP_STEP_BODY(pass_steps - 2, true)  // a pass holds an even number of steps >= 2 (chunks of 8 slots)
-            {
-                const int npx = pass_steps * DLAGP_STEP_PIXELS;
-                const long last = S - 1 - sample0;
-                if (src.cache_write && lane < npx) {
-                    __attribute__((address_space(1))) double *out_col =
-                        (__attribute__((address_space(1))) double *)src.running + ((long)b * S + sample0) * src.cache_stride +
-                        (long)step0 * DLAGP_STEP_PIXELS + lane;
-#pragma unroll
-                    for (int ss = 0; ss < 16; ++ss)
-                        if (ss <= last) {
-                            const double prod = a_lds[ss * A_STRIDE + lane];
-                            if (DLAGP_CACHE_STORE_NT) __builtin_nontemporal_store(prod, out_col + ss * src.cache_stride);
-                            else out_col[ss * src.cache_stride] = prod;
-                        }
-                }
-                if (pass + 1 < pass_end) issue_rows(pd_next);
-            }
+            // Behind this condition the wait counts of the step after the join are the minimum over the two arms -- the
+            // arm without reads -- so the last step waits for 24 of the 32 row reads (vmcnt(8) in the ISA): the wave idles
+            // for the rows' trip while the SIMD's other wave computes.  Both obvious cures were measured and are worse
+            // (profiles/r04_experiments.txt item 3): the reads made unconditional (exact wait counts, vmcnt(40..32): the
+            // last step runs beside the reads) DOUBLED the kernel time (8.5 -> 16.0 ms on config 5; not understood), and
+            // the step written out in both arms spilled 188 registers.
+            if (pass + 1 < pass_end) issue_rows(pd_next);
             DLAGP_STEP_BODY(pass_steps - 1, false)
         }
 #undef DLAGP_STEP_BODY
@@ -924,30 +1008,13 @@ __device__ __forceinline__ void accumulate_mfma_body(
     }
 }
 
-// The kernel: one wave per work item, see accumulate_mfma_body.  On the cached levels the wave first looks at the cached
-// rows its 16 samples stack on their running products.  The resampled base indices of a level concentrate on very few
-// QMC points (their weights are exp(log-likelihood): one to four distinct values among 10 000 draws on every spectrum
-// looked at, profiles/r03_experiments.txt item 16), so the 16 are nearly always the SAME row -- which is then read once
-// per pass instead of 16 times, by a copy of the body that holds one row register pair instead of 16.
+// The kernel: one wave per work item, see accumulate_mfma_body.
 template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, int PATCH = 0, bool LLS = false>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *__restrict__ passes,
     const WorkItem *__restrict__ items, int nb, long S, int kd,
     SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags) {
-    if constexpr (MODE == 2) {
-        const WorkItem &item = items[blockIdx.x];
-        const long gb = sightlines[__builtin_amdgcn_readfirstlane(item.b)].batch_index;
-        long smp = (long)__builtin_amdgcn_readfirstlane(item.group) * DLAGP_MFMA_GROUP + (threadIdx.x & 15);
-        smp = smp < S ? smp : S - 1;
-        const int mine = (int)sample_point(src, gb, smp, kd - 1, S, kd);
-        const bool uniform = __builtin_amdgcn_ballot_w64(mine != __builtin_amdgcn_readfirstlane(mine)) == 0;
-        if (uniform && !(launch_flags & DLAGP_LAUNCH_GENERAL_ROWS))
-            accumulate_mfma_body<LINES, BROADEN, STAMPS, MODE, PATCH, LLS, true>(sightlines, passes, items, nb, S, kd, src, part, status, launch_flags);
-        else
-            accumulate_mfma_body<LINES, BROADEN, STAMPS, MODE, PATCH, LLS, false>(sightlines, passes, items, nb, S, kd, src, part, status, launch_flags);
-    } else {
-        accumulate_mfma_body<LINES, BROADEN, STAMPS, MODE, PATCH, LLS, false>(sightlines, passes, items, nb, S, kd, src, part, status, launch_flags);
-    }
+    accumulate_mfma_body<LINES, BROADEN, STAMPS, MODE, PATCH, LLS>(sightlines, passes, items, nb, S, kd, src, part, status, launch_flags);
 }
 
 // Diagnostic (dlagp_debug_voigt): the Voigt profile V(v; sigma, gamma_l) = Re w((v + i gamma_l)/(sqrt2 sigma)) /

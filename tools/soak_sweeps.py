@@ -25,7 +25,7 @@ for trial in range(trials):
     S = int(rng.choice([1, 7, 16, 17, 100, 625, 1000, 2048, 4000]))
     if nb > 2 and S > 1000:
         S = 1000
-    max_dlas = int(rng.choice([2, 3, 4]))
+    max_dlas = int(rng.choice([2, 3, 4, 4, 6]))
     sights = [make_sightline(int(rng.integers(0, 1000)), n_unmasked=int(rng.integers(40, 3300)),
                              n_masked=int(rng.integers(0, 30))) for _ in range(nb)]
     mixed = nb > 1 and rng.random() < 0.4
