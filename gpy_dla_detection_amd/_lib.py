@@ -96,10 +96,34 @@ def _preload_torch_hip_runtime() -> None:
         if spec is None or not spec.submodule_search_locations:
             return
         path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(path):
-            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        # only a runtime of the SONAME the library was linked against can stand in for it: a torch wheel built for
+        # another ROCm major is left alone (the library then binds to the system runtime, and `hip_runtime_copies`
+        # reports two runtimes once torch is imported)
+        wanted = _needed_hip_soname()
+        if os.path.exists(path) and wanted and _file_contains(path, wanted.encode() + b"\0"):
+            ctypes.CDLL(path)  # RTLD_LOCAL: the loader's SONAME match needs no global symbols
     except Exception:  # no torch, a CPU-only torch, an unreadable install: the system runtime serves
         pass
+
+
+def _file_contains(path: str, needle: bytes) -> bool:
+    import mmap
+
+    with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as view:
+        return view.find(needle) >= 0
+
+
+def _needed_hip_soname() -> str:
+    """the `libamdhip64.so.N` libdlagp_hip.so was linked against (its DT_NEEDED entry), '' if it cannot be read"""
+    import mmap
+    import re
+
+    try:
+        with open(LIB_PATH, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as view:
+            found = re.search(rb"libamdhip64\.so\.\d+", view)
+            return found.group(0).decode() if found else ""
+    except OSError:
+        return ""
 
 
 def load():
@@ -113,6 +137,14 @@ def load():
             )
         _preload_torch_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
+        copies = hip_runtime_copies()
+        if len(copies) > 1:  # e.g. the system runtime was mapped before this module had a say
+            import warnings
+
+            warnings.warn("two HIP runtimes are mapped into this process (%s): streams and tensors of one are not valid "
+                          "in the other; import gpy_dla_detection_amd before anything that loads the system runtime, "
+                          "or set DLAGP_HIP_RUNTIME=system in a process that never imports torch" % ", ".join(copies),
+                          RuntimeWarning, stacklevel=2)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = restype

@@ -208,12 +208,15 @@ def sweep_sharded_samples_device(batch, sample_z: np.ndarray, sample_nhi: np.nda
     nb, S = sample_z.shape
     if max_dlas > 1 and (uniforms is None or uniforms.shape != (nb, max_dlas - 1, S)):
         raise ValueError("uniforms must be (nb, max_dlas - 1, S)")
-    # with an initialised process group the collective runs even for a single rank (a one-GPU rehearsal of the
-    # RCCL calls); without one this is the single-process sweep
+    # world_size == 1 with no group passed is the LOCAL sweep, also inside a multi-rank job (e.g. one rank of a
+    # by-spectrum sharded run sweeping a sightline of its own): no collective.  The collective path runs for
+    # world_size > 1, and -- a one-GPU rehearsal of the RCCL calls -- for a single rank when a group is passed
+    # explicitly or the default group itself has one rank.
     group_up = dist.is_available() and dist.is_initialized()
     if world_size > 1 and not group_up and slices is None:
         raise RuntimeError("world_size = %d needs an initialised torch.distributed process group" % world_size)
-    distributed = group_up and slices is None
+    distributed = group_up and slices is None and (
+        world_size > 1 or group is not None or dist.get_world_size() == 1)
     if distributed:
         if dist.get_world_size(group) != world_size or dist.get_rank(group) != rank:
             raise ValueError("rank / world_size do not match the process group")

@@ -149,6 +149,11 @@ ev, ll, base = parallel.sweep_sharded_samples_device(batch, g["dla_sample_z"][No
                                                      float(g["dla_min_z_separation"]), uniforms,
                                                      rank=rank, world_size=world)
 np.savez(os.path.join(out, "by_sample_rank%d.npz" % rank), ev=ev, ll=ll, base=base)
+if world > 1:
+    # a rank of a multi-rank job sweeping a sightline of its own: defaults (rank 0 of 1, no group) = local, no collective
+    ev1, ll1, base1 = parallel.sweep_sharded_samples_device(batch, g["dla_sample_z"][None, :], nhi, max_dlas,
+                                                            float(g["dla_min_z_separation"]), uniforms)
+    np.savez(os.path.join(out, "local_rank%d.npz" % rank), ev=ev1, ll=ll1, base=base1)
 with open(os.path.join(out, "runtime_rank%d.txt" % rank), "w") as f:
     f.write("\n".join(_lib.hip_runtime_copies()))
 dist.barrier()
@@ -185,5 +190,9 @@ def test_sharded_sweeps_through_a_process_group(tmp_path, backend, nproc):
         np.testing.assert_array_equal(by_sample["base"][0], g["dla_base_inds"])
         np.testing.assert_allclose(by_sample["ev"][0], g["dla_evidences"], rtol=1e-9)
         np.testing.assert_allclose(by_sample["ll"][0], g["dla_sample_ll"], rtol=1e-9, equal_nan=True)
+        if nproc > 1:
+            local = np.load(tmp_path / ("local_rank%d.npz" % rank))
+            np.testing.assert_array_equal(local["base"][0], g["dla_base_inds"])
+            np.testing.assert_allclose(local["ev"][0], g["dla_evidences"], rtol=1e-9)
         copies = (tmp_path / ("runtime_rank%d.txt" % rank)).read_text().split()
         assert len(copies) == 1, copies  # torch (RCCL) and the library share one HIP runtime
