@@ -70,7 +70,7 @@ def measured_hbm_traffic(config: int):
     HBM bytes per accumulate-kernel launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, collected in
     their own rocprofv3 runs of this same command, gfx950 read-side correction applied).  None when absent.
     """
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 data = json.load(f)

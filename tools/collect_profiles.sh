@@ -9,14 +9,16 @@ cd /tmp && export TMPDIR=/tmp && cd "$root"
 python3 bench.py > $out/bench.json 2> $out/bench.err
 for c in 3 4 5; do python3 bench.py --config $c > $out/bench_config$c.json 2>> $out/bench.err; done
 python3 bench.py --strong --no-cpu-baseline > $out/bench_strong_n1.json 2>> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2>&1
+python3 bench.py --gpus 2 --rehearse-on-one-gpu --no-cpu-baseline > $out/bench_two_ranks_on_one_gpu.json 2>> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --no-cpu-baseline --no-other-configs > $out/bench_under_rocprof.json 2>&1
 cp $out/prof/*/*_kernel_stats.csv $out/kernel_stats.csv
 python3 tools/timed_region_average.py $out/prof/*/*_kernel_trace.csv 200 > $out/kernel_timed_region.json
-for c in 3 5; do
+for c in 3 4 5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_c$c -- python3 bench.py --no-cpu-baseline --config $c --steps 3 > $out/bench_config${c}_under_rocprof.json 2>&1
   cp $out/prof_c$c/*/*_kernel_stats.csv $out/kernel_stats_config$c.csv
 done
 python3 tools/measure_configs.py 2>/dev/null | tail -1 > $out/other_configs.json
 python3 tools/measure_catalogue.py 2048 10000 32 2>/dev/null | tail -1 > $out/catalogue_pipeline.json
-rm -rf $out/prof $out/prof_c3 $out/prof_c5
+python3 tools/measure_route_a.py 256 2>/dev/null | tail -1 > $out/route_a.json
+rm -rf $out/prof $out/prof_c3 $out/prof_c4 $out/prof_c5
 ls -la $out
