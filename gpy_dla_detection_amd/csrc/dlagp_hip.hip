@@ -303,16 +303,17 @@ static Option g_opt_negative_noise_mfma = 0;
 
 // Decomposition of one MFMA launch (a launch group at one sample count) into work items, see build_plan
 struct LaunchPlan {
-    DeviceBuffer passes;  // PassDesc[]: the pass lists of all items (shared between items with equal pixel ranges)
-    DeviceBuffer items;   // WorkItem[nitems], largest first
-    DeviceBuffer counts;  // unsigned char[nblocks]: pieces per block of 16 samples (partial-sum slots to add)
+    // one device allocation, one upload: [PassDesc passes[] | WorkItem items[] (largest first) | unsigned char counts[]]
+    //   passes  the pass lists of all items (shared between items with equal pixel ranges)
+    //   counts  pieces per block of 16 samples (partial-sum slots to add), [nblocks]
+    DeviceBuffer blob;
+    size_t items_at = 0, counts_at = 0;
     int nitems = 0;
     int max_parts = 1;
-    void release() {
-        passes.release();
-        items.release();
-        counts.release();
-    }
+    const PassDesc *passes() const { return static_cast<const PassDesc *>(blob.ptr); }
+    const WorkItem *items() const { return reinterpret_cast<const WorkItem *>(static_cast<const char *>(blob.ptr) + items_at); }
+    const unsigned char *counts() const { return static_cast<const unsigned char *>(blob.ptr) + counts_at; }
+    void release() { blob.release(); }
 };
 
 struct dlagp_ctx;
@@ -464,14 +465,18 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
         g.plans.clear();
     }
     std::unique_ptr<LaunchPlan> plan(new LaunchPlan());
-    int rc = plan->passes.reserve(std::max<size_t>(1, host.passes.size()) * sizeof(PassDesc));
-    if (!rc) rc = plan->items.reserve(std::max<size_t>(1, host.items.size()) * sizeof(WorkItem));
-    if (!rc) rc = plan->counts.reserve(std::max<size_t>(1, host.counts.size()));
+    // planning runs on the launching thread, ahead of the launch on the caller's stream: ONE blocking copy (three cost
+    // a one-spectrum call 50 us more)
+    const size_t passes_bytes = host.passes.size() * sizeof(PassDesc), items_bytes = host.items.size() * sizeof(WorkItem);
+    plan->items_at = (passes_bytes + 255) & ~(size_t)255;
+    plan->counts_at = (plan->items_at + items_bytes + 255) & ~(size_t)255;
+    std::vector<char> staged(plan->counts_at + std::max<size_t>(1, host.counts.size()), 0);
+    std::memcpy(staged.data(), host.passes.data(), passes_bytes);
+    std::memcpy(staged.data() + plan->items_at, host.items.data(), items_bytes);
+    std::memcpy(staged.data() + plan->counts_at, host.counts.data(), host.counts.size());
+    int rc = plan->blob.reserve(staged.size());
     if (rc) return rc;
-    // planning runs on the launching thread, ahead of the launch on the caller's stream: blocking copies
-    HIP_TRY(hipMemcpy(plan->passes.ptr, host.passes.data(), host.passes.size() * sizeof(PassDesc), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(plan->items.ptr, host.items.data(), host.items.size() * sizeof(WorkItem), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(plan->counts.ptr, host.counts.data(), host.counts.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(plan->blob.ptr, staged.data(), staged.size(), hipMemcpyHostToDevice));
     plan->nitems = (int)host.items.size();
     plan->max_parts = host.max_parts;
     *out = plan.get();
@@ -487,7 +492,7 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
 #define DLAGP_LAUNCH_MFMA(...)                                                                                     \
     hipExtLaunchKernelGGL((accumulate_mfma<__VA_ARGS__>), grid, dim3(DLAGP_MFMA_THREADS), (uint32_t)prep_lds, stream, \
                           ev_start, ev_stop, 0u, table,                                                             \
-                       plan->passes.as<const PassDesc>(), plan->items.as<const WorkItem>(), nb, S, kd, src, part, \
+                       plan->passes(), plan->items(), nb, S, kd, src, part, \
                        status, launch_flags)
 
 // how the line cores are handled (kernels_mfma.h): 0 tested for inside the sample loop; 1 one absorber per sample,
@@ -647,12 +652,12 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
                          : (use_mfma ? finalize_rank20<false, true> : finalize_rank20<false, false>);
         hipLaunchKernelGGL(fin, dim3((unsigned)nblocks), dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
                            ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
-                           plan ? plan->counts.as<const unsigned char>() : nullptr);
+                           plan ? plan->counts() : nullptr);
     } else {
         const int threads = DLAGP_FINALIZE_THREADS;
         hipLaunchKernelGGL(finalize_samples<0>, dim3((unsigned)((rows + threads - 1) / threads)), dim3(threads), 0,
                            stream, ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
-                           plan ? plan->counts.as<const unsigned char>() : nullptr);
+                           plan ? plan->counts() : nullptr);
     }
     HIP_TRY(hipGetLastError());
     return DLAGP_OK;

@@ -7,7 +7,7 @@ tag=${1:-run}; shift || true
 root=${GRAFT_REPO_ROOT:?run this on the GPU box (gpurun exports GRAFT_REPO_ROOT)}
 out=$root/gpurun_out/pmc_$tag
 mkdir -p "$out"
-args=${*:---steps 5 --warmup 1 --ramp-ms 0}
+args=${*:---steps 5 --warmup 1 --ramp-ms 0 --no-other-configs}
 : > "$out/counters.txt"
 i=0
 for group in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
