@@ -221,7 +221,7 @@ def host_description():
     return info
 
 
-def cpu_baseline(sight, evals, chunks: int = 5, chunk_seconds: float = 3.5, single_seconds: float = 4.0):
+def cpu_baseline(sight, evals, chunks: int = 5, chunk_seconds: float = 2.0, single_seconds: float = 3.0):
     """
     BASELINE.md §3 on a bounded sample of the step's evals (`evals`: parameter sets drawn from the workload):
       (iii) one process per core of this job's share (`host_cpu_share`), each PINNED to its own physical core, BLAS
