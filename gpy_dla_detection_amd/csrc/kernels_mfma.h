@@ -903,11 +903,10 @@ __device__ __forceinline__ void accumulate_mfma_body(
             for (int st = 0; st + 2 < pass_steps; ++st) DLAGP_STEP_BODY(st, true)
             DLAGP_STEP_BODY(pass_steps - 2, true)  // a pass holds an even number of steps >= 2 (chunks of 8 slots)
             // Behind this condition the wait counts of the step after the join are the minimum over the two arms -- the
-            // arm without reads -- so the last step waits for 24 of the 32 row reads (vmcnt(8) in the ISA): the wave idles
-            // for the rows' trip while the SIMD's other wave computes.  Both obvious cures were measured and are worse
-            // (profiles/r04_experiments.txt item 3): the reads made unconditional (exact wait counts, vmcnt(40..32): the
-            // last step runs beside the reads) DOUBLED the kernel time (8.5 -> 16.0 ms on config 5; not understood), and
-            // the step written out in both arms spilled 188 registers.
+            // arm without reads -- so the last step waits for 24 of the 32 row reads (vmcnt(8) in the ISA).  Making the
+            // reads unconditional gives exact counts (vmcnt(40..32): the step runs beside the reads) and changes nothing:
+            // 8208 / 8245 us against 8205 / 8249 us on config 5 (profiles/r04_experiments.txt item 3) -- the rows' trip is
+            // waited for at the head of the next pass instead.
             if (pass + 1 < pass_end) issue_rows(pd_next);
             DLAGP_STEP_BODY(pass_steps - 1, false)
         }
