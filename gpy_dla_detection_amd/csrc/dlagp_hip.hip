@@ -564,7 +564,9 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
         return fail(DLAGP_EINVAL, "internal: the profile cache is only served by the MFMA path");
     LaunchPlan *plan = nullptr;
     if (use_mfma && (rc = build_plan(g, S, &plan))) return rc;
-    const int nparts = plan ? plan->max_parts : 1;
+    // the null model on the generic kernel (one sample per sightline): four pixel ranges per sightline, always four,
+    // so that a sightline's sums are formed the same way alone and in any batch
+    const int nparts = plan ? plan->max_parts : (kd == 0 ? 4 : 1);
 
     // partial sums: [piece][sightline x ceil(S/16) blocks][row_width columns][16 samples]
     const size_t nblocks = (size_t)nb * ((S + 15) / 16);
@@ -631,7 +633,7 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
         if (lds_bytes > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_generic),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        dim3 grid((unsigned)S, (unsigned)nb);
+        dim3 grid((unsigned)S, (unsigned)nb, (unsigned)nparts);
         hipExtLaunchKernelGGL(accumulate_generic, grid, dim3(DLAGP_GENERIC_THREADS), (uint32_t)lds_bytes, stream,
                               ev_start, ev_stop, 0u, table, (long)S, kd, src, ws.part.as<double>(), status, lds_entries,
                               lds_pixels, keep_status ? 1 : 0);
@@ -922,19 +924,13 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     if ((rc = grow(g, ws.level_ll, rows * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.cdf, rows * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.alive, (size_t)(nb + 1) * sizeof(int)))) return rc;  // [nb] = sticky non-PD flag
-    const double nan = std::numeric_limits<double>::quiet_NaN();
     const long n_ll = (long)rows * max_dlas, n_base = (long)rows * (max_dlas - 1);
     g.last_stream = stream;  // the fills below already use the group's scratch
     g.launched = true;
-    hipLaunchKernelGGL(fill_f64, dim3((unsigned)std::min<long>((n_ll + 255) / 256, 2048)), dim3(256), 0, stream,
-                       d_sample_ll, n_ll, nan);
-    hipLaunchKernelGGL(fill_f64, dim3(1), dim3(256), 0, stream, d_evidences, (long)nb * max_dlas, nan);
-    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(256), 0, stream, ws.alive.as<int>(), (long)nb, 1);
-    if (!keep_sticky_flag)  // a second sweep of the same call adds to the first one's non-PD flag
-        hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, stream, ws.alive.as<int>() + nb, 1L, 0);
-    if (n_base > 0)
-        hipLaunchKernelGGL(fill_i32, dim3((unsigned)std::min<long>((n_base + 255) / 256, 2048)), dim3(256), 0, stream,
-                           d_base, n_base, 0);
+    // a second sweep of the same call adds to the first one's non-PD flag (keep_sticky_flag)
+    hipLaunchKernelGGL(sweep_init, dim3((unsigned)std::max<long>(1, std::min<long>((std::max(n_ll, n_base) + 255) / 256, 2048))),
+                       dim3(256), 0, stream, d_sample_ll, n_ll, d_evidences, (long)nb * max_dlas, ws.alive.as<int>(),
+                       (long)nb, keep_sticky_flag ? 0 : 1, n_base > 0 ? d_base : nullptr, n_base);
     HIP_TRY(hipGetLastError());
     const SampleSource src0{d_sample_z, d_sample_nhi, d_base, 1, (long)nhi_stride, max_dlas - 1, nullptr, nullptr, 0, 0, 0, 0, 0};
     // the homogeneous launch groups of this sweep: the batch itself, or the parts of a batch of mixed flavours

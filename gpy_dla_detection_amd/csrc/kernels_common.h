@@ -808,28 +808,44 @@ __global__ __launch_bounds__(DLAGP_LEVEL_THREADS) void level_finish(
     // up most of the kernel's 46-98 us).  Same values, same summation orders as the global-memory form below.
     double *work = CDF_IN_LDS ? cdf_lds : col;
 
-    // 1. Occam term, separation mask, running maximum
+    // 1. Occam term, separation mask, running maximum.  Four samples per thread at a time, their reads issued together:
+    // a sample's redshifts sit behind the index table (base -> z: two dependent trips), and one sample after the other
+    // a thread paid those trips ten times over.  "Two absorbers closer than the cut" is tested pair by pair: the smallest
+    // gap of the sorted redshifts (reference dla_gp.py:164-177: diff of the sort) IS the smallest pairwise distance, a
+    // NaN redshift compares false either way, and no sorting loop keeps the reads from being hoisted.
+    constexpr int BATCH = 4;
     double top = -__builtin_inf();
-    for (long i = tid; i < S; i += DLAGP_LEVEL_THREADS) {
-        double v = in[i] - log_s;
-        if (level > 0) {
-            double zs[DLAGP_MAX_ABSORBERS_DEV];
-            for (int j = 0; j < kd; ++j) {  // insertion sort of the sample's redshifts
-                double zj = sample_z(src, b, i, j, S, kd);
-                int m = j;
-                while (m > 0 && zs[m - 1] > zj) {
-                    zs[m] = zs[m - 1];
-                    --m;
-                }
-                zs[m] = zj;
-            }
-            bool close = false;
-            for (int j = 1; j < kd; ++j) close |= (zs[j] - zs[j - 1]) < min_z_separation;
-            if (close) v = __builtin_nan("");
+    for (long i0 = tid; i0 < S; i0 += (long)BATCH * DLAGP_LEVEL_THREADS) {
+        double v[BATCH];
+        double zs[BATCH][DLAGP_MAX_ABSORBERS_DEV];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const long i = i0 + (long)u * DLAGP_LEVEL_THREADS;
+            const long ii = i < S ? i : S - 1;
+            v[u] = in[ii] - log_s;
+            if (level > 0)
+#pragma unroll
+                for (int j = 0; j < DLAGP_MAX_ABSORBERS_DEV; ++j)
+                    if (j < kd) zs[u][j] = sample_z(src, b, ii, j, S, kd);
         }
-        col[i] = v;
-        if (CDF_IN_LDS) work[i] = v;
-        if (v == v) top = fmax(top, v);
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const long i = i0 + (long)u * DLAGP_LEVEL_THREADS;
+            if (i >= S) continue;
+            double value = v[u];
+            if (level > 0) {
+                bool close = false;
+#pragma unroll
+                for (int p = 1; p < DLAGP_MAX_ABSORBERS_DEV; ++p)
+#pragma unroll
+                    for (int q = 0; q < p; ++q)
+                        if (p < kd) close |= fabs(zs[u][p] - zs[u][q]) < min_z_separation;
+                if (close) value = __builtin_nan("");
+            }
+            col[i] = value;
+            if (CDF_IN_LDS) work[i] = value;
+            if (value == value) top = fmax(top, value);
+        }
     }
     top = block_reduce(top, true, red);
 
@@ -883,15 +899,49 @@ __global__ __launch_bounds__(DLAGP_LEVEL_THREADS) void level_finish(
     __threadfence_block();
     int *out = base + (b * (max_dlas - 1) + level) * S;
     const double *u = uniforms + (b * (max_dlas - 1) + level) * S;
-    for (long i = tid; i < S; i += DLAGP_LEVEL_THREADS) {
-        const double ui = u[i];
-        long left = 0, right = S;  // first index with cdf[index] > u  (searchsorted side="right")
-        while (left < right) {
-            const long mid = (left + right) >> 1;
-            if (cdf[mid] <= ui) left = mid + 1;
-            else right = mid;
+    // four searches per thread in flight: each is ~14 dependent reads of the cdf
+    for (long i0 = tid; i0 < S; i0 += (long)BATCH * DLAGP_LEVEL_THREADS) {
+        double ui[BATCH];
+        long left[BATCH], right[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const long i = i0 + (long)k * DLAGP_LEVEL_THREADS;
+            ui[k] = u[i < S ? i : S - 1];
+            left[k] = 0;
+            right[k] = S;  // first index with cdf[index] > u  (searchsorted side="right")
         }
-        out[i] = (int)(left < S ? left : S - 1);
+        bool busy = true;
+        while (busy) {
+            busy = false;
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k)
+                if (left[k] < right[k]) {
+                    const long mid = (left[k] + right[k]) >> 1;
+                    if (cdf[mid] <= ui[k]) left[k] = mid + 1;
+                    else right[k] = mid;
+                    busy = true;
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const long i = i0 + (long)k * DLAGP_LEVEL_THREADS;
+            if (i < S) out[i] = (int)(left[k] < S ? left[k] : S - 1);
+        }
+    }
+}
+
+// Start of an occupation sweep in one launch (reference dla_gp.py:112-119: NaN-initialised likelihoods and evidences,
+// zeroed base indices; plus this library's flags): five fill launches before, 20 us of a one-spectrum call.
+__global__ void sweep_init(double *__restrict__ sample_ll, long n_ll, double *__restrict__ evidences, long n_ev,
+                           int *__restrict__ alive, long nb, int clear_sticky, int *__restrict__ base, long n_base) {
+    const double nan = __builtin_nan("");
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_ll; i += stride) sample_ll[i] = nan;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_base; i += stride) base[i] = 0;
+    if (blockIdx.x == 0) {
+        for (long i = threadIdx.x; i < n_ev; i += blockDim.x) evidences[i] = nan;
+        for (long i = threadIdx.x; i < nb; i += blockDim.x) alive[i] = 1;
+        if (threadIdx.x == 0 && clear_sticky) alive[nb] = 0;
     }
 }
 

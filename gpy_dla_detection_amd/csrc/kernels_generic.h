@@ -71,7 +71,10 @@ __device__ __forceinline__ double block_sum(double x, double *red) {
     return total;
 }
 
-// grid: (S, nb).  Dynamic LDS: (num_entries + n_pad + MAX_LINES + 8) doubles (max over sightlines).
+// grid: (S, nb, pixel splits).  Dynamic LDS: (num_entries + n_pad + MAX_LINES + 8) doubles (max over sightlines).
+// gridDim.z > 1 (the null model: one sample per sightline, nothing to amortise the pixel loop over) cuts every
+// sightline's steps into gridDim.z equal ranges, one workgroup and one set of partial sums each (the finalisation adds
+// them in order, like the MFMA path's pieces): the null evidence of one spectrum took 68 us on one workgroup.
 __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
     const SightlineDev *__restrict__ sightlines, long S, int kd, SampleSource src, double *__restrict__ part,
     int *__restrict__ status, int lds_entries, int lds_pixels, int keep_status) {
@@ -80,17 +83,22 @@ __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
     double *a = raw + lds_entries;
     double *mult = a + lds_pixels;
     double *red = mult + DLAGP_MAX_LINES + 1;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && !keep_status) *status = 0;  // finalize raises it
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && !keep_status) *status = 0;  // finalize raises it
 
     const SightlineDev &sl = sightlines[blockIdx.y];
     const int tid = threadIdx.x;
 
     sample_absorption(sl, kd, src, sl.batch_index, blockIdx.x, S, raw, a, mult);
 
+    // this workgroup's range of steps (all of them unless the launch splits the pixels)
+    const int nsplit = gridDim.z, split = blockIdx.z;
+    const int steps_per = (sl.nsteps + nsplit - 1) / nsplit;
+    const int step_lo = min(split * steps_per, sl.nsteps), step_hi = min(step_lo + steps_per, sl.nsteps);
+
     // phase B: per-pixel weights; w overwrites raw[], q overwrites a[]
     double *w = raw;
     double sum_r2 = 0.0, sum_logd = 0.0;
-    for (int i = tid; i < sl.n_pad; i += DLAGP_GENERIC_THREADS) {
+    for (int i = step_lo * DLAGP_STEP_PIXELS + tid; i < step_hi * DLAGP_STEP_PIXELS; i += DLAGP_GENERIC_THREADS) {
         const double ai = a[i];
         const double d = fma(sl.omega2[i] * ai, ai, sl.v[i]);
         const double h = 1.0 / d;
@@ -116,18 +124,18 @@ __global__ __launch_bounds__(DLAGP_GENERIC_THREADS) void accumulate_generic(
         const int cc = c % DLAGP_TILE_COLS;
         const double *weight = tile < sl.ntw ? w : a;
         double acc = 0.0;
-        for (int step = 0; step < sl.nsteps; ++step) {
+        for (int step = step_lo; step < step_hi; ++step) {
 #pragma unroll
             for (int slot = 0; slot < DLAGP_STEP_PIXELS; ++slot)
                 acc = fma(weight[step * DLAGP_STEP_PIXELS + slot],
                           sl.P[shared_operand_index(step, tile, slot, cc, sl.npair)], acc);
         }
-        part[partial_index(0, nblocks, block, sl.row_width, c, lane16)] = acc;
+        part[partial_index(split, nblocks, block, sl.row_width, c, lane16)] = acc;
     }
     if (tid == 0) {
-        part[partial_index(0, nblocks, block, sl.row_width, nt * DLAGP_TILE_COLS, lane16)] = sum_r2;
-        part[partial_index(0, nblocks, block, sl.row_width, nt * DLAGP_TILE_COLS + 1, lane16)] = sum_logd;
-        part[partial_index(0, nblocks, block, sl.row_width, nt * DLAGP_TILE_COLS + 2, lane16)] = sl.n * DLAGP_LOG_2PI;
+        part[partial_index(split, nblocks, block, sl.row_width, nt * DLAGP_TILE_COLS, lane16)] = sum_r2;
+        part[partial_index(split, nblocks, block, sl.row_width, nt * DLAGP_TILE_COLS + 1, lane16)] = sum_logd;
+        part[partial_index(split, nblocks, block, sl.row_width, nt * DLAGP_TILE_COLS + 2, lane16)] = split == 0 ? sl.n * DLAGP_LOG_2PI : 0.0;
     }
 }
 
