@@ -259,6 +259,7 @@ struct PinnedBuffer {
 // scratch shared by the launches of one launch group
 struct Workspace {
     DeviceBuffer part;    // partial rows [nsplit][rows][row_width]
+    DeviceBuffer part2;   // ranks above 20 on the MFMA path: the column groups' sums regrouped into one row per block
     DeviceBuffer status;  // int flag raised by finalize on a non-PD pivot
     DeviceBuffer z, nhi, out;  // staging for the host-pointer entry points
     // device-resident occupation sweep: raw level log-likelihoods, cdf scratch, per-sightline alive flag,
@@ -278,6 +279,7 @@ struct Workspace {
         sample_ll.release();
         base.release();
         part.release();
+        part2.release();
         status.release();
         z.release();
         nhi.release();
@@ -300,6 +302,7 @@ static Option g_opt_shared_rows = 1;  // cached levels: a wave whose samples sta
 // test hook: contexts with a negative noise variance stay on the MFMA kernel (default: they take the generic kernel, whose
 // per-pixel log(d) is NaN for any negative d as in the reference) -- the tests of that kernel's non-PD flag need them
 static Option g_opt_negative_noise_mfma = 0;
+static Option g_opt_finalize_wave = 1;  // ranks above 20: one wave per sample factors the matrix in LDS (0: one thread per sample)
 
 // Decomposition of one MFMA launch (a launch group at one sample count) into work items, see build_plan
 struct LaunchPlan {
@@ -329,6 +332,7 @@ struct LaunchGroup {
     hipStream_t last_stream = nullptr;  // stream of the most recent launch (drained before buffers are recycled)
     bool launched = false;
     bool mfma_ok = false;
+    int col_groups = 1;         // MFMA path: column groups per block (1 for rank <= 20, see kernels_mfma.h)
     bool grid_uniform = false;  // every member's wavelength grid is log-uniform (core patch eligible)
     bool lls_break = false;     // members carry the Lyman-limit term (all or none, else no MFMA path)
     Workspace ws;
@@ -412,7 +416,8 @@ struct dlagp_ctx {
     bool negative_noise = false;        // v or omega2 has a negative entry: d = omega2 a^2 + v may be negative
     std::vector<int> h_pos;    // host copy of pos[]
     std::vector<int> h_slot_pos;  // window start of every slot (padding slots repeat their chunk's last pixel), for planning
-    bool mfma_ok = false;      // rank padded to 20
+    bool mfma_ok = false;      // the MFMA kernel can serve this sightline
+    int col_groups = 1;        // ... with this many column groups (1: rank <= 20, padded to 20)
     LaunchGroup self;          // the group {this}
     std::vector<dlagp_batch *> batches;  // live batches this context is a member of (g_membership_mutex)
 };
@@ -427,8 +432,9 @@ static std::mutex g_membership_mutex;
 // ------------------------------------------------------------------------------------------------
 // planning (MFMA path): plan_host.h -- pure host code, also built alone under ASan/UBSan and fuzzed on the CPU
 // ------------------------------------------------------------------------------------------------
-static plan::Options planner_options() {
+static plan::Options planner_options(int column_groups = 1) {
     plan::Options opt;
+    opt.column_groups = column_groups;
     opt.pixel_splits = g_opt_pixel_splits;
     opt.item_cost = g_opt_plan_item_cost;
     opt.rest_first = g_opt_plan_rest_first;
@@ -451,7 +457,7 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
         members.push_back(plan::Sightline{&c->h_slot_pos, c->sl.ntaps, (long)(c->sl.n_slots / DLAGP_CHUNK_PIXELS)});
     plan::HostPlan host;
     std::string err;
-    if (plan::build(members, S, planner_options(), host, err)) return fail(DLAGP_EINVAL, "%s", err.c_str());
+    if (plan::build(members, S, planner_options(g.col_groups), host, err)) return fail(DLAGP_EINVAL, "%s", err.c_str());
     // One plan per distinct (S, planner options): a by-sample run adds one per slice size, a tuning session one per
     // option set.  Beyond kMaxPlans the cache starts over -- after draining the group's stream, since a launch in
     // flight still reads its plan.
@@ -544,6 +550,21 @@ static bool mfma_path_serves(const LaunchGroup &g, int kd, bool cached = false) 
     return g.mfma_ok && kd >= 1 && mfma_prep_lds <= 40 * 1024 && g_opt_path != 1;
 }
 
+// finalisation of a general rank (above 20) from column-major rows: one wave per sample, or (option finalize_wave = 0,
+// the cross-check) one thread per sample
+static void launch_finalize_general(hipStream_t stream, const double *part, int nsplit, long rows, long S,
+                                    const SightlineDev *table, double *d_out, int *status, const unsigned char *counts) {
+    if (g_opt_finalize_wave) {
+        const size_t lds = (size_t)DLAGP_FINW_SAMPLES * finalize_wave_lds_doubles(DLAGP_MAX_RANK) * sizeof(double);
+        hipLaunchKernelGGL(finalize_wave, dim3((unsigned)((rows + DLAGP_FINW_SAMPLES - 1) / DLAGP_FINW_SAMPLES)),
+                           dim3(64 * DLAGP_FINW_SAMPLES), lds, stream, part, nsplit, rows, S, table, d_out, status, counts);
+    } else {
+        const int threads = DLAGP_FINALIZE_THREADS;
+        hipLaunchKernelGGL(finalize_samples<0>, dim3((unsigned)((rows + threads - 1) / threads)), dim3(threads), 0, stream,
+                           part, nsplit, rows, S, table, d_out, status, counts);
+    }
+}
+
 // One homogeneous launch group: accumulate + finalize.  `status`: the non-PD flag the finalisation raises (the
 // group's own unless the caller shares one between the parts of a heterogeneous batch); `keep_status`: this launch
 // must not clear it (an earlier part of the same level may have raised it).
@@ -559,7 +580,7 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
 
     bool use_mfma = mfma_path_serves(g, kd, src.cache_mode == 2);
     if (g_opt_path == 2 && kd >= 1 && !use_mfma)
-        return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (rank > 20, mixed line counts / broadening / Lyman-limit flags, or kd x lines too large)");
+        return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (negative noise variance, mixed line counts / broadening / Lyman-limit flags, or kd x lines too large)");
     if (!use_mfma && src.cache_mode)
         return fail(DLAGP_EINVAL, "internal: the profile cache is only served by the MFMA path");
     LaunchPlan *plan = nullptr;
@@ -570,7 +591,11 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
 
     // partial sums: [piece][sightline x ceil(S/16) blocks][row_width columns][16 samples]
     const size_t nblocks = (size_t)nb * ((S + 15) / 16);
-    const size_t part_bytes = (size_t)nparts * nblocks * g.row_width * 16 * sizeof(double);
+    // ranks above 20 on the MFMA path: every column group leaves rank-20-sized sums, regrouped into ws.part2 (below)
+    const bool grouped = use_mfma && g.col_groups > 1;
+    const size_t part_bytes = grouped ? (size_t)g.col_groups * nparts * nblocks * DLAGP_MFMA_ROW_WIDTH * 16 * sizeof(double)
+                                      : (size_t)nparts * nblocks * g.row_width * 16 * sizeof(double);
+    if (grouped && (rc = grow(g, ws.part2, nblocks * g.row_width * 16 * sizeof(double)))) return rc;
     // kernels enqueued earlier may still be using the buffer that a larger request replaces: grow() drains them
     if ((rc = grow(g, ws.part, part_bytes))) return rc;
     if ((rc = grow(g, ws.status, sizeof(int)))) return rc;
@@ -610,7 +635,8 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
         g_last_launch_patch = patch;
         const bool lls = g.lls_break;
         double *part = ws.part.as<double>();
-        const int launch_flags = (keep_status ? DLAGP_LAUNCH_KEEP_STATUS : 0) | (g_opt_shared_rows ? 0 : DLAGP_LAUNCH_GENERAL_ROWS);
+        const int launch_flags = (keep_status ? DLAGP_LAUNCH_KEEP_STATUS : 0) | (g_opt_shared_rows ? 0 : DLAGP_LAUNCH_GENERAL_ROWS) |
+                                 (nparts & DLAGP_LAUNCH_PIECES_MASK);
         if (src.cache_mode == 2) {
             // [kd - 1][16] stacked rows of the wave's samples + its pool of 16 distinct rows (ints), see accumulate_mfma_body
             const size_t prep_lds = (size_t)(DLAGP_MAX_ABSORBERS * 16) * sizeof(int);
@@ -646,7 +672,11 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
         tg.armed = false;
     }
 
-    if (g.k == DLAGP_FIN_K) {
+    if (grouped) {
+        hipLaunchKernelGGL(regroup_native, dim3((unsigned)nblocks), dim3(256), 0, stream, ws.part.as<const double>(), nparts,
+                           (long)S, table, plan->counts(), ws.part2.as<double>());
+        launch_finalize_general(stream, ws.part2.as<const double>(), 1, rows, (long)S, table, d_out, status, nullptr);
+    } else if (g.k == DLAGP_FIN_K) {
         const size_t lds_bytes = DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double);
         const bool row16 = (int64_t)nblocks <= g_opt_finalize_row16_blocks;
         // which layout the partial sums are in: the MFMA kernel's tiles as they come, or the generic kernel's columns
@@ -656,10 +686,8 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
                            ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
                            plan ? plan->counts() : nullptr);
     } else {
-        const int threads = DLAGP_FINALIZE_THREADS;
-        hipLaunchKernelGGL(finalize_samples<0>, dim3((unsigned)((rows + threads - 1) / threads)), dim3(threads), 0,
-                           stream, ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
-                           plan ? plan->counts() : nullptr);
+        launch_finalize_general(stream, ws.part.as<const double>(), nparts, rows, (long)S, table, d_out, status,
+                                plan ? plan->counts() : nullptr);
     }
     HIP_TRY(hipGetLastError());
     return DLAGP_OK;
@@ -951,7 +979,8 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     for (Target &t : targets) {
         LaunchGroup &tg = *t.g;
         Workspace &tws = tg.ws;
-        bool use_cache = g_opt_profile_cache != 0 && max_dlas > 1;
+        // (ranks above 20 run every block once per column group: each would store / stream the rows again -- they recompute)
+        bool use_cache = g_opt_profile_cache != 0 && max_dlas > 1 && tg.col_groups == 1;
         for (int level = 0; level < max_dlas; ++level) use_cache = use_cache && mfma_path_serves(tg, level + 1, level > 0);
         const size_t cache_bytes = tg.ctxs.size() * (size_t)S * (size_t)tg.max_slots * sizeof(double);
         const size_t want_bytes = cache_bytes;  // the profiles; the deeper levels multiply cached rows, nothing is written back
@@ -1108,6 +1137,7 @@ static int finish_group(LaunchGroup &g, const std::vector<int> *positions = null
     g.mfma_ok = true;
     g.grid_uniform = true;
     g.lls_break = g.ctxs[0]->sl.lls_break != 0;
+    g.col_groups = g.ctxs[0]->col_groups;  // a batch's members share one rank (dlagp_batch_create)
     bool lls_mixed = false;
     for (dlagp_ctx *ctx : g.ctxs) {
         lls_mixed = lls_mixed || (ctx->sl.lls_break != 0) != g.lls_break;
@@ -1133,7 +1163,7 @@ static int finish_group(LaunchGroup &g, const std::vector<int> *positions = null
 static int split_mixed_batch(LaunchGroup &g) {
     if (g.mfma_ok) return DLAGP_OK;
     for (const dlagp_ctx *ctx : g.ctxs)
-        if (!ctx->mfma_ok) return DLAGP_OK;  // rank above 20: the generic kernel serves the whole batch
+        if (!ctx->mfma_ok) return DLAGP_OK;  // a member the MFMA kernel cannot serve (negative noise variance): the generic kernel serves the whole batch
     typedef std::tuple<int, int, int> Flavour;  // line count, taps, Lyman-limit flag
     std::map<Flavour, std::vector<int>> members;
     for (size_t b = 0; b < g.ctxs.size(); ++b) {
@@ -1230,7 +1260,12 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     }
     // MFMA path: slot order (zero-weight slots close a chunk at a wide mask gap, so every mask is plannable)
     std::vector<int> slot_pixel;
-    ctx->mfma_ok = k_eff == DLAGP_MFMA_RANK;
+    // Every rank runs the MFMA kernel: up to 20 as rank 20 (one column group); above, the k (k + 1) / 2 + k columns in
+    // groups of 210 + 20, each contracted by its own waves (kernels_mfma.h, kernels_common.h regroup_native)
+    ctx->mfma_ok = true;
+    ctx->col_groups = k_eff == DLAGP_MFMA_RANK ? 1
+                      : std::max((k_eff * (k_eff + 1) / 2 + DLAGP_MFMA_GROUP_W_COLS - 1) / DLAGP_MFMA_GROUP_W_COLS,
+                                 (k_eff + DLAGP_MFMA_GROUP_Q_COLS - 1) / DLAGP_MFMA_GROUP_Q_COLS);
     if (ctx->mfma_ok) {
         std::vector<int> real_pos(hpos.begin(), hpos.begin() + n);
         plan::plan_slots(real_pos, n, sl.ntaps, slot_pixel, ctx->h_slot_pos);
@@ -1240,7 +1275,7 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
 
     const size_t px = (size_t)sl.n_pad * sizeof(double);
     const size_t p_bytes = (size_t)sl.nsteps * sl.npair * 2 * DLAGP_TILE_DOUBLES * sizeof(double);
-    const size_t pm_bytes = (size_t)sl.nsteps_m * DLAGP_MFMA_PAIRS * 2 * DLAGP_TILE_DOUBLES * sizeof(double);
+    const size_t pm_bytes = (size_t)ctx->col_groups * sl.nsteps_m * DLAGP_MFMA_PAIRS * 2 * DLAGP_TILE_DOUBLES * sizeof(double);
     rc = ctx->y.reserve(px);
     if (!rc) rc = ctx->mu.reserve(px);
     if (!rc) rc = ctx->omega2.reserve(px);
@@ -1287,7 +1322,7 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
                            ctx->slot_pixel.as<const int>(), ctx->slot_pos.as<const int>(), sl.y, sl.mu, sl.omega2, sl.v,
                            ctx->aux.as<double>());
         hipLaunchKernelGGL(build_mfma_operand, dim3(1024), dim3(256), 0, setup, ctx->dense_M.as<double>(),
-                           ctx->slot_pixel.as<const int>(), sl.n_slots, ctx->Pm.as<double>());
+                           ctx->slot_pixel.as<const int>(), sl.n_slots, ctx->Pm.as<double>(), k_eff, ctx->col_groups);
     }
     hipLaunchKernelGGL(build_shared_operand, dim3(1024), dim3(256), 0, setup, ctx->dense_M.as<double>(), n, sl.n_pad,
                        k_eff, sl.ntw, sl.ntq, sl.npair, ctx->P.as<double>());
@@ -2003,6 +2038,7 @@ int dlagp_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "shared_work_stream")) g_opt_shared_work_stream = value != 0;
     else if (!strcmp(name, "shared_rows")) g_opt_shared_rows = value != 0;
     else if (!strcmp(name, "negative_noise_mfma")) g_opt_negative_noise_mfma = value != 0;
+    else if (!strcmp(name, "finalize_wave")) g_opt_finalize_wave = value != 0;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 }
@@ -2043,6 +2079,7 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "shared_work_stream")) *value = g_opt_shared_work_stream;
     else if (!strcmp(name, "shared_rows")) *value = g_opt_shared_rows;
     else if (!strcmp(name, "negative_noise_mfma")) *value = g_opt_negative_noise_mfma;
+    else if (!strcmp(name, "finalize_wave")) *value = g_opt_finalize_wave;
     else if (!strcmp(name, "big_allocs")) *value = g_stat_big_allocs;
     else if (!strcmp(name, "big_frees")) *value = g_stat_big_frees;
     else if (!strcmp(name, "last_launch_path")) *value = g_last_launch_path;

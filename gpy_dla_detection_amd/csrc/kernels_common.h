@@ -211,11 +211,19 @@ __device__ __forceinline__ void vech_invert(int col, int &a, int &b) {
     b = col - a * (a + 1) / 2;
 }
 
+// Ranks above 20 (K = the rank, `colgroups` > 1): the same layout once per column group g, group after group; group g
+// carries vech columns 210 g .. 210 g + 209 (13 full tiles + the small w-MFMA's two) and columns 20 g .. 20 g + 19 of M (tile
+// 13 + the small q-MFMA's four); columns beyond k (k + 1) / 2 resp. k are zero.
+#define DLAGP_MFMA_GROUP_W_COLS 210
+#define DLAGP_MFMA_GROUP_Q_COLS 20
 __global__ void build_mfma_operand(const double *__restrict__ M_dev, const int *__restrict__ slot_pixel, int n_slots,
-                                   double *__restrict__ Pm) {
-    constexpr int K = 20;
-    const long total = (long)n_slots * DLAGP_MFMA_PAIRS * 16 * 2;  // (slot, pair, lane-in-slot 0..15, half)
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+                                   double *__restrict__ Pm, int K, int colgroups) {
+    const long per_group = (long)n_slots * DLAGP_MFMA_PAIRS * 16 * 2;  // (slot, pair, lane-in-slot 0..15, half)
+    const long total = per_group * colgroups;
+    const int W = K * (K + 1) / 2;
+    for (long at = blockIdx.x * (long)blockDim.x + threadIdx.x; at < total; at += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(at / per_group);
+        const long idx = at % per_group;
         const int half = idx & 1;
         const int cc = (idx >> 1) & 15;
         const int pair = (idx >> 5) % DLAGP_MFMA_PAIRS;
@@ -224,31 +232,29 @@ __global__ void build_mfma_operand(const double *__restrict__ M_dev, const int *
         double val = 0.0;
         if (i >= 0) {
             const double *row = M_dev + (long)i * K;
+            int wcol = -1, qcol = -1;  // column of vech(M_i M_i') resp. of M_i this element carries
             if (pair < DLAGP_MFMA_PAIRS - 1) {
                 const int tile = 2 * pair + half;
-                if (tile < DLAGP_MFMA_W_TILES) {
-                    int a, b;
-                    vech_invert(tile * 16 + cc, a, b);
-                    val = row[a] * row[b];
-                } else {
-                    val = row[cc];
-                }
+                if (tile < DLAGP_MFMA_W_TILES) wcol = g * DLAGP_MFMA_GROUP_W_COLS + tile * 16 + cc;
+                else qcol = g * DLAGP_MFMA_GROUP_Q_COLS + cc;
             } else {
                 const int j = cc & 3;  // replicated over the four blocks cc >> 2
                 if (half == 0) {
-                    const int col = DLAGP_MFMA_SMALL_W_COL + j;
-                    if (col < K * (K + 1) / 2) {
-                        int a, b;
-                        vech_invert(col, a, b);
-                        val = row[a] * row[b];
-                    }
+                    if (j < 2) wcol = g * DLAGP_MFMA_GROUP_W_COLS + DLAGP_MFMA_SMALL_W_COL + j;
                 } else {
-                    val = row[DLAGP_MFMA_SMALL_Q_COL + j];
+                    qcol = g * DLAGP_MFMA_GROUP_Q_COLS + DLAGP_MFMA_SMALL_Q_COL + j;
                 }
+            }
+            if (wcol >= 0 && wcol < W) {
+                int a, b;
+                vech_invert(wcol, a, b);
+                val = row[a] * row[b];
+            } else if (qcol >= 0 && qcol < K) {
+                val = row[qcol];
             }
         }
         const int step = slot / DLAGP_STEP_PIXELS, s_in = slot % DLAGP_STEP_PIXELS;
-        Pm[(((long)step * DLAGP_MFMA_PAIRS + pair) * 64 + s_in * 16 + cc) * 2 + half] = val;
+        Pm[g * per_group + (((long)step * DLAGP_MFMA_PAIRS + pair) * 64 + s_in * 16 + cc) * 2 + half] = val;
     }
 }
 
@@ -368,6 +374,88 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Finalisation for ranks above 20: ONE WAVE per sample (finalize_samples<0> gives a sample to one thread, whose
+// k (k + 1) / 2 matrix entries then live in scratch memory: 13.7 ms for 10 000 samples at k = 64, four times the
+// accumulate kernel).  The sample's matrix B = I + [sum of the pieces] sits packed in LDS (row i at i (i + 1) / 2) with u
+// behind it; column by column (right-looking): lane = row scales its entry of column j, takes its share of the forward
+// solve, and updates its row's trailing entries.  Same formula as null_gp.py:343-358, another summation order than
+// finalize_samples (agreement to rounding).  blockDim = 64 x DLAGP_FINW_SAMPLES; dynamic LDS: that many matrices.
+// ---------------------------------------------------------------------------------------------
+#define DLAGP_FINW_SAMPLES 2
+__host__ __device__ __forceinline__ int finalize_wave_lds_doubles(int k) { return k * (k + 1) / 2 + k; }
+// one wave's LDS writes before another lane's reads: the LDS serves a wave's operations in issue order, so program order
+// (the asm's memory clobber) and an lgkmcnt wait are all it takes
+__device__ __forceinline__ void finw_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64 * DLAGP_FINW_SAMPLES) void finalize_wave(
+    const double *__restrict__ part, int nsplit, long rows, long S, const SightlineDev *__restrict__ sightlines,
+    double *__restrict__ out, int *__restrict__ status, const unsigned char *__restrict__ part_counts) {
+    extern __shared__ double finw_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = blockIdx.x * (long)DLAGP_FINW_SAMPLES + wave;
+    if (row >= rows) return;  // whole waves leave; no workgroup barrier below
+    const long b = row / S, smp = row % S;
+    const SightlineDev &sl = sightlines[b];
+    const int k = sl.k, W = k * (k + 1) / 2;
+    const int rw = sl.row_width;
+    const int qbase = sl.ntw * DLAGP_TILE_COLS, sbase = (sl.ntw + sl.ntq) * DLAGP_TILE_COLS;
+    const long ngroups = (S + 15) / 16;
+    const long nblocks = (rows / S) * ngroups;
+    const long block = b * ngroups + smp / 16;
+    const int lane16 = (int)(smp % 16);
+    if (part_counts) nsplit = part_counts[block];
+    double *A = finw_lds + (long)wave * finalize_wave_lds_doubles(DLAGP_MAX_RANK);
+    double *u = A + W;
+    auto partial = [&](int h, int col) { return part[partial_index(h, nblocks, block, rw, col, lane16)]; };
+    for (int c = lane; c < W + k; c += 64) {
+        double acc = 0.0;
+        for (int h = 0; h < nsplit; ++h) acc += partial(h, c < W ? c : qbase + (c - W));
+        A[c] = acc;
+    }
+    double sum_r2 = 0.0, sum_logd = 0.0;
+    for (int h = 0; h < nsplit; ++h) {
+        sum_r2 += partial(h, sbase);
+        sum_logd += partial(h, sbase + 1);
+    }
+    finw_sync();
+    bool bad = false;
+    double tt = 0.0, log_diag = 0.0;
+    for (int j = 0; j < k; ++j) {
+        const double s = A[vech_col(j, j)] + 1.0;  // identity on the diagonal (null_gp.py:341); already updated by columns < j
+        if (s <= 0.0) bad = true;                  // NaN pivots propagate silently, as LAPACK's do
+        const double diag = sqrt(s);
+        log_diag += log(diag);
+        const double tj = u[j] / diag;  // forward solve, column-oriented: u_i -= L_ij t_j for i > j
+        tt = fma(tj, tj, tt);
+        const int i = j + 1 + lane;  // this lane's row (k <= 64: one row per lane)
+        double lij = 0.0;
+        if (i < k) {
+            lij = A[vech_col(i, j)] / diag;
+            A[vech_col(i, j)] = lij;
+            u[i] = fma(-lij, tj, u[i]);
+        }
+        finw_sync();
+        if (i < k) {
+            // trailing update of row i: A[i][m] -= L[i][j] L[m][j], m = j + 1 .. i
+            double *row_i = A + vech_col(i, 0);
+            for (int m = j + 1; m <= i; ++m) row_i[m] = fma(-lij, A[vech_col(m, j)], row_i[m]);
+        }
+        finw_sync();
+    }
+    if (lane == 0) {
+        double result = -0.5 * ((sum_r2 - tt) + (sum_logd + 2.0 * log_diag) + sl.n * DLAGP_LOG_2PI);
+        if (bad) {
+            result = __builtin_nan("");
+            atomicOr(status, 1);
+        }
+        out[sl.batch_index * S + smp] = result;  // the caller's row of this sightline
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Finalisation for the fixed rank K = 20 (the production path): 16 samples per workgroup.
 //   stage   every column of [B - I | u | scalars], summed over the splits in index order, goes to
 //           LDS as lds[column][sample]: independent coalesced loads shared by the 4 waves of the
@@ -415,6 +503,49 @@ __device__ __forceinline__ void static_for(F &&f) {
 __host__ __device__ __forceinline__ int native_tile_offset(int tile, int sample, int cc) {
     const int r = sample >> 2;
     return ((tile * 2 + (r >> 1)) * 64 + ((sample & 3) << 4) + cc) * 2 + (r & 1);
+}
+
+// Ranks above 20 on the MFMA path.  Column group g of a (piece, block) leaves its sums in the native layout above, at
+// piece index g nparts + piece of a buffer of DLAGP_MFMA_ROW_WIDTH-wide rows.  This kernel adds a block's pieces in piece
+// order and sorts the groups' columns into ONE column-major row of the sightline's own width -- the generic kernel's
+// layout -- for finalize_samples: vech column c of group c / 210, column j of u of group j / 20, the three scalars of
+// group 0 (every group forms them; they are equal).  grid: blocks of 16 samples.
+__global__ __launch_bounds__(256) void regroup_native(const double *__restrict__ part, int nparts, long S,
+                                                      const SightlineDev *__restrict__ sightlines,
+                                                      const unsigned char *__restrict__ part_counts,
+                                                      double *__restrict__ rows_out) {
+    const long block = blockIdx.x, nblocks = gridDim.x;
+    const long ngroups = (S + 15) / 16;
+    const SightlineDev &sl = sightlines[block / ngroups];
+    const int k = sl.k, W = k * (k + 1) / 2;
+    const int qbase = sl.ntw * DLAGP_TILE_COLS, sbase = (sl.ntw + sl.ntq) * DLAGP_TILE_COLS;
+    const int nsplit = part_counts ? part_counts[block] : nparts;
+    constexpr int RW = (14 + 2) * DLAGP_TILE_COLS + DLAGP_ROW_EXTRA;  // DLAGP_MFMA_ROW_WIDTH (kernels_mfma.h): a rank-20 row
+    for (int idx = threadIdx.x; idx < (W + k + 3) * 16; idx += blockDim.x) {
+        const int c = idx >> 4, s = idx & 15;
+        int g, off, dest;
+        if (c < W) {
+            g = c / DLAGP_MFMA_GROUP_W_COLS;
+            const int l = c % DLAGP_MFMA_GROUP_W_COLS;
+            off = l < DLAGP_MFMA_SMALL_W_COL ? native_tile_offset(l >> 4, s, l & 15)
+                                             : DLAGP_NATIVE_EXTRAS + (l - DLAGP_MFMA_SMALL_W_COL) * 16 + s;
+            dest = c;
+        } else if (c < W + k) {
+            const int j = c - W;
+            g = j / DLAGP_MFMA_GROUP_Q_COLS;
+            const int l = j % DLAGP_MFMA_GROUP_Q_COLS;
+            off = l < DLAGP_MFMA_SMALL_Q_COL ? native_tile_offset(DLAGP_MFMA_W_TILES, s, l)
+                                             : DLAGP_NATIVE_EXTRAS + (2 + l - DLAGP_MFMA_SMALL_Q_COL) * 16 + s;
+            dest = qbase + j;
+        } else {
+            g = 0;
+            off = DLAGP_NATIVE_EXTRAS + (6 + c - W - k) * 16 + s;
+            dest = sbase + (c - W - k);
+        }
+        double acc = 0.0;
+        for (int h = 0; h < nsplit; ++h) acc += part[partial_index((long)g * nparts + h, nblocks, block, RW, 0, 0) + off];
+        rows_out[partial_index(0, nblocks, block, sl.row_width, dest, s)] = acc;
+    }
 }
 
 // NATIVE: the partial sums come from the MFMA kernel (layout above); else from the generic kernel (column-major).

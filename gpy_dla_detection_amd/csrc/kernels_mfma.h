@@ -54,6 +54,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define DLAGP_RAW_STRIDE 67      // doubles per sample row in LDS; odd -> conflict-free ds_read2_b64 windows
 #define DLAGP_AUX_FIELDS 8       // per-pixel record: y, mu, omega2, v, window start, 3 spare
 #define DLAGP_BUFFER_FLAGS 0x00020000  // word 3 of a raw buffer resource on gfx9-family targets
+#define DLAGP_LAUNCH_PIECES_MASK 0xff       // launch_flags, low byte: pieces per block of the launch plan (the partial sums'
+                                           // stride between column groups)
+#define DLAGP_MFMA_ROW_WIDTH ((14 + 2) * DLAGP_TILE_COLS + DLAGP_ROW_EXTRA)  // 264: row_width of a rank-20 sightline (ntw 14, ntq 2)
 #define DLAGP_LAUNCH_KEEP_STATUS 0x10000   // launch_flags: do not clear the non-PD flag (see accumulate_mfma)
 #define DLAGP_LAUNCH_GENERAL_ROWS 0x20000  // cached levels: 16 row reads per pass even where one would do (option shared_rows = 0)
 // DLAGP_MFMA_GROUP (16 samples per wave), DLAGP_PASS_ENTRIES, DLAGP_CHUNK_PIXELS, DLAGP_MAX_PASS_STEPS / _CHUNKS and the
@@ -285,6 +288,11 @@ __device__ __forceinline__ void accumulate_mfma_body(
     const SightlineDev &sl = sightlines[b];
     const long gb = sl.batch_index;  // this sightline's position in the caller's sample arrays
     const int split = __builtin_amdgcn_readfirstlane(item.part);
+    // Ranks above 20: the sightline's columns -- vech(M_p M_p') and M_p -- are contracted in groups of 210 + 20, each
+    // group by its own waves with this same body: the group's slice of the operand (below) and its own partial sums
+    // (epilogue).  The Voigt / weights work is repeated per group; against the 2.4x (k = 32) to 9.3x (k = 64) MFMA work
+    // of such a rank that is the cheaper price than a kernel of its own.  Always 0 for rank <= 20.
+    const int colgroup = __builtin_amdgcn_readfirstlane(item.colgroup);
     const long group = __builtin_amdgcn_readfirstlane(item.group);
     const int lane = threadIdx.x;
     const int s_loc = lane & 15;
@@ -296,7 +304,8 @@ __device__ __forceinline__ void accumulate_mfma_body(
     // P and the per-pixel records are streamed with buffer loads: scalar resource + per-lane byte
     // offset + scalar step offset + immediate, i.e. no vector address arithmetic in the loops
     const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)as_global<gptr_d>(sl.Pm), 0, sl.nsteps_m * (2 * DLAGP_MFMA_PAIRS * DLAGP_TILE_DOUBLES * 8), DLAGP_BUFFER_FLAGS);
+        (void *)as_global<gptr_d>(sl.Pm + (long)colgroup * sl.nsteps_m * (2 * DLAGP_MFMA_PAIRS * DLAGP_TILE_DOUBLES)), 0,
+        sl.nsteps_m * (2 * DLAGP_MFMA_PAIRS * DLAGP_TILE_DOUBLES * 8), DLAGP_BUFFER_FLAGS);
     const __amdgpu_buffer_rsrc_t aux_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)as_global<gptr_d>(sl.aux), 0, sl.n_slots * (DLAGP_AUX_FIELDS * 8), DLAGP_BUFFER_FLAGS);
     const int p_voff = lane * 16;                         // one double2 per lane and tile pair
@@ -952,12 +961,15 @@ __device__ __forceinline__ void accumulate_mfma_body(
     // beyond S are never read back as results) and no transposition -- the finalisation sorts them into its LDS image
     // while it sums the pieces (kernels_common.h, native_tile_offset).  Up to round 2 every tile went through LDS
     // first and left in 56 stores of 8 bytes per lane.
-    const int rw = sl.row_width;
+    // a (piece, block) of partial sums is DLAGP_MFMA_ROW_WIDTH x 16 doubles whatever the rank (= row_width at rank 20);
+    // column group g's pieces follow those of group g - 1: [group][piece][block]
+    const int rw = DLAGP_MFMA_ROW_WIDTH;
     const long rows_left = S - sample0;  // valid samples of this wave
     const long ngroups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
     const long nblocks = (long)nb * ngroups;
     __attribute__((address_space(1))) double *base =
-        (__attribute__((address_space(1))) double *)(part) + partial_index(split, nblocks, b * ngroups + group, rw, 0, 0);
+        (__attribute__((address_space(1))) double *)(part) +
+        partial_index((long)colgroup * (launch_flags & DLAGP_LAUNCH_PIECES_MASK) + split, nblocks, b * ngroups + group, rw, 0, 0);
     typedef v2d __attribute__((address_space(1))) *gstore_d2;
     const gstore_d2 tiles = (gstore_d2)base + lane;
 #pragma unroll

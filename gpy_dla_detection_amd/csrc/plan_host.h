@@ -47,8 +47,10 @@ struct PassDesc {
 
 // One wave's work: 16 samples (`group`) of sightline `b` over the passes [pass_begin, pass_end) of the launch
 // plan's pass list; its sums go to partial slot `part` of the block.
+// `colgroup`: which slice of the sightline's columns this wave contracts (ranks above 20 run as several column groups of
+// 210 vech columns + 20 columns of M each, see kernels_mfma.h; always 0 for rank <= 20).
 struct WorkItem {
-    int b, group, part, pass_begin, pass_end, pad0, pad1, pad2;
+    int b, group, part, pass_begin, pass_end, colgroup, pad1, pad2;
 };
 
 namespace plan {
@@ -60,6 +62,7 @@ struct Options {
     int64_t rest_first = 0;    // dispatch the remainder pieces before the full ones
     int64_t slots = 2048;      // wave slots to fill: 256 CUs x 4 SIMDs x 2 waves
     int64_t xcd_affine = 1;    // batches: deal the items so that an XCD sweeps one sightline at a time
+    int64_t column_groups = 1; // ranks above 20: every (block, piece) is evaluated once per column group
 };
 
 // what the planner needs to know of one sightline
@@ -238,7 +241,10 @@ inline int build(const std::vector<Sightline> &sightlines, int64_t S, const Opti
         return DLAGP_EINVAL;
     }
     const long ngroups = (long)((S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP);
-    const long groups = (long)nb * ngroups;
+    const int colgroups = (int)std::max<int64_t>(1, opt.column_groups);
+    // a block of 16 samples with G column groups fills wave slots like G blocks: the cut is chosen for that many
+    const long groups = (long)nb * ngroups * colgroups;
+    const long blocks = (long)nb * ngroups;
     double mean_chunks = 0.0;
     for (int b = 0; b < nb; ++b) {
         if (sightlines[b].chunks < 1 ||
@@ -256,11 +262,11 @@ inline int build(const std::vector<Sightline> &sightlines, int64_t S, const Opti
         bool rest;
     };
     std::vector<Piece> pieces;
-    pieces.reserve((size_t)groups * (full + 1));
+    pieces.reserve((size_t)blocks * (full + 1));
     std::vector<PassDesc> &passes = plan.passes;
     passes.clear();
     const bool remainder = frac * full < 1.0 - 1e-9;
-    plan.counts.assign((size_t)groups, 1);
+    plan.counts.assign((size_t)blocks, 1);
     int max_parts = 1;
     // remainder items a left-over wave slot works through (shape (B)); 1 otherwise
     const long slots_total = std::max<int64_t>(opt.slots, 1), left = slots_total - (long)full * groups;
@@ -301,7 +307,7 @@ inline int build(const std::vector<Sightline> &sightlines, int64_t S, const Opti
     // only), each with its own 4 MB L2, and a sightline's MFMA operand is 6 MB.  In (sightline, group) order every XCD
     // has waves of the ~3 sightlines that are in flight at a time; dealt so that workgroup i works on a sightline
     // b = i (mod 8), every XCD sweeps ONE sightline's operand with all of its waves.  Option "plan_xcd_affine".
-    if (opt.xcd_affine != 0 && !remainder && full == 1 && nb >= 8 && pieces.size() == (size_t)groups) {
+    if (opt.xcd_affine != 0 && !remainder && full == 1 && nb >= 8 && pieces.size() == (size_t)blocks) {
         std::vector<Piece> dealt;
         dealt.reserve(pieces.size());
         // pieces are in (b, group) order, ngroups each: rounds of 8 sightlines, inside a round group-major
@@ -312,9 +318,11 @@ inline int build(const std::vector<Sightline> &sightlines, int64_t S, const Opti
         }
         pieces.swap(dealt);
     }
+    // column groups one after the other: every phase of the launch sweeps ONE slice of the sightlines' operands
     plan.items.clear();
-    plan.items.reserve(pieces.size());
-    for (const Piece &pc : pieces) plan.items.push_back(WorkItem{pc.b, pc.group, pc.part, pc.pass_begin, pc.pass_end, 0, 0, 0});
+    plan.items.reserve(pieces.size() * colgroups);
+    for (int cg = 0; cg < colgroups; ++cg)
+        for (const Piece &pc : pieces) plan.items.push_back(WorkItem{pc.b, pc.group, pc.part, pc.pass_begin, pc.pass_end, cg, 0, 0});
     plan.max_parts = max_parts;
     plan.full = full;
     plan.frac = frac;
@@ -338,7 +346,8 @@ inline int debug(int nb, const int *n_u, const uint8_t *const *keep, int ntaps, 
         opt.rest_first = options[2];
         opt.slots = options[3];
         opt.xcd_affine = options[4];
-        if (opt.slots < 1 || opt.item_cost < 0 || opt.pixel_splits < 0) {
+        opt.column_groups = options[5];
+        if (opt.slots < 1 || opt.item_cost < 0 || opt.pixel_splits < 0 || opt.column_groups < 1 || opt.column_groups > 16) {
             err = "dlagp_plan_debug: options out of range";
             return DLAGP_EINVAL;
         }
@@ -389,11 +398,12 @@ inline int debug(int nb, const int *n_u, const uint8_t *const *keep, int ntaps, 
     if (items_out && items_cap >= (int64_t)plan.items.size())
         for (size_t i = 0; i < plan.items.size(); ++i) {
             const WorkItem &w = plan.items[i];
-            items_out[5 * i + 0] = w.b;
-            items_out[5 * i + 1] = w.group;
-            items_out[5 * i + 2] = w.part;
-            items_out[5 * i + 3] = w.pass_begin;
-            items_out[5 * i + 4] = w.pass_end;
+            items_out[6 * i + 0] = w.b;
+            items_out[6 * i + 1] = w.group;
+            items_out[6 * i + 2] = w.part;
+            items_out[6 * i + 3] = w.pass_begin;
+            items_out[6 * i + 4] = w.pass_end;
+            items_out[6 * i + 5] = w.colgroup;
         }
     if (counts_out && counts_cap >= (int64_t)plan.counts.size())
         std::copy(plan.counts.begin(), plan.counts.end(), counts_out);

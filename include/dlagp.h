@@ -330,13 +330,14 @@ int dlagp_plan_cut(int64_t groups, double chunks, int64_t forced_splits, int *fu
  * is exported by the host-only sanitizer build libdlagp_plan_host.so, csrc/plan_host_debug.cpp).  keep[b] is the mask
  * of sightline b over its n_u[b] unmasked pixels (= ~pixel_mask[ind_unmasked], reference null_gp.py:139-152), ntaps 7
  * with instrumental broadening and 1 without, S the samples per sightline, options NULL (the library's current values
- * are NOT used: defaults) or {pixel_splits, plan_item_cost, plan_rest_first, plan_slots, plan_xcd_affine}.
+ * are NOT used: defaults) or {pixel_splits, plan_item_cost, plan_rest_first, plan_slots, plan_xcd_affine, column groups
+ * (1 for rank <= 20; ranks 21..64 run every block once per group of 210 + 20 columns)}.
  *   summary[8]  {slots of all sightlines, passes, work items, blocks, most pieces per block, full pieces, remainder
  *               piece 0/1, fraction of a sightline per full piece x 1e9}
  *   slot_pixel / slot_pos [slots]   per sightline, concatenated: kept pixel of every slot (-1 = padding slot) and
  *               first entry of its convolution window
- *   passes [passes][3]  {entry_start, chunk_begin, nchunks};  items [items][5]  {sightline, block, piece, pass_begin,
- *               pass_end} in dispatch order;  counts [blocks]  pieces of block b * ceil(S / 16) + group
+ *   passes [passes][3]  {entry_start, chunk_begin, nchunks};  items [items][6]  {sightline, block, piece, pass_begin,
+ *               pass_end, column group} in dispatch order;  counts [blocks]  pieces of block b * ceil(S / 16) + group
  * Every output array may be NULL or too small (its *_cap says how many records fit): the summary then tells the sizes. */
 int dlagp_plan_debug(int nb, const int *n_u, const uint8_t *const *keep, int ntaps, int64_t S, const int64_t *options,
                      int64_t *summary, int32_t *slot_pixel, int32_t *slot_pos, int64_t slots_cap, int32_t *passes,

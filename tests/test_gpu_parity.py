@@ -148,6 +148,66 @@ def test_against_oracle_on_fresh_inputs(shape):
         np.testing.assert_allclose(dev.eval(zz, nn), want, rtol=RTOL_LL)
 
 
+@pytest.mark.parametrize("k", [21, 33, 40, 64])
+def test_ranks_above_20_run_the_mfma_kernel_in_column_groups(k, restore_options):
+    """
+    `Parameters(k=...)` is a constructor argument of the reference (set_parameters.py:36).  Ranks 21..64 used to drop to
+    the generic kernel (4.7 % of peak); they now run the MFMA kernel once per group of 210 + 20 columns, the groups' sums
+    regrouped for the general finalisation: against the oracle, against the generic kernel, one to three absorbers, a
+    gapped mask, a batch, and the multi-level device sweep (which recomputes: no profile cache above rank 20).
+    """
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch, get_option
+    from oracle import ref_like as R
+
+    set_option = restore_options
+    rng = np.random.default_rng(k)
+    sights = [make_sightline(40 + k, n_unmasked=900, n_masked=25, k=k), make_sightline(41 + k, n_unmasked=333, n_masked=60, k=k)]
+    devs = [device_sightline(s) for s in sights]
+    S = 150  # not a multiple of 16
+    for sight, dev in zip(sights, devs):
+        st = oracle_state(sight)
+        z, _, nhi = make_qmc_samples(sight, S)
+        for kd in (1, 3):
+            zz = np.stack([z] + [z[rng.permutation(S)] for _ in range(kd - 1)], axis=1)
+            nn = np.stack([nhi] + [nhi[rng.permutation(S)] for _ in range(kd - 1)], axis=1)
+            set_option("path", 2)  # refuse the generic kernel
+            got = dev.eval(zz, nn)
+            assert get_option("last_launch_path") == 2
+            want = np.array([R.sample_log_likelihood_k_dlas(st, zz[i], nn[i]) for i in range(0, S, 7)])
+            np.testing.assert_allclose(got[::7], want, rtol=RTOL_LL)
+            set_option("path", 1)
+            generic = dev.eval(zz, nn)
+            assert get_option("last_launch_path") == 1
+            np.testing.assert_allclose(got, generic, rtol=1e-10)
+            for splits in (1, 3):  # forced cuts: every piece of every column group is added up
+                set_option("path", 2)
+                set_option("pixel_splits", splits)
+                np.testing.assert_allclose(dev.eval(zz, nn), got, rtol=1e-11)
+            set_option("pixel_splits", 0)
+            set_option("finalize_wave", 0)  # the one-thread-per-sample factorisation: another summation order
+            np.testing.assert_allclose(dev.eval(zz, nn), got, rtol=1e-11)
+            set_option("finalize_wave", 1)
+            set_option("path", 0)
+        null = R.null_log_model_evidence(st)
+        assert abs(dev.null() - null) <= RTOL_LL * abs(null)
+    # a batch of the two, and the occupation sweep on the device against the host levels
+    batch = DeviceBatch(devs)
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    set_option("path", 2)
+    both = batch.eval(zs, np.stack([nhi, nhi]))
+    for b, dev in enumerate(devs):
+        np.testing.assert_allclose(both[b], dev.eval(zs[b], nhi), rtol=1e-11)  # a batch is cut elsewhere: rounding
+    ev, ll, base = parallel.sweep_batch_device(batch, zs, nhi, 3, 0.003, seed=0)
+    assert get_option("last_sweep_cached") == 0 and get_option("last_launch_path") == 2
+    set_option("path", 0)
+    ev_h, ll_h, base_h = parallel.sweep_batch(batch.eval, zs, nhi, 3, 0.003, seed=0)
+    np.testing.assert_array_equal(base, base_h)
+    np.testing.assert_allclose(ev, ev_h, rtol=1e-11)
+    np.testing.assert_allclose(ll, ll_h, rtol=1e-11, equal_nan=True)
+
+
 # ------------------------------------------------------------------------------------------------
 # the occupation sweep through the drop-in classes (reference dla_gp.py:92-225, subdla_gp.py:90-222)
 # ------------------------------------------------------------------------------------------------
@@ -658,6 +718,7 @@ def restore_options():
     set_option("shared_work_stream", 0)
     set_option("shared_rows", 1)
     set_option("negative_noise_mfma", 0)
+    set_option("finalize_wave", 1)
 
 
 @pytest.mark.parametrize("shape", [dict(index=4, n_unmasked=1250, n_masked=28, k=20),
@@ -1846,9 +1907,9 @@ def test_randomised_sightlines_against_oracle(restore_options):
         S = 24
         z, _, nhi = make_qmc_samples(sight, S)
         z = z + 1e-3 * rng.standard_normal(S)
-        set_option("path", 2 if k <= 20 else 0)  # rank <= 20: the MFMA kernel must serve it (raises otherwise)
+        set_option("path", 2)  # the MFMA kernel must serve it whatever the rank (raises otherwise)
         got = dev.eval(z, nhi)
-        assert get_option("last_launch_path") == (2 if k <= 20 else 1)
+        assert get_option("last_launch_path") == 2
         st = oracle_state(sight)
         pick = rng.choice(S, 6, replace=False)
         want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in pick])

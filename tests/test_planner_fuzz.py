@@ -59,7 +59,7 @@ def check_case(lib, ct, rng, case):
     options = None
     if case % 3:
         options = np.array([rng.integers(0, 11), rng.integers(0, 101), rng.integers(0, 2),
-                            rng.choice([1, 7, 64, 2048, 100000]), rng.integers(0, 2)], dtype=np.int64)
+                            rng.choice([1, 7, 64, 2048, 100000]), rng.integers(0, 2), rng.choice([1, 1, 3, 10])], dtype=np.int64)
     n_u = (ct.c_int * nb)(*[len(m) for m in masks])
     keep = (ct.POINTER(ct.c_ubyte) * nb)(*[m.ctypes.data_as(ct.POINTER(ct.c_ubyte)) for m in masks])
     opt_ptr = options.ctypes.data_as(ct.POINTER(ct.c_int64)) if options is not None else None
@@ -72,7 +72,7 @@ def check_case(lib, ct, rng, case):
     slot_pixel = np.full(nslots, -7, dtype=np.int32)
     slot_pos = np.full(nslots, -7, dtype=np.int32)
     passes = np.full((npasses, 3), -7, dtype=np.int32)
-    items = np.full((nitems, 5), -7, dtype=np.int32)
+    items = np.full((nitems, 6), -7, dtype=np.int32)
     counts = np.zeros(nblocks, dtype=np.uint8)
     rc = lib.dlagp_plan_debug(nb, n_u, keep, ntaps, S, opt_ptr, sp, slot_pixel.ctypes.data_as(i32),
                               slot_pos.ctypes.data_as(i32), nslots, passes.ctypes.data_as(i32), npasses,
@@ -109,8 +109,16 @@ def check_case(lib, ct, rng, case):
     # -- passes: 1..7 chunks, windows inside the 64 entries that start at the first slot's window
     assert np.all((passes[:, 2] >= 1) & (passes[:, 2] <= MAX_PASS_CHUNKS)) and np.all(passes[:, 1] >= 0)
     # -- items: b / group in range, every block's pieces tile its sightline's chunks exactly once, in piece order
-    assert nitems == int(counts.sum()) and max_parts == int(counts.max()) and counts.min() >= 1 and max_parts <= 255
-    b, grp, part, p0, p1 = items.T
+    colgroups = int(options[5]) if options is not None else 1
+    assert nitems == colgroups * int(counts.sum()) and max_parts == int(counts.max()) and counts.min() >= 1 and max_parts <= 255
+    b, grp, part, p0, p1, cg = items.T
+    # every (block, piece) once per column group, the groups one after the other
+    per_group = nitems // colgroups
+    np.testing.assert_array_equal(cg, np.repeat(np.arange(colgroups), per_group))
+    for g in range(1, colgroups):
+        np.testing.assert_array_equal(items[g * per_group:(g + 1) * per_group, :5], items[:per_group, :5])
+    items, nitems = items[:per_group], per_group
+    b, grp, part, p0, p1, cg = items.T
     assert np.all((b >= 0) & (b < nb) & (grp >= 0) & (grp < ngroups) & (part >= 0))
     assert np.all((p0 >= 0) & (p0 < p1) & (p1 <= npasses))
     block = b.astype(np.int64) * ngroups + grp
