@@ -1,4 +1,6 @@
 set -x
 mkdir -p gpurun_out/r4
-timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/r4/gpu_tests.log 2>&1
-tail -3 gpurun_out/r4/gpu_tests.log
+timeout -k 10 900 python tools/soak_paths.py 41 400 > gpurun_out/r4/soak_paths.log 2>&1
+tail -2 gpurun_out/r4/soak_paths.log
+timeout -k 10 600 python tools/soak_sweeps.py 42 300 > gpurun_out/r4/soak_sweeps3.log 2>&1
+tail -1 gpurun_out/r4/soak_sweeps3.log

@@ -24,13 +24,14 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 150):
     lines = int(rng.choice([3, 3, 3, 1, 5, 31]))
     if lls: lines = 3
     sights = []
+    rank = int(rng.choice([20, 20, 20, 12, 24, 33, 64]))  # one rank per batch; above 20: column groups of the MFMA kernel
     for b in range(nb):
         n_u = int(rng.integers(9, 3300))
         if rng.random() < 0.3 and n_u > 400:
             lo = int(rng.integers(5, n_u // 2)); run = int(rng.integers(30, n_u // 3))
-            s = gapped_sightline(index=int(rng.integers(0, 1000)), n_unmasked=n_u, gaps=((lo, lo + run),), comb=None)
+            s = gapped_sightline(index=int(rng.integers(0, 1000)), n_unmasked=n_u, gaps=((lo, lo + run),), comb=None, k=rank)
         else:
-            s = make_sightline(int(rng.integers(0, 1000)), n_unmasked=n_u, n_masked=int(rng.integers(0, max(1, n_u // 10))))
+            s = make_sightline(int(rng.integers(0, 1000)), n_unmasked=n_u, n_masked=int(rng.integers(0, max(1, n_u // 10))), k=rank)
         sights.append(s)
     mixed = nb > 1 and rng.random() < 0.4  # every member its own flavour: one MFMA launch group per flavour
     devs = []
