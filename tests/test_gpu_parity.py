@@ -206,6 +206,24 @@ def test_ranks_above_20_run_the_mfma_kernel_in_column_groups(k, restore_options)
     np.testing.assert_array_equal(base, base_h)
     np.testing.assert_allclose(ev, ev_h, rtol=1e-11)
     np.testing.assert_allclose(ll, ll_h, rtol=1e-11, equal_nan=True)
+    if k == 33:
+        # the by-sample split (one rank's slices of every level) and a batch of mixed flavours, both in column groups
+        uniforms = parallel.resampling_uniforms(2, 3, S, seed=0)
+        sliced = parallel.sweep_sharded_samples_device(batch, zs, nhi, 3, 0.003, uniforms, slices=[(0, 64), (64, 71), (71, S)])
+        np.testing.assert_array_equal(sliced[2], base)
+        np.testing.assert_allclose(sliced[0], ev, rtol=1e-11)
+        flavours = [dict(num_lines=5, broadening=True), dict(num_lines=3, broadening=False)]
+        mixed_devs = [device_sightline(s, **f) for s, f in zip(sights, flavours)]
+        mixed = DeviceBatch(mixed_devs)
+        set_option("path", 2)
+        got = mixed.eval(zs, np.stack([nhi, nhi]))
+        assert get_option("last_launch_groups") == 2 and get_option("last_launch_path") == 2
+        set_option("path", 0)
+        for b, dev in enumerate(mixed_devs):
+            np.testing.assert_allclose(got[b], dev.eval(zs[b], nhi), rtol=1e-11)
+            st = oracle_state(sights[b], **flavours[b])
+            want = np.array([R.sample_log_likelihood_k_dlas(st, [zs[b, i]], [nhi[i]]) for i in range(0, S, 11)])
+            np.testing.assert_allclose(got[b][::11], want, rtol=RTOL_LL)
 
 
 # ------------------------------------------------------------------------------------------------
