@@ -310,11 +310,17 @@ inline int build(const std::vector<Sightline> &sightlines, int64_t S, const Opti
     if (opt.xcd_affine != 0 && !remainder && full == 1 && nb >= 8 && pieces.size() == (size_t)blocks) {
         std::vector<Piece> dealt;
         dealt.reserve(pieces.size());
+        // Longest sightlines first (a catalogue batch is ragged: n follows z_qso): the eight of a round are then of
+        // similar length, and the launch ends on its shortest items instead of on whatever came last.  Equal lengths
+        // (the bench) keep their order.
+        std::vector<int> order(nb);
+        for (int b = 0; b < nb; ++b) order[b] = b;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sightlines[x].chunks > sightlines[y].chunks; });
         // pieces are in (b, group) order, ngroups each: rounds of 8 sightlines, inside a round group-major
         for (int b0 = 0; b0 < nb; b0 += 8) {
             const int width = std::min(8, nb - b0);
             for (long grp = 0; grp < ngroups; ++grp)
-                for (int x = 0; x < width; ++x) dealt.push_back(pieces[(size_t)(b0 + x) * ngroups + grp]);
+                for (int x = 0; x < width; ++x) dealt.push_back(pieces[(size_t)order[b0 + x] * ngroups + grp]);
         }
         pieces.swap(dealt);
     }

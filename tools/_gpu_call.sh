@@ -1,4 +1,4 @@
 set -x
 mkdir -p gpurun_out/r4
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "ranks_above_20" > gpurun_out/r4/gpu_tests_k.log 2>&1
-tail -15 gpurun_out/r4/gpu_tests_k.log
+bash tools/ab_catalogue_kernels.sh "1024 10000 32" ab/base.so ab/new.so ab/base.so ab/new.so > gpurun_out/r4/ab_catalogue2.txt 2>&1
+cut -c1-400 gpurun_out/r4/ab_catalogue2.txt
