@@ -1,4 +1,7 @@
 set -x
 mkdir -p gpurun_out/r4
-bash tools/ab_catalogue_kernels.sh "1024 10000 32" ab/base.so ab/new.so ab/base.so ab/new.so > gpurun_out/r4/ab_catalogue2.txt 2>&1
-cut -c1-400 gpurun_out/r4/ab_catalogue2.txt
+for i in 1 2; do
+for lib in base new; do
+  DLAGP_LIB=$PWD/ab/$lib.so python3 tools/measure_catalogue.py 2048 10000 32 2>/dev/null | tail -1 | cut -c1-140 >> gpurun_out/r4/ab_catalogue3.txt
+done; done
+cat gpurun_out/r4/ab_catalogue3.txt
