@@ -77,6 +77,7 @@ static Option g_opt_plan_item_cost = 20;   // fixed cost of a work item in the p
 static Option g_opt_plan_rest_first = 0;   // dispatch the remainder pieces before the full ones (tuning)
 static Option g_opt_plan_slots = 2048;     // wave slots the planner fills: 256 CUs x 4 SIMDs x 2 waves (tuning)
 static Option g_opt_plan_xcd_affine = 1;   // batches: deal the work items so that an XCD sweeps one sightline at a time
+static Option g_opt_plan_taper = 1;        // batches: pieces per block for the sightlines of the last round of eight (1 = off)
 // launches of up to this many blocks of 16 samples finalise with 16 lanes per sample (kernels_common.h); 0: never
 static Option g_opt_finalize_row16_blocks = DLAGP_FIN_ROW16_MAX_BLOCKS;
 // read-only diagnostics of the most recent launch / sweep (dlagp_get_option): which kernel served it
@@ -338,7 +339,7 @@ struct LaunchGroup {
     Workspace ws;
     int max_slots = 0;  // largest n_slots of a member (row stride of the profile cache)
     // key: (S, and the planner options in force: forced split count, item cost, dispatch order, slot count)
-    typedef std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t> PlanKey;
+    typedef std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t> PlanKey;
     std::map<PlanKey, std::unique_ptr<LaunchPlan>> plans;
     // A batch whose members differ in line count, broadening or Lyman-limit flag cannot share one instantiation of
     // the MFMA kernel.  Instead of sending all of them to the generic kernel (21x slower) it runs as several
@@ -440,12 +441,13 @@ static plan::Options planner_options(int column_groups = 1) {
     opt.rest_first = g_opt_plan_rest_first;
     opt.slots = g_opt_plan_slots;
     opt.xcd_affine = g_opt_plan_xcd_affine;
+    opt.taper = g_opt_plan_taper;
     return opt;
 }
 
 static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
     const LaunchGroup::PlanKey key(S, g_opt_pixel_splits, g_opt_plan_item_cost, g_opt_plan_rest_first, g_opt_plan_slots,
-                                   g_opt_plan_xcd_affine);
+                                   g_opt_plan_xcd_affine, g_opt_plan_taper);
     auto it = g.plans.find(key);
     if (it != g.plans.end()) {
         *out = it->second.get();
@@ -2033,6 +2035,7 @@ int dlagp_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "plan_rest_first")) g_opt_plan_rest_first = value;
     else if (!strcmp(name, "plan_slots")) g_opt_plan_slots = value > 0 ? value : 2048;
     else if (!strcmp(name, "plan_xcd_affine")) g_opt_plan_xcd_affine = value;
+    else if (!strcmp(name, "plan_taper")) g_opt_plan_taper = value < 1 ? 1 : (value > 8 ? 8 : value);
     else if (!strcmp(name, "finalize_row16_blocks")) g_opt_finalize_row16_blocks = value;
     else if (!strcmp(name, "spare_workspaces")) g_opt_spare_workspaces = value;
     else if (!strcmp(name, "shared_work_stream")) g_opt_shared_work_stream = value != 0;
@@ -2074,6 +2077,7 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "plan_rest_first")) *value = g_opt_plan_rest_first;
     else if (!strcmp(name, "plan_slots")) *value = g_opt_plan_slots;
     else if (!strcmp(name, "plan_xcd_affine")) *value = g_opt_plan_xcd_affine;
+    else if (!strcmp(name, "plan_taper")) *value = g_opt_plan_taper;
     else if (!strcmp(name, "finalize_row16_blocks")) *value = g_opt_finalize_row16_blocks;
     else if (!strcmp(name, "spare_workspaces")) *value = g_opt_spare_workspaces;
     else if (!strcmp(name, "shared_work_stream")) *value = g_opt_shared_work_stream;

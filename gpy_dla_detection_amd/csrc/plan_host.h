@@ -63,6 +63,7 @@ struct Options {
     int64_t slots = 2048;      // wave slots to fill: 256 CUs x 4 SIMDs x 2 waves
     int64_t xcd_affine = 1;    // batches: deal the items so that an XCD sweeps one sightline at a time
     int64_t column_groups = 1; // ranks above 20: every (block, piece) is evaluated once per column group
+    int64_t taper = 1;         // batches: pieces per block for the sightlines of the last round of eight (1 = off)
 };
 
 // what the planner needs to know of one sightline
@@ -261,8 +262,6 @@ inline int build(const std::vector<Sightline> &sightlines, int64_t S, const Opti
         int b, group, part, pass_begin, pass_end;
         bool rest;
     };
-    std::vector<Piece> pieces;
-    pieces.reserve((size_t)blocks * (full + 1));
     std::vector<PassDesc> &passes = plan.passes;
     passes.clear();
     const bool remainder = frac * full < 1.0 - 1e-9;
@@ -271,58 +270,71 @@ inline int build(const std::vector<Sightline> &sightlines, int64_t S, const Opti
     // remainder items a left-over wave slot works through (shape (B)); 1 otherwise
     const long slots_total = std::max<int64_t>(opt.slots, 1), left = slots_total - (long)full * groups;
     const long rest_per_slot = remainder && left > 0 ? (groups + left - 1) / left : 1;
+    // XCD affinity (batches, one piece per block): workgroups are dealt round-robin over the 8 XCDs (observed, for speed
+    // only), each with its own 4 MB L2, and a sightline's MFMA operand is 6 MB.  In (sightline, group) order every XCD
+    // has waves of the ~3 sightlines that are in flight at a time; dealt so that workgroup i works on a sightline
+    // b = i (mod 8), every XCD sweeps ONE sightline's operand with all of its waves.  Option "plan_xcd_affine".
+    const bool affine = opt.xcd_affine != 0 && !remainder && full == 1 && nb >= 8;
+    // Longest sightlines first (a catalogue batch is ragged: n follows z_qso): the eight of a round are then of similar
+    // length, and the launch ends on its shortest items instead of on whatever came last.  Equal lengths (the bench)
+    // keep their order.
+    std::vector<int> order(nb);
+    for (int b = 0; b < nb; ++b) order[b] = b;
+    if (affine) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sightlines[x].chunks > sightlines[y].chunks; });
+    // Taper: a launch of many equal rounds ends with every wave slot somewhere inside its last item -- on average half an
+    // item of idle time per slot.  The sightlines of the LAST round of eight are cut into `taper` pieces each, so that
+    // the launch ends on items a fraction as long.  Option "plan_taper" (0 / 1: off).
+    const int taper = affine && nb >= 16 && opt.taper > 1 ? (int)std::min<int64_t>(opt.taper, 8) : 1;
+    const int taper_from = taper > 1 ? (nb - 1) / 8 * 8 : nb;  // position in `order` of the last round's first sightline
+    std::vector<int> position(nb);
+    for (int x = 0; x < nb; ++x) position[order[x]] = x;
+    std::vector<std::vector<Piece>> cuts_of(nb);
     for (int b = 0; b < nb; ++b) {
         // cut positions of sightline b (the same for all of its groups); empty pieces are dropped
         const long chunks = sightlines[b].chunks;
-        const int npieces = full + (remainder ? 1 : 0);
+        const bool tapered = position[b] >= taper_from && chunks >= (long)taper * DLAGP_MAX_PASS_CHUNKS;
+        const int npieces = tapered ? taper : full + (remainder ? 1 : 0);
+        const double piece_frac = tapered ? 1.0 / taper : frac;
         std::vector<int> edge(npieces + 1, (int)chunks);
         edge[0] = 0;
         for (int j = 1; j < npieces; ++j)
-            edge[j] = (int)std::max<long>(edge[j - 1], std::min<long>(chunks, std::llround(j * frac * chunks)));
-        refine_cuts(*sightlines[b].slot_pos, sightlines[b].ntaps, edge, remainder, rest_per_slot, opt);
-        std::vector<Piece> cuts;
+            edge[j] = (int)std::max<long>(edge[j - 1], std::min<long>(chunks, std::llround(j * piece_frac * chunks)));
+        refine_cuts(*sightlines[b].slot_pos, sightlines[b].ntaps, edge, remainder && !tapered, rest_per_slot, opt);
+        std::vector<Piece> &cuts = cuts_of[b];
         for (int j = 0; j < npieces; ++j)
             if (edge[j + 1] > edge[j]) {
                 const int begin = (int)passes.size();  // the pass list of a piece is shared by all groups
                 plan_passes(*sightlines[b].slot_pos, sightlines[b].ntaps, edge[j], edge[j + 1], passes);
-                cuts.push_back({b, 0, (int)cuts.size(), begin, (int)passes.size(), remainder && j == npieces - 1});
+                cuts.push_back({b, 0, (int)cuts.size(), begin, (int)passes.size(), remainder && !tapered && j == npieces - 1});
             }
         if (cuts.size() > DLAGP_MAX_PIECES) {
             err = "internal: " + std::to_string(cuts.size()) + " pieces per block exceed the byte-sized piece count";
             return DLAGP_EINVAL;
         }
         max_parts = std::max(max_parts, (int)cuts.size());
-        for (long grp = 0; grp < ngroups; ++grp) {
-            plan.counts[(size_t)b * ngroups + grp] = (unsigned char)cuts.size();
-            for (Piece pc : cuts) {
-                pc.group = (int)grp;
-                pieces.push_back(pc);
-            }
-        }
+        for (long grp = 0; grp < ngroups; ++grp) plan.counts[(size_t)b * ngroups + grp] = (unsigned char)cuts.size();
     }
-    // dispatch order: the full pieces in (sightline, group, piece) order, then the remainders
-    const bool rest_first = opt.rest_first != 0;
-    if (remainder) std::stable_partition(pieces.begin(), pieces.end(), [=](const Piece &x) { return x.rest == rest_first; });
-    // XCD affinity (batches, one piece per block): workgroups are dealt round-robin over the 8 XCDs (observed, for speed
-    // only), each with its own 4 MB L2, and a sightline's MFMA operand is 6 MB.  In (sightline, group) order every XCD
-    // has waves of the ~3 sightlines that are in flight at a time; dealt so that workgroup i works on a sightline
-    // b = i (mod 8), every XCD sweeps ONE sightline's operand with all of its waves.  Option "plan_xcd_affine".
-    if (opt.xcd_affine != 0 && !remainder && full == 1 && nb >= 8 && pieces.size() == (size_t)blocks) {
-        std::vector<Piece> dealt;
-        dealt.reserve(pieces.size());
-        // Longest sightlines first (a catalogue batch is ragged: n follows z_qso): the eight of a round are then of
-        // similar length, and the launch ends on its shortest items instead of on whatever came last.  Equal lengths
-        // (the bench) keep their order.
-        std::vector<int> order(nb);
-        for (int b = 0; b < nb; ++b) order[b] = b;
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sightlines[x].chunks > sightlines[y].chunks; });
-        // pieces are in (b, group) order, ngroups each: rounds of 8 sightlines, inside a round group-major
+    std::vector<Piece> pieces;
+    pieces.reserve((size_t)blocks * (full + 1));
+    auto emit = [&](int bb, long grp) {
+        for (Piece pc : cuts_of[bb]) {
+            pc.group = (int)grp;
+            pieces.push_back(pc);
+        }
+    };
+    if (affine) {
+        // rounds of 8 sightlines, inside a round group-major
         for (int b0 = 0; b0 < nb; b0 += 8) {
             const int width = std::min(8, nb - b0);
             for (long grp = 0; grp < ngroups; ++grp)
-                for (int x = 0; x < width; ++x) dealt.push_back(pieces[(size_t)order[b0 + x] * ngroups + grp]);
+                for (int x = 0; x < width; ++x) emit(order[b0 + x], grp);
         }
-        pieces.swap(dealt);
+    } else {
+        // the full pieces in (sightline, group, piece) order, then the remainders
+        for (int b = 0; b < nb; ++b)
+            for (long grp = 0; grp < ngroups; ++grp) emit(b, grp);
+        const bool rest_first = opt.rest_first != 0;
+        if (remainder) std::stable_partition(pieces.begin(), pieces.end(), [=](const Piece &x) { return x.rest == rest_first; });
     }
     // column groups one after the other: every phase of the launch sweeps ONE slice of the sightlines' operands
     plan.items.clear();
@@ -353,7 +365,8 @@ inline int debug(int nb, const int *n_u, const uint8_t *const *keep, int ntaps, 
         opt.slots = options[3];
         opt.xcd_affine = options[4];
         opt.column_groups = options[5];
-        if (opt.slots < 1 || opt.item_cost < 0 || opt.pixel_splits < 0 || opt.column_groups < 1 || opt.column_groups > 16) {
+        opt.taper = options[6];
+        if (opt.slots < 1 || opt.item_cost < 0 || opt.pixel_splits < 0 || opt.column_groups < 1 || opt.column_groups > 16 || opt.taper < 0 || opt.taper > 8) {
             err = "dlagp_plan_debug: options out of range";
             return DLAGP_EINVAL;
         }

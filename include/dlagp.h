@@ -331,7 +331,8 @@ int dlagp_plan_cut(int64_t groups, double chunks, int64_t forced_splits, int *fu
  * of sightline b over its n_u[b] unmasked pixels (= ~pixel_mask[ind_unmasked], reference null_gp.py:139-152), ntaps 7
  * with instrumental broadening and 1 without, S the samples per sightline, options NULL (the library's current values
  * are NOT used: defaults) or {pixel_splits, plan_item_cost, plan_rest_first, plan_slots, plan_xcd_affine, column groups
- * (1 for rank <= 20; ranks 21..64 run every block once per group of 210 + 20 columns)}.
+ * (1 for rank <= 20; ranks 21..64 run every block once per group of 210 + 20 columns), plan_taper (pieces per block for the
+ * sightlines of a batch's last round of eight; 0 / 1 = off)}.
  *   summary[8]  {slots of all sightlines, passes, work items, blocks, most pieces per block, full pieces, remainder
  *               piece 0/1, fraction of a sightline per full piece x 1e9}
  *   slot_pixel / slot_pos [slots]   per sightline, concatenated: kept pixel of every slot (-1 = padding slot) and

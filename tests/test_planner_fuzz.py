@@ -46,7 +46,7 @@ def random_mask(rng, kind, n_u):
 
 
 def check_case(lib, ct, rng, case):
-    nb = int(rng.integers(1, 13))
+    nb = int(rng.integers(1, 13)) if case % 5 else int(rng.integers(16, 41))  # tapering needs at least two rounds of eight
     ntaps = int(rng.choice([1, 7]))
     S = int(10 ** rng.uniform(0, 5)) if case % 7 else int(rng.integers(1, 40))
     if nb * S > 400000:
@@ -59,7 +59,8 @@ def check_case(lib, ct, rng, case):
     options = None
     if case % 3:
         options = np.array([rng.integers(0, 11), rng.integers(0, 101), rng.integers(0, 2),
-                            rng.choice([1, 7, 64, 2048, 100000]), rng.integers(0, 2), rng.choice([1, 1, 3, 10])], dtype=np.int64)
+                            rng.choice([1, 7, 64, 2048, 100000]), rng.integers(0, 2), rng.choice([1, 1, 3, 10]),
+                            rng.choice([0, 1, 2, 3, 8])], dtype=np.int64)
     n_u = (ct.c_int * nb)(*[len(m) for m in masks])
     keep = (ct.POINTER(ct.c_ubyte) * nb)(*[m.ctypes.data_as(ct.POINTER(ct.c_ubyte)) for m in masks])
     opt_ptr = options.ctypes.data_as(ct.POINTER(ct.c_int64)) if options is not None else None
