@@ -923,12 +923,11 @@ static int launch_level_finish(int nb, hipStream_t stream, const double *ll, lon
                                double *evidences, int *base, double *cdf, int *alive, const int *status, int *sticky) {
     const size_t lds_bytes = (size_t)S * sizeof(double);
     if (lds_bytes <= 144 * 1024) {
-        static std::atomic<size_t> allowed{64 * 1024 - 9 * 1024};  // default dynamic LDS limit minus the static part
-        if (lds_bytes > allowed.load()) {
+        // beyond the default limit (64 KB with the kernel's static 8.3 KB) the attribute is needed -- per device, so it is
+        // set at every such launch rather than remembered (a process may drive several devices)
+        if (lds_bytes > 55 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(level_finish<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-            allowed.store(144 * 1024);
-        }
         hipLaunchKernelGGL(level_finish<true>, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS), (uint32_t)lds_bytes, stream,
                            ll, S, level, max_dlas, src, min_z_separation, uniforms, sample_ll, evidences, base, cdf, alive,
                            status, sticky);
