@@ -293,39 +293,37 @@ class OracleBatch:
         return np.array([self.R.null_log_model_evidence(st) for st in self.states])
 
 
-def test_sharded_evidences_gloo_world_size_2(tmp_path):
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_sharded_evidences_gloo_world_size_2(tmp_path, nproc):
     """N > 1 path: cost-balanced shards (5 sightlines over 2 ranks: {0, 1, 4} + {2, 3}), padded all-gather, rows back
-    in catalogue order"""
+    in catalogue order; with 4 ranks the catalogue run (3 spectra) leaves one rank without a spectrum"""
     env = dict(os.environ, DLAGP_REPO=REPO, DLAGP_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1",
                OMP_NUM_THREADS="1")
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)]
     res = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
-    got0 = np.load(tmp_path / "rank0.npy")
-    got1 = np.load(tmp_path / "rank1.npy")
-    np.testing.assert_array_equal(got0, got1)  # every rank holds the full table
     sights = [make_sightline(i, n_unmasked=120 + 4 * i, n_masked=2) for i in range(5)]
     want = parallel.model_evidences_sharded(sights, num_samples=24, max_dlas=2,
                                             make_batch=lambda s, device: OracleBatch(s))
     assert want.shape == (5, 4) and np.all(np.isfinite(want))
-    np.testing.assert_array_equal(got0, want)
-    # catalogue driver: both ranks hold the complete result arrays, equal to the reference's
-    g = load_golden("catalogue.npz")
-    cat0, cat1 = (np.load(tmp_path / ("catalogue_rank%d.npz" % r)) for r in (0, 1))
-    for name in cat0.files:
-        np.testing.assert_array_equal(cat0[name], cat1[name], err_msg=name)
-    assert_catalogue_matches_golden(cat0, g, rtol=1e-10)
-    # by-sample split of one sightline (each rank evaluated half of the samples of every level): both ranks hold
-    # the reference's evidences, per-sample likelihoods and -- exactly -- its resampled base indices
-    g = load_golden("evidences_small.npz")
-    for r in (0, 1):
+    g_cat, g5 = load_golden("catalogue.npz"), load_golden("evidences_small.npz")
+    cat0 = np.load(tmp_path / "catalogue_rank0.npz")
+    for r in range(nproc):
+        np.testing.assert_array_equal(np.load(tmp_path / ("rank%d.npy" % r)), want)  # every rank holds the full table
+        # catalogue driver: every rank holds the complete result arrays, equal to the reference's
+        cat = np.load(tmp_path / ("catalogue_rank%d.npz" % r))
+        for name in cat0.files:
+            np.testing.assert_array_equal(cat0[name], cat[name], err_msg=name)
+        # by-sample split of one sightline (each rank evaluated its share of the samples of every level): every rank
+        # holds the reference's evidences, per-sample likelihoods and -- exactly -- its resampled base indices
         got = np.load(tmp_path / ("by_sample_rank%d.npz" % r))
-        np.testing.assert_array_equal(got["base"], g["dla_base_inds"])
-        np.testing.assert_allclose(got["ev"], g["dla_evidences"], rtol=1e-12)
-        np.testing.assert_allclose(got["sll"], g["dla_sample_ll"], rtol=1e-12, equal_nan=True)
+        np.testing.assert_array_equal(got["base"], g5["dla_base_inds"])
+        np.testing.assert_allclose(got["ev"], g5["dla_evidences"], rtol=1e-12)
+        np.testing.assert_allclose(got["sll"], g5["dla_sample_ll"], rtol=1e-12, equal_nan=True)
+    assert_catalogue_matches_golden(cat0, g_cat, rtol=1e-10)
 
 
 # ------------------------------------------------------------------------------------------------
