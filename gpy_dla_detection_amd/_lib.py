@@ -53,6 +53,8 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "dlagp_batch_model_evidences": (c_int, [c_void_p, c_int64, c_int, _dp, _dp, c_int64, _dp, _dp, c_int64, c_double,
                                             _dp, _dp, _dp, _dp, _dp, _dp, POINTER(ctypes.c_int32)]),
+    "dlagp_batch_model_evidences_start": (c_int, [c_void_p, c_int64, c_int, _dp, _dp, c_int64, _dp, _dp, c_int64, c_double]),
+    "dlagp_batch_model_evidences_finish": (c_int, [c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, POINTER(ctypes.c_int32)]),
     "dlagp_batch_level_eval_device": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
                                               c_void_p, c_int, c_void_p, c_void_p]),
     "dlagp_sweep_state_init_device": (c_int, [c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

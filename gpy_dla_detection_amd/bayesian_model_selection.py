@@ -49,6 +49,11 @@ class BayesModelSelect:
         assert isinstance(model_list[-1], NullGP)
         assert len(model_list) > self.dla_model_ind
 
+        # The reference's model list on one shared sightline: the device starts on the sub-DLA sweep (no random numbers
+        # needed) while the priors are assembled and the occupation sweep's uniforms are drawn here on the host.  Neither
+        # touches what the other reads, so the order of the two is free.
+        finish_evidences = self._start_evidences_in_one_call(model_list)
+
         # priors of the absorber models; the null model takes what is left (reference :68-80)
         priors = []
         for model, num in zip(model_list, self.all_max_dlas):
@@ -57,7 +62,7 @@ class BayesModelSelect:
         log_priors[0] = np.log(1 - np.exp(logsumexp(log_priors[1:])))
 
         # evidences: this is where the GPU sweep runs (reference :84-96)
-        log_likelihoods = self._evidences_in_one_call(model_list)
+        log_likelihoods = finish_evidences() if finish_evidences is not None else None
         if log_likelihoods is None:
             evidences = []
             for model, num in zip(model_list, self.all_max_dlas):
@@ -72,14 +77,16 @@ class BayesModelSelect:
         self.log_posteriors = log_likelihoods + log_priors
         return self.log_posteriors
 
-    def _evidences_in_one_call(self, model_list: List[NullGP]):
+    def _start_evidences_in_one_call(self, model_list: List[NullGP]):
         """
         The reference driver's model list [null, sub-DLA (1), DLA (1..k)] on ONE spectrum (run_bayes_select.py:189):
         when the three stock models share one HBM-resident sightline (`null_gp.SharedSightline` -- equal learned
         model, settings and spectrum by content), the loop above is one call into the library
         (dlagp_batch_model_evidences: null evidence, sub-DLA sweep and occupation sweep enqueued back to back, one
         wait).  Same numbers bit for bit, same side effects on the models (`sample_log_likelihoods`,
-        `base_sample_inds`), same use of the legacy global RNG.  None when the shape does not apply.
+        `base_sample_inds`), same use of the legacy global RNG.  Returns None when the shape does not apply, else -- with
+        the first phase (uploads, sub-DLA sweep) already running on the device -- the function that draws the uniforms,
+        finishes the call and returns the log-likelihoods.
         """
         if len(model_list) != 3 or list(self.all_max_dlas[:2]) != [0, 1] or len(self.all_max_dlas) != 3:
             return None
@@ -108,16 +115,21 @@ class BayesModelSelect:
         nhi_dla = np.asarray(dla.dla_samples.nhi_samples, dtype=np.float64)
         if not (z_lls.shape == z_dla.shape == nhi_sub.shape == nhi_dla.shape == (S,)):
             return None
-        # the sub-DLA sweep (one level) draws nothing; the occupation sweep draws one random_sample(S) per resampled
-        # level, exactly as in DLAGP.log_model_evidences
-        rng_before = np.random.get_state()
-        uniforms = np.random.random_sample((1, max(max_dlas - 1, 0), S))
-        nulls, (ev_sub, ll_sub, _), (ev_dla, ll_dla, base) = shared.batch.model_evidences(
-            z_lls[None, :], nhi_sub, z_dla[None, :], nhi_dla, max_dlas, dla.min_z_separation, uniforms)
-        sub.sample_log_likelihoods = ll_sub[0]
-        dla.sample_log_likelihoods, dla.base_sample_inds = ll_dla[0], base[0]
-        settle_rng_after_sweep(ev_dla[0], max_dlas, S, rng_before)
-        return np.concatenate([nulls, ev_sub[0], ev_dla[0]])
+        batch = shared.batch
+        batch.model_evidences_start(z_lls[None, :], nhi_sub, z_dla[None, :], nhi_dla, max_dlas, dla.min_z_separation)
+
+        def finish():
+            # the sub-DLA sweep (one level) draws nothing; the occupation sweep draws one random_sample(S) per resampled
+            # level, exactly as in DLAGP.log_model_evidences
+            rng_before = np.random.get_state()
+            uniforms = np.random.random_sample((1, max(max_dlas - 1, 0), S))
+            nulls, (ev_sub, ll_sub, _), (ev_dla, ll_dla, base) = batch.model_evidences_finish(uniforms)
+            sub.sample_log_likelihoods = ll_sub[0]
+            dla.sample_log_likelihoods, dla.base_sample_inds = ll_dla[0], base[0]
+            settle_rng_after_sweep(ev_dla[0], max_dlas, S, rng_before)
+            return np.concatenate([nulls, ev_sub[0], ev_dla[0]])
+
+        return finish
 
     @property
     def dla_model_posterior_ind(self) -> np.ndarray:

@@ -425,6 +425,15 @@ struct dlagp_ctx {
 
 struct dlagp_batch {
     LaunchGroup group;
+    // dlagp_batch_model_evidences_start has run and _finish has not
+    struct Pending {
+        bool active = false;
+        int64_t S = 0, nhi_stride = 0;
+        int max_dlas = 0;
+        double min_z_separation = 0.0;
+        size_t stage_used = 0;          // staging bytes of the first phase: the second phase's lie behind them
+        hipStream_t stream = nullptr;   // the calling thread's kernel stream: _finish must come from the same thread
+    } pending;
 };
 
 // which batches a context belongs to: a context destroyed before its batches drains their streams first
@@ -822,6 +831,7 @@ struct Transfers {
     hipStream_t compute, transfer;  // kernels of the call / copies of the call (may be the same stream)
     std::vector<Item> up, down;
     size_t total = 0;
+    size_t base = 0;  // first byte of the staging buffer this call may use (a two-phase call's second phase: behind the first's)
     // Every transfer, small ones included, goes through the page-locked staging buffer as an ASYNCHRONOUS copy: a
     // blocking hipMemcpy of a few bytes costs 50-90 us of host time each, and a call made for ONE spectrum (the drop-in
     // classes: a dozen arrays in and out per model selection) spent 0.9 ms of its 1.4 ms in them
@@ -834,15 +844,15 @@ struct Transfers {
     void download(void *host, const void *device_ptr, size_t bytes) {
         if (bytes && host) down.push_back({const_cast<void *>(device_ptr), host, bytes, 0});
     }
-    int reserve() {
+    int reserve(size_t also = 0) {
         total = 0;
         for (auto *list : {&up, &down})
             for (Item &it : *list)
                 if (it.bytes > kDirect) {
-                    it.offset = total;
+                    it.offset = base + total;
                     total += (it.bytes + 255) & ~(size_t)255;
                 }
-        return total ? stage.reserve(total) : DLAGP_OK;
+        return total + also ? stage.reserve(base + total + also) : DLAGP_OK;
     }
     // host -> stage -> device on the transfer stream; the kernel stream waits for them (an event, no host wait)
     int run_uploads() {
@@ -1826,18 +1836,20 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
 // sightline of the batch in ONE call: the one-absorber model (sub-DLAs), the occupation sweep of the DLA model and the
 // null model are enqueued back to back and waited for once -- one upload phase, one wait and one download phase per
 // batch instead of three of each.
-int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, const double *sub_sample_z,
-                                const double *sub_sample_nhi, int64_t sub_nhi_stride, const double *sample_z,
-                                const double *sample_nhi, int64_t nhi_stride, double min_z_separation,
-                                const double *uniforms, double *null_evidences, double *sub_evidences,
-                                double *sub_sample_ll, double *evidences, double *sample_ll, int32_t *base_inds) {
-    int rc = check_sweep_args(batch, S, max_dlas, sample_z, sample_nhi, nhi_stride, uniforms, evidences);
+int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dlas, const double *sub_sample_z,
+                                      const double *sub_sample_nhi, int64_t sub_nhi_stride, const double *sample_z,
+                                      const double *sample_nhi, int64_t nhi_stride, double min_z_separation) {
+    double dummy = 0.0;  // check_sweep_args wants the output arrays of the one-call form: they come with _finish
+    int rc = check_sweep_args(batch, S, max_dlas, sample_z, sample_nhi, nhi_stride, max_dlas > 1 ? &dummy : nullptr, &dummy);
     if (rc) return rc;
-    if ((rc = check_sweep_args(batch, S, 1, sub_sample_z, sub_sample_nhi, sub_nhi_stride, nullptr, sub_evidences))) return rc;
-    if (!null_evidences) return fail(DLAGP_EINVAL, "NULL argument");
+    if ((rc = check_sweep_args(batch, S, 1, sub_sample_z, sub_sample_nhi, sub_nhi_stride, nullptr, &dummy))) return rc;
     LaunchGroup &g = batch->group;
     HIP_TRY(hipSetDevice(g.device));
     Workspace &ws = g.ws;
+    if (batch->pending.active) {  // a call that was started and never finished: let its kernels drain
+        g.drain();
+        batch->pending.active = false;
+    }
     const size_t nb = g.ctxs.size();
     const size_t rows = nb * (size_t)S;
     const size_t n_nhi = nhi_stride ? (size_t)nhi_stride * (nb - 1) + S : (size_t)S;
@@ -1854,12 +1866,54 @@ int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, con
     if ((rc = grow(g, ws.sub_evidences, nb * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.sub_ll, rows * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.out, nb * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.alive, (nb + 1) * sizeof(int)))) return rc;  // [nb]: the sweeps' sticky non-PD flag
+    if ((rc = grow(g, ws.status, sizeof(int)))) return rc;            // the null launch's
     Transfers tr(ws.stage, g.device);
     const hipStream_t stream = tr.compute;
     tr.upload(ws.sub_z.ptr, sub_sample_z, rows * sizeof(double));
     tr.upload(ws.sub_nhi.ptr, sub_sample_nhi, n_sub_nhi * sizeof(double));
     tr.upload(ws.z.ptr, sample_z, rows * sizeof(double));
     tr.upload(ws.nhi.ptr, sample_nhi, n_nhi * sizeof(double));
+    // the staging buffer is sized for BOTH phases now: growing it in _finish would free memory the copies of this
+    // phase may still be reading
+    const size_t second_phase = (n_base + 2 * nb + rows + nb * max_dlas + rows * max_dlas) * sizeof(double) +
+                                n_base * sizeof(int32_t) + 2 * sizeof(int) + 16 * 256;
+    if ((rc = tr.reserve(second_phase)) || (rc = tr.run_uploads())) return rc;
+    // model order of the reference's model list (run_bayes_select.py:189): the one-absorber model before the DLA model
+    rc = sweep_levels(g, S, 1, ws.sub_z.as<double>(), ws.sub_nhi.as<double>(), sub_nhi_stride, min_z_separation, nullptr,
+                      ws.sub_evidences.as<double>(), ws.sub_ll.as<double>(), nullptr, stream);
+    if (rc) return rc;
+    batch->pending.active = true;
+    batch->pending.S = S;
+    batch->pending.max_dlas = max_dlas;
+    batch->pending.nhi_stride = nhi_stride;
+    batch->pending.min_z_separation = min_z_separation;
+    batch->pending.stage_used = tr.total;
+    batch->pending.stream = stream;
+    return DLAGP_OK;
+}
+
+int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniforms, double *null_evidences,
+                                       double *sub_evidences, double *sub_sample_ll, double *evidences, double *sample_ll,
+                                       int32_t *base_inds) {
+    int rc = batch_alive(batch);
+    if (rc) return rc;
+    if (!batch->pending.active) return fail(DLAGP_EINVAL, "dlagp_batch_model_evidences_finish without a matching _start");
+    const int64_t S = batch->pending.S;
+    const int max_dlas = batch->pending.max_dlas;
+    if (!null_evidences || !sub_evidences || !evidences || (max_dlas > 1 && !uniforms)) return fail(DLAGP_EINVAL, "NULL argument");
+    LaunchGroup &g = batch->group;
+    HIP_TRY(hipSetDevice(g.device));
+    Workspace &ws = g.ws;
+    const size_t nb = g.ctxs.size();
+    const size_t rows = nb * (size_t)S;
+    const size_t n_base = rows * (max_dlas - 1);
+    Transfers tr(ws.stage, g.device);
+    const hipStream_t stream = tr.compute;
+    if (stream != batch->pending.stream)
+        return fail(DLAGP_EINVAL, "dlagp_batch_model_evidences_finish must be called by the thread that called _start");
+    batch->pending.active = false;
+    tr.base = batch->pending.stage_used;
     tr.upload(ws.uniforms.ptr, uniforms, n_base * sizeof(double));
     tr.download(null_evidences, ws.out.ptr, nb * sizeof(double));
     tr.download(sub_evidences, ws.sub_evidences.ptr, nb * sizeof(double));
@@ -1868,18 +1922,15 @@ int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, con
     tr.download(sample_ll, ws.sample_ll.ptr, rows * max_dlas * sizeof(double));
     tr.download(base_inds, ws.base.ptr, n_base * sizeof(int32_t));
     int status[2] = {0, 0};
-    if ((rc = grow(g, ws.alive, (nb + 1) * sizeof(int)))) return rc;  // [nb]: the sweeps' sticky non-PD flag
-    if ((rc = grow(g, ws.status, sizeof(int)))) return rc;            // the null launch's
     tr.download(&status[0], ws.alive.as<int>() + nb, sizeof(int));
     tr.download(&status[1], ws.status.ptr, sizeof(int));
-    if ((rc = tr.reserve()) || (rc = tr.run_uploads())) return rc;
-    // model order of the reference's model list (run_bayes_select.py:189): the one-absorber model before the DLA model
-    rc = sweep_levels(g, S, 1, ws.sub_z.as<double>(), ws.sub_nhi.as<double>(), sub_nhi_stride, min_z_separation, nullptr,
-                      ws.sub_evidences.as<double>(), ws.sub_ll.as<double>(), nullptr, stream);
-    if (rc) return rc;
-    rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), nhi_stride, min_z_separation,
-                      ws.uniforms.as<double>(), ws.evidences.as<double>(), ws.sample_ll.as<double>(),
-                      ws.base.as<int>(), stream, /*keep_sticky_flag=*/true);
+    const size_t capacity = ws.stage.bytes;
+    if ((rc = tr.reserve())) return rc;
+    if (ws.stage.bytes != capacity) return fail(DLAGP_EDEVICE, "internal: the staging buffer grew between the two phases");
+    if ((rc = tr.run_uploads())) return rc;
+    rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), batch->pending.nhi_stride,
+                      batch->pending.min_z_separation, ws.uniforms.as<double>(), ws.evidences.as<double>(),
+                      ws.sample_ll.as<double>(), ws.base.as<int>(), stream, /*keep_sticky_flag=*/true);
     if (rc) return rc;
     // the null model last: its launch leaves its own flag in ws.status, which the sweeps' launches would reset
     rc = launch_sweep(g, 1, 0, SampleSource{nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0},
@@ -1890,6 +1941,20 @@ int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, con
     for (auto &p : g.parts) p->launched = false;
     if (status[0] || status[1]) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
     return DLAGP_OK;
+}
+
+int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, const double *sub_sample_z,
+                                const double *sub_sample_nhi, int64_t sub_nhi_stride, const double *sample_z,
+                                const double *sample_nhi, int64_t nhi_stride, double min_z_separation,
+                                const double *uniforms, double *null_evidences, double *sub_evidences,
+                                double *sub_sample_ll, double *evidences, double *sample_ll, int32_t *base_inds) {
+    if (max_dlas > 1 && !uniforms) return fail(DLAGP_EINVAL, "uniforms are required when max_dlas > 1");
+    if (!null_evidences || !sub_evidences || !evidences) return fail(DLAGP_EINVAL, "NULL argument");
+    int rc = dlagp_batch_model_evidences_start(batch, S, max_dlas, sub_sample_z, sub_sample_nhi, sub_nhi_stride, sample_z,
+                                               sample_nhi, nhi_stride, min_z_separation);
+    if (rc) return rc;
+    return dlagp_batch_model_evidences_finish(batch, uniforms, null_evidences, sub_evidences, sub_sample_ll, evidences,
+                                              sample_ll, base_inds);
 }
 
 // ---- one sightline's samples split over several GPUs (SURVEY 8e "secondary", reference dla_gp.py:132-159 is

@@ -585,7 +585,7 @@ class NullGP:
                 x, y, v, wavelengths, z_qso = self.x, self.y, self.v, self.this_wavelengths, float(self.z_qso)
                 self._shared = _SHARED.find_or_make(key, lambda: _sl.DeviceSightline.from_model(
                     model, x, y, v, wavelengths, z_qso, grid, keep, num_lines=settings[0], broadening=broadening,
-                    lls_break=settings[3]))
+                    lls_break=settings[3], defer_sync=True))  # its first use waits for its set-up (an event), not this call
                 self._device_sightline = self._shared.dev
                 self._device_key = key
             return self._device_sightline

@@ -333,6 +333,60 @@ class DeviceBatch:
         return (nulls, (sub_ev, sub_ll.transpose(0, 2, 1), np.zeros((nb, 0, S), dtype=np.int32)),
                 (evidences, sample_ll.transpose(0, 2, 1), base))
 
+    def model_evidences_start(self, sub_sample_z, sub_sample_nhi, sample_z, sample_nhi, max_dlas: int,
+                              min_z_separation: float) -> None:
+        """
+        First phase of `model_evidences` (dlagp_batch_model_evidences_start): the samples go up and the sub-DLA sweep,
+        which needs no random numbers, starts; returns at once.  The caller draws the occupation sweep's uniforms and
+        does its other host work while the device runs, then calls `model_evidences_finish`.
+        """
+        nb = self.nb
+
+        def tables(z, nhi):
+            z = np.ascontiguousarray(_lib.as_f64(z))
+            nhi = np.ascontiguousarray(_lib.as_f64(nhi))
+            if z.ndim != 2 or z.shape[0] != nb:
+                raise ValueError("sample_z must be (nb, S)")
+            if nhi.shape == (z.shape[1],):
+                return z, nhi, 0
+            if nhi.shape == z.shape:
+                return z, nhi, z.shape[1]
+            raise ValueError("sample_nhi must be (S,) or (nb, S)")
+
+        sub_z, sub_nhi, sub_stride = tables(sub_sample_z, sub_sample_nhi)
+        z, nhi, stride = tables(sample_z, sample_nhi)
+        S = z.shape[1]
+        if sub_z.shape[1] != S:
+            raise ValueError("both models need the same number of samples")
+        _lib.check(_lib.load().dlagp_batch_model_evidences_start(
+            self._handle, S, int(max_dlas), _lib.ptr(sub_z), _lib.ptr(sub_nhi), sub_stride, _lib.ptr(z), _lib.ptr(nhi), stride,
+            float(min_z_separation)))
+        self._pending = (S, int(max_dlas))
+
+    def model_evidences_finish(self, uniforms=None):
+        """second phase: same return value as `model_evidences`"""
+        S, max_dlas = self._pending
+        self._pending = None
+        nb = self.nb
+        if max_dlas > 1:
+            if uniforms is None:
+                raise ValueError("uniforms are required when max_dlas > 1")
+            uniforms = np.ascontiguousarray(_lib.as_f64(uniforms))
+            if uniforms.shape != (nb, max_dlas - 1, S):
+                raise ValueError("uniforms must be (nb, max_dlas - 1, S)")
+        nulls = np.empty(nb, dtype=np.float64)
+        sub_ev = np.empty((nb, 1), dtype=np.float64)
+        sub_ll = np.empty((nb, 1, S), dtype=np.float64)
+        evidences = np.empty((nb, max_dlas), dtype=np.float64)
+        sample_ll = np.empty((nb, max_dlas, S), dtype=np.float64)
+        base = np.zeros((nb, max(max_dlas - 1, 0), S), dtype=np.int32)
+        _lib.check(_lib.load().dlagp_batch_model_evidences_finish(
+            self._handle, _lib.ptr(uniforms) if max_dlas > 1 else None, _lib.ptr(nulls), _lib.ptr(sub_ev), _lib.ptr(sub_ll),
+            _lib.ptr(evidences), _lib.ptr(sample_ll),
+            base.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) if max_dlas > 1 else None))
+        return (nulls, (sub_ev, sub_ll.transpose(0, 2, 1), np.zeros((nb, 0, S), dtype=np.int32)),
+                (evidences, sample_ll.transpose(0, 2, 1), base))
+
     def sweep_device(self, S: int, max_dlas: int, d_sample_z: int, d_sample_nhi: int, nhi_stride: int,
                      min_z_separation: float, d_uniforms: int, d_evidences: int, d_sample_ll: int, d_base_inds: int,
                      stream: int = 0) -> None:

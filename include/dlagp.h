@@ -243,6 +243,18 @@ int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, con
                                 const double *sample_nhi, int64_t nhi_stride, double min_z_separation,
                                 const double *uniforms, double *null_evidences, double *sub_evidences,
                                 double *sub_sample_ll, double *evidences, double *sample_ll, int32_t *base_inds);
+/* The same call in two phases, for a caller that has host work of its own to do meanwhile (the drop-in classes draw the
+ * occupation sweep's 30 000 uniforms from NumPy's legacy generator and assemble priors while the device already runs):
+ * _start uploads the samples and enqueues the sub-DLA sweep, which needs no random numbers, and returns at once; _finish
+ * takes the uniforms and the output arrays, enqueues the occupation sweep and the null evidences, waits and copies back.
+ * _start followed by _finish IS dlagp_batch_model_evidences (bit for bit).  Both from the same host thread; the batch
+ * must not be used in between; a _start that is never finished is drained by the batch's next call. */
+int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dlas, const double *sub_sample_z,
+                                      const double *sub_sample_nhi, int64_t sub_nhi_stride, const double *sample_z,
+                                      const double *sample_nhi, int64_t nhi_stride, double min_z_separation);
+int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniforms, double *null_evidences,
+                                       double *sub_evidences, double *sub_sample_ll, double *evidences, double *sample_ll,
+                                       int32_t *base_inds);
 
 /*
  * Level evidence on the device (reference dla_gp.py:155-190), for sweeps whose results stay in HBM.

@@ -521,8 +521,9 @@ def test_model_evidences_in_one_call_equal_the_three_calls(restore_options):
     and a non-PD member in any of the three models is reported.
     """
     import threading
+    import time
 
-    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd import _lib, parallel
     from gpy_dla_detection_amd.sightline import DeviceBatch, DeviceSightline, get_option, set_option
 
     sights = [make_sightline(20 + i, n_unmasked=n_u, n_masked=m) for i, (n_u, m) in
@@ -599,6 +600,20 @@ def test_model_evidences_in_one_call_equal_the_three_calls(restore_options):
                 np.testing.assert_array_equal(halves[i].nulls(), want[i][0])
         except Exception as exc:  # noqa: BLE001
             errors.append(exc)
+
+    # the call in two phases (the drop-in classes do host work in between): the same arrays, also with a first phase that
+    # is never finished in front of it
+    halves[0].model_evidences_start(z_sub[:2], nhi_sub, zs[:2], nhi, max_dlas, min_sep)
+    halves[0].model_evidences_start(z_sub[:2], nhi_sub, zs[:2], nhi, max_dlas, min_sep)
+    time.sleep(0.01)  # "host work"
+    two = halves[0].model_evidences_finish(uniforms[:2])
+    np.testing.assert_array_equal(two[0], want[0][0])
+    for a, b in zip(two[1], want[0][1]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(two[2], want[0][2]):
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(ValueError):
+        _lib.check(_lib.load().dlagp_batch_model_evidences_finish(halves[0]._handle, None, None, None, None, None, None, None))
 
     for shared in (0, 1):
         set_option("shared_work_stream", shared)
@@ -1498,7 +1513,7 @@ def test_the_three_gp_objects_of_a_spectrum_share_one_sightline_and_one_call():
     S, max_dlas = 512, 4
     _, spectra, z_qsos, _, _, _ = catalogue_inputs(S)
     calls = {"model_evidences": 0, "sweep": 0}
-    real_me, real_sweep = sl.DeviceBatch.model_evidences, sl.DeviceBatch.sweep
+    real_me, real_sweep = sl.DeviceBatch.model_evidences_finish, sl.DeviceBatch.sweep
 
     def counted(name, fn):
         def wrapper(self, *a, **k):
@@ -1506,7 +1521,7 @@ def test_the_three_gp_objects_of_a_spectrum_share_one_sightline_and_one_call():
             return fn(self, *a, **k)
         return wrapper
 
-    sl.DeviceBatch.model_evidences = counted("model_evidences", real_me)
+    sl.DeviceBatch.model_evidences_finish = counted("model_evidences", real_me)  # the two-phase form of the one call
     sl.DeviceBatch.sweep = counted("sweep", real_sweep)
     try:
         for spectrum, z_qso in zip(spectra, z_qsos):
@@ -1540,7 +1555,7 @@ def test_the_three_gp_objects_of_a_spectrum_share_one_sightline_and_one_call():
             np.testing.assert_allclose(apart.log_likelihoods, fused.log_likelihoods, rtol=1e-11)
             np.testing.assert_array_equal(private[2].base_sample_inds, ll_fused[2])
     finally:
-        sl.DeviceBatch.model_evidences, sl.DeviceBatch.sweep = real_me, real_sweep
+        sl.DeviceBatch.model_evidences_finish, sl.DeviceBatch.sweep = real_me, real_sweep
     assert calls["model_evidences"] == len(spectra) and calls["sweep"] == 4 * len(spectra)
 
 
