@@ -207,6 +207,7 @@ class DeviceBatch:
         _lib.check(lib.dlagp_batch_create(ctypes.byref(handle), arr, nb))
         self._handle = handle
         self.nb = nb
+        self._pending = None  # (S, max_dlas) between model_evidences_start and model_evidences_finish
 
     def close(self) -> None:
         if getattr(self, "_handle", None):
@@ -365,6 +366,8 @@ class DeviceBatch:
 
     def model_evidences_finish(self, uniforms=None):
         """second phase: same return value as `model_evidences`"""
+        if self._pending is None:
+            raise ValueError("model_evidences_finish without a matching model_evidences_start")
         S, max_dlas = self._pending
         self._pending = None
         nb = self.nb
