@@ -642,15 +642,42 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     else if (nsplit == 3) stage(std::integral_constant<int, 3>{});
     else if (nsplit == 4) stage(std::integral_constant<int, 4>{});
     else if (nsplit == 5) stage(std::integral_constant<int, 5>{});
-    else
-        for (int idx = tid; idx < PAIRS; idx += DLAGP_FIN_THREADS) {
-            int src, lds_a, lds_b;
-            locate(idx, src, lds_a, lds_b);
-            d2 acc = d2{0.0, 0.0};
-            for (int h = 0; h < nsplit; ++h) acc += *reinterpret_cast<const d2 *>(piece0 + h * piece_stride + src);
-            fin_lds[lds_a] = acc.x;
-            fin_lds[lds_b] = acc.y;
+    else {
+        // more pieces (a launch of few blocks cut into up to 32 pieces each, dlagp_plan_cut): four pieces' loads in flight
+        // at a time, added in piece order like the unrolled forms above
+        d2 acc[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) acc[it] = d2{0.0, 0.0};
+        for (int h0 = 0; h0 < nsplit; h0 += 4) {
+            d2 v[ITER][4];
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int idx = tid + it * DLAGP_FIN_THREADS;
+                int src, lds_a, lds_b;
+                locate(idx < PAIRS ? idx : tid, src, lds_a, lds_b);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int h = h0 + u < nsplit ? h0 + u : nsplit - 1;  // clamp: a valid address, value unused
+                    v[it][u] = *reinterpret_cast<const d2 *>(piece0 + h * piece_stride + src);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < ITER; ++it)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (h0 + u < nsplit) acc[it] += v[it][u];
         }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * DLAGP_FIN_THREADS;
+            int src, lds_a, lds_b;
+            locate(idx < PAIRS ? idx : tid, src, lds_a, lds_b);
+            if (idx < PAIRS) {
+                fin_lds[lds_a] = acc[it].x;
+                fin_lds[lds_b] = acc[it].y;
+            }
+        }
+    }
     __syncthreads();
     if constexpr (ROW16) {
     // ---- factor + solve: SIXTEEN lanes per sample, all four waves (4 samples each).

@@ -208,7 +208,9 @@ inline void choose_cut(long groups, double C, const Options &opt, int *full_out,
     const double finalize_per_piece = 0.005 * 8.0 / DLAGP_CHUNK_PIXELS;
     int full = 1;
     double frac = 1.0, best = 1e300;
-    const int h_max = (int)std::max(1.0, std::min(8.0, std::floor(C / DLAGP_MAX_PASS_CHUNKS)));
+    // up to 32 equal pieces (8 until round 4): a launch of few blocks -- one rank's S / 8 = 1250 samples when ONE
+    // sightline's samples are split over 8 GPUs: 79 blocks -- filled a third of the wave slots with 8 pieces each
+    const int h_max = (int)std::max(1.0, std::min(32.0, std::floor(C / DLAGP_MAX_PASS_CHUNKS)));
     for (int h = 1; h <= h_max; ++h) {
         if (forced > 0 && h != std::min<int64_t>(forced, h_max)) continue;
         const double cost = (double)((groups * h + slots - 1) / slots) * (C / h + o) + finalize_per_piece * groups * h;

@@ -646,7 +646,12 @@ def test_work_decomposition_model():
     # large launches: one item per block; forced equal pieces
     assert cut(64 * 625, 375) == (1, 1.0)
     assert cut(625, 375, forced=3) == (3, 1.0 / 3)
-    assert cut(625, 375, forced=1000)[0] == 8          # never more than 8 pieces, never less than a pass each
+    assert cut(625, 375, forced=1000)[0] == 32         # never more than 32 equal pieces, never less than a pass each
+    assert cut(625, 60, forced=1000)[0] == 8           # 60 chunks hold 8 passes of 7
+    # one rank's slice when ONE sightline's samples are split over 8 GPUs (79 blocks): far more than 8 pieces, so that
+    # the 2048 wave slots are filled
+    full, frac = cut(79, 375)
+    assert full * 79 > 1500 and full * frac <= 1.0 + 1e-12
     assert cut(3, 9) == (1, 1.0)
     # every cut covers the block: full * frac <= 1
     for groups in (1, 7, 300, 625, 1250, 1875, 2047, 2048, 2500, 5000, 10000):
