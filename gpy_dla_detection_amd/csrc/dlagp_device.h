@@ -75,13 +75,18 @@ struct SampleSource {
     // Profile cache of a multi-level sweep (indexed mode, MFMA path).  Every absorber of every level is
     // one of the sightline's S QMC points, and sample s of level l stacks point base[l-1][s] on the
     // absorbers sample s had at level l-1 (reference dla_gp.py:135-150).  So level 1 keeps the convolved
-    // absorption of every point on the kept pixels, cache[(b S + p) cache_stride + pixel] (cache_mode 1),
+    // absorption of every point on the sightline's pixel slots (cache_mode 1),
     // and level l > 1 forms the product  cache[s] cache[base[0][s]] .. cache[base[l-2][s]]  (cache_mode 2) instead of
     // evaluating Voigt profiles: one streamed row per sample and level, the stacked rows -- a handful of distinct ones per
     // wave -- from L2 (kernels_mfma.h).  240 MB per sightline at S = 10 000, n = 3000.
+    // Layout: tiles of 16 points x 64 slots.  Point p, slot x of sightline b sits at
+    //   cache[b G cache_group_stride + (p / 16) cache_group_stride + (x / 64) 1024 + (p % 16) 64 + x % 64],
+    // G = ceil(S / 16) groups of points, cache_stride = 64 T = the row length padded to whole tiles,
+    // cache_group_stride = 16 cache_stride: the 16 rows a wave
+    // streams in one pass of a cached level are one contiguous 8 KB block, and its passes follow each other in memory.
     double *cache;
     double *running;   // unused since round 4 (no running product is kept in memory)
-    long cache_stride;
+    long cache_stride;  // slots per row, a multiple of 64
     int cache_mode;    // 0 off, 1 store level-1 profiles, 2 multiply cached rows
     int cache_write;   // unused since round 4
     // Indexed mode on a slice of the samples (one rank's share when ONE sightline's samples are split over several
@@ -89,6 +94,7 @@ struct SampleSource {
     // per sightline.  table_S == 0: the launch covers the whole table (offset 0, table_S = S).
     long sample_offset;
     long table_S;
+    long cache_group_stride;  // doubles from one group of 16 points to the next: 16 cache_stride
 };
 
 #if defined(__HIPCC__)

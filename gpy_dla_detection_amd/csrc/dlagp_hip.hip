@@ -993,10 +993,17 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
         // (ranks above 20 run every block once per column group: each would store / stream the rows again -- they recompute)
         bool use_cache = g_opt_profile_cache != 0 && max_dlas > 1 && tg.col_groups == 1;
         for (int level = 0; level < max_dlas; ++level) use_cache = use_cache && mfma_path_serves(tg, level + 1, level > 0);
-        const size_t cache_bytes = tg.ctxs.size() * (size_t)S * (size_t)tg.max_slots * sizeof(double);
+        // tiled layout (dlagp_device.h): rows padded to whole tiles of 64 slots, points to whole groups of 16
+        const size_t cache_row = ((size_t)tg.max_slots + DLAGP_CACHE_TILE_SLOTS - 1) / DLAGP_CACHE_TILE_SLOTS * DLAGP_CACHE_TILE_SLOTS;
+        const size_t cache_points = ((size_t)S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP * DLAGP_MFMA_GROUP;
+        // doubles per group of 16 points (padding between the groups -- 64 bytes to 12 KB, to spread the groups over the
+        // memory channels -- changed nothing: profiles/r04_experiments.txt item 8)
+        const size_t cache_group = DLAGP_MFMA_GROUP * cache_row;
+        const size_t cache_sightline = cache_points / DLAGP_MFMA_GROUP * cache_group;
+        const size_t cache_bytes = tg.ctxs.size() * cache_sightline * sizeof(double);
         const size_t want_bytes = cache_bytes;  // the profiles; the deeper levels multiply cached rows, nothing is written back
         // the cached levels address a sightline's rows with 32-bit byte offsets (raw buffer loads, kernels_mfma.h)
-        use_cache = use_cache && (size_t)S * (size_t)tg.max_slots * sizeof(double) < ((size_t)1 << 31);
+        use_cache = use_cache && cache_sightline * sizeof(double) < ((size_t)1 << 31);
         if (use_cache) {
             const size_t have = tws.cache.bytes;
             if (have < want_bytes) {
@@ -1010,7 +1017,8 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
         all_cached = all_cached && use_cache;
         if (use_cache) {
             t.src.cache = tws.cache.as<double>();
-            t.src.cache_stride = tg.max_slots;
+            t.src.cache_stride = (long)cache_row;
+            t.src.cache_group_stride = (long)cache_group;
         }
     }
     g_last_sweep_cached = all_cached ? 1 : 0;

@@ -254,7 +254,12 @@ __device__ __forceinline__ void accumulate_mfma_body(
     SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags) {
     constexpr bool CACHED = MODE == 2;
     constexpr int NPOOL = 16;  // distinct cached rows a wave holds per pass (cached levels)
-    constexpr int A_STRIDE = 4 * DLAGP_MAX_PASS_STEPS + 2;  // 58: stride/2 odd -> conflict-free b64 reads
+    // Pixel slots a pass holds.  Voigt passes: 7 chunks, what a 64-entry profile window covers behind the 7-tap
+    // convolution.  The cached levels have no window: lane = pixel slot, so a pass is 8 chunks = all 64 lanes, and the
+    // kernel walks its work item's chunk range in passes of its own (same chunks, same steps in the same order -- the
+    // sums stay bit-identical to the recomputing kernel's -- in 1/8 fewer passes).
+    constexpr int PASS_CHUNKS = CACHED ? DLAGP_CACHED_PASS_CHUNKS : DLAGP_MAX_PASS_CHUNKS;
+    constexpr int A_STRIDE = 4 * PASS_CHUNKS * DLAGP_CHUNK_STEPS + 2;  // 58 (66 cached): stride/2 odd -> conflict-free b64 reads
     __shared__ double raw[16 * DLAGP_RAW_STRIDE];
     __shared__ double a_lds[16 * A_STRIDE];
     __shared__ int pos_lds[64];
@@ -330,12 +335,13 @@ __device__ __forceinline__ void accumulate_mfma_body(
     // (up to round 3: the running product read, multiplied by one row and written back -- 72 KB per sample and level).
     // A wave whose samples stack more than 16 distinct rows (flat likelihoods) reads them level by level, 16 rows at a
     // time, at the head of every pass (`pooled` = false; also forced by launch flag DLAGP_LAUNCH_GENERAL_ROWS).
-    int *row_lds = reinterpret_cast<int *>(prep_lds);  // [kd - 1][16] cached row of (level, sample); then [NPOOL] pool rows
+    int *row_lds = reinterpret_cast<int *>(prep_lds);  // [kd - 1][16] cached row of (level, sample), as a byte offset; then [NPOOL] pool rows
     constexpr int MAXJ = DLAGP_MAX_ABSORBERS - 1;  // stacked rows per sample
     constexpr int POOLJ = 3;                       // ... that the pool serves (the reference sweeps up to 4 absorbers)
     int *pool_row_lds = row_lds + MAXJ * 16;
     unsigned long long slot_bits[POOLJ] = {};  // pool slot of (level, sample): 4 bits each, wave-uniform
     bool pooled = false;
+    int pool_used = 0;  // slots of the pool in use
     if constexpr (CACHED) {
         int npool = 0;
         bool overflow = (launch_flags & DLAGP_LAUNCH_GENERAL_ROWS) != 0 || kd - 1 > POOLJ;
@@ -344,7 +350,7 @@ __device__ __forceinline__ void accumulate_mfma_body(
             long smp = sample0 + (lane & 15);
             smp = smp < S ? smp : S - 1;
             const int mine = (int)sample_point(src, gb, smp, j, S, kd);
-            if (lane < 16) row_lds[(j - 1) * 16 + lane] = mine;
+            if (lane < 16) row_lds[(j - 1) * 16 + lane] = (mine >> 4) * ((int)src.cache_group_stride * 8) + (mine & 15) * (DLAGP_CACHE_TILE_SLOTS * 8);
             for (int ss = 0; ss < 16; ++ss) {
                 const int v = __builtin_amdgcn_readlane(mine, ss);
                 const unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < npool && pool_val == v);
@@ -363,9 +369,13 @@ __device__ __forceinline__ void accumulate_mfma_body(
             }
         }
         pooled = !overflow;
+        pool_used = pooled ? npool : 0;
         // unused pool slots repeat slot 0's row: every pass issues the same number of row reads whatever the pool holds
         const int first = __builtin_amdgcn_readfirstlane(pool_val);
-        if (lane < NPOOL) pool_row_lds[lane] = lane < npool ? pool_val : first;
+        // kept as the byte offset of the row within tile 0 of its group (issue_rows)
+        const int pool_point = lane < npool ? pool_val : first;
+        if (lane < NPOOL)
+            pool_row_lds[lane] = (pool_point >> 4) * ((int)src.cache_group_stride * 8) + (pool_point & 15) * (DLAGP_CACHE_TILE_SLOTS * 8);
         lds_wave_sync();
     }
     for (int i = lane; i < wave_prep; i += 64) {
@@ -506,6 +516,9 @@ __device__ __forceinline__ void accumulate_mfma_body(
 #ifndef DLAGP_CACHE_STORE_NT
 #define DLAGP_CACHE_STORE_NT 1
 #endif
+#ifndef DLAGP_CACHE_LOAD_AUX
+#define DLAGP_CACHE_LOAD_AUX 2  // cache policy of the streamed rows of a cached level: nt
+#endif
 #ifndef DLAGP_PRIO_VOIGT
 #define DLAGP_PRIO_VOIGT 2
 #endif
@@ -523,7 +536,28 @@ __device__ __forceinline__ void accumulate_mfma_body(
 #endif
     // The descriptor and the wavelengths of a pass are fetched during the pass before it: read at the head of
     // their own pass they are two dependent trips to L2 before the Voigt loop can start.
-    PassDesc pd_next = passes[pass_begin];
+    // cached levels: the item's chunk range [c_first, c_last) (an item's passes are consecutive chunk ranges,
+    // plan_passes) in passes that are the 64-slot TILES of the cache (dlagp_device.h): the first and the last pass of an
+    // item may cover part of their tile
+    int c_first = 0, c_last = 0;
+    if constexpr (CACHED) {
+        c_first = __builtin_amdgcn_readfirstlane(passes[pass_begin].chunk_begin);
+        c_last = __builtin_amdgcn_readfirstlane(passes[pass_end - 1].chunk_begin + passes[pass_end - 1].nchunks);
+    }
+    const int tile_first = c_first / PASS_CHUNKS;
+    const int loop_begin = CACHED ? 0 : pass_begin;
+    const int loop_end = CACHED ? (c_last + PASS_CHUNKS - 1) / PASS_CHUNKS - tile_first : pass_end;
+    auto pass_desc = [&](int p) __attribute__((always_inline)) -> PassDesc {
+        if constexpr (CACHED) {
+            const int tile_chunk = (tile_first + p) * PASS_CHUNKS;
+            const int lo = tile_chunk > c_first ? tile_chunk : c_first;
+            const int hi = tile_chunk + PASS_CHUNKS < c_last ? tile_chunk + PASS_CHUNKS : c_last;
+            return PassDesc{0, lo, hi - lo, 0};
+        } else {
+            return passes[p];
+        }
+    };
+    PassDesc pd_next = pass_desc(loop_begin);
     double lam_next = 0.0;
     if (DLAGP_PREFETCH_PASS && !CACHED) {
         int e = __builtin_amdgcn_readfirstlane(pd_next.entry_start) + lane;
@@ -531,46 +565,84 @@ __device__ __forceinline__ void accumulate_mfma_body(
         lam_next = lam_ptr[e];
     }
     // cached levels (MODE 2): per sample the cached row of its own QMC point (streamed), and the wave's pool of stacked
-    // rows, for the 64 pixel slots of a pass (lane = slot); loaded a pass ahead, see the step loop
-    constexpr int NROW = CACHED ? 16 : 1;
-    double own[NROW], rowreg[CACHED ? NPOOL : 1];
-    // Row reads are raw buffer loads: ONE scalar resource over the sightline's part of the cache, the row as a scalar
-    // byte offset, the pass's pixel column as the per-lane offset -- no 64-bit vector addresses (32 of them at a time
-    // spilled a hundred registers).  The host keeps S x cache_stride x 8 bytes below 2^31.
+    // rows, for the 64 pixel slots of a pass; loaded a pass ahead, see the step loop
+    double rowreg[CACHED ? 16 : 1];  // only the level-by-level path of a wave beyond the pool
+    // Row reads are raw buffer loads: ONE scalar resource over the sightline's part of the cache, the (tile, row) as a
+    // scalar byte offset, the slot within the tile as the per-lane offset -- no 64-bit vector addresses (32 of them at a
+    // time spilled a hundred registers).  The host keeps a sightline's part of the cache below 2^31 bytes.
+    // Layout (dlagp_device.h): [group of 16 points][tile of 64 slots][16 points][64 slots] -- the 16 own rows of a
+    // wave's pass are ONE contiguous 8 KB block and its passes follow each other in memory (round 4; with rows of
+    // n_slots doubles a pass read sixteen 512-byte pieces 24 KB apart: -2.7 % on the cached level).
+    const int group_bytes = (int)src.cache_group_stride * 8;
+    const long cache_groups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
     const __amdgpu_buffer_rsrc_t cache_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)as_global<gptr_d>(CACHED ? src.cache + (long)b * S * src.cache_stride : nullptr), 0,
-        CACHED ? (int)(S * src.cache_stride * 8) : 0, DLAGP_BUFFER_FLAGS);
-    const int row_bytes = CACHED ? (int)src.cache_stride * 8 : 0;
-    auto pass_column = [&](const PassDesc &pd) __attribute__((always_inline)) -> int {
-        const int st0 = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd.chunk_begin);
-        const int npx = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd.nchunks) * DLAGP_STEP_PIXELS;
-        const int px = lane < npx ? lane : npx - 1;
-        return (st0 * DLAGP_STEP_PIXELS + px) * 8;  // byte offset of this lane's pixel slot within a row
-    };
+        (void *)as_global<gptr_d>(CACHED ? src.cache + (long)b * cache_groups * src.cache_group_stride : nullptr), 0,
+        CACHED ? (int)(cache_groups * src.cache_group_stride * 8) : 0, DLAGP_BUFFER_FLAGS);
+    constexpr int TILE_BYTES = DLAGP_MFMA_GROUP * DLAGP_CACHE_TILE_SLOTS * 8;  // 8192
+    constexpr int TILE_ROW_BYTES = DLAGP_CACHE_TILE_SLOTS * 8;                 // 512
+    // The 32 rows of a pass go from memory straight into LDS (`buffer_load_dwordx4 ... lds`: 32 lanes x 16 bytes = the 64
+    // slots of one row per instruction) -- sample ss's own row into a_lds[ss][], where its product will stand, pool row t
+    // into raw[t][] (unused on these levels) -- so rows in flight hold no registers: up to round 4 they were 64 of the
+    // wave's 253.  Always the whole tile, whatever part of it the pass covers.
+    typedef __attribute__((address_space(3))) void *lds_ptr;
     auto issue_rows = [&](const PassDesc &pd) __attribute__((always_inline)) {
         if constexpr (CACHED) {
-            const int voff = pass_column(pd);
+            const int tile_off = __builtin_amdgcn_readfirstlane(pd.chunk_begin / PASS_CHUNKS) * TILE_BYTES;
+            const int own_off = (int)group * group_bytes + tile_off;
+            const int voff = (lane & 31) * 16;
             const long last = S - 1 - sample0;  // rows beyond S repeat the last sample (never stored)
+            int pool_off[NPOOL];
 #pragma unroll
-            for (int ss = 0; ss < 16; ++ss) {
-                const int rel = (int)(ss < last ? ss : last);
-                // read once per level: streamed (nt) past the L2 that serves the sightline's operand and the pool's rows
-                own[ss] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                                         cache_rsrc, voff, ((int)sample0 + rel) * row_bytes, DLAGP_CACHE_STORE_NT ? 2 : 0));
+            for (int t = 0; t < NPOOL; ++t) pool_off[t] = __builtin_amdgcn_readfirstlane(pool_row_lds[t]) + tile_off;
+            // a_lds[] was last read by the step before (its `a` of the pass's last step): landed before any row does
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < 32) {
+#pragma unroll
+                for (int ss = 0; ss < 16; ++ss) {
+                    const int rel = (int)(ss < last ? ss : last);
+                    // read once per level: streamed (nt) past the L2 that serves the sightline's operand and the pool's rows
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(cache_rsrc, (lds_ptr)(a_lds + ss * A_STRIDE), 16, voff,
+                                                             own_off + rel * TILE_ROW_BYTES, 0, DLAGP_CACHE_LOAD_AUX);
+                }
+                // only the pool's rows, four at a time (the slots of a group beyond the pool repeat slot 0's row): these
+                // are the hot lines of the sightline -- every wave of it reads the same few rows at about the same tile
+#pragma unroll
+                for (int t0 = 0; t0 < NPOOL; t0 += 4)
+                    if (t0 < pool_used) {
+#pragma unroll
+                        for (int t = t0; t < t0 + 4; ++t)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(cache_rsrc, (lds_ptr)(raw + t * 64), 16, voff, pool_off[t], 0, 0);
+                    }
             }
-#pragma unroll
-            for (int t = 0; t < NPOOL; ++t)
-                rowreg[t] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                                           cache_rsrc, voff, __builtin_amdgcn_readfirstlane(pool_row_lds[t]) * row_bytes, 0));
         }
     };
-    if constexpr (CACHED) issue_rows(pd_next);  // the first pass's rows
-    for (int pass = pass_begin; pass < pass_end; ++pass) {
-        const PassDesc pd_v = DLAGP_PREFETCH_PASS ? pd_next : passes[pass];
+    int item_last_step = 0;  // cached levels: where the rolling operand prefetch stops
+    if constexpr (CACHED) {
+        issue_rows(pd_next);  // the first pass's rows
+        // ... and the operands of the item's first step, in the step loop's order (see there)
+        const int step = DLAGP_CHUNK_STEPS * c_first;
+        const int soff = step * STEP_BYTES;
+        rec_ym = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff, step * REC_STEP_BYTES, 0));
+        rec_ov = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff + 16, step * REC_STEP_BYTES, 0));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NPAIR; ++j) {
+            frag[j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  p_rsrc, p_voff + (j & 3) * 1024, soff + (j >> 2) * 4096, 0));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        item_last_step = DLAGP_CHUNK_STEPS * c_last - 1;
+    }
+    for (int pass = loop_begin; pass < loop_end; ++pass) {
+        const PassDesc pd_v = DLAGP_PREFETCH_PASS ? pd_next : pass_desc(pass);
         const int entry_start = __builtin_amdgcn_readfirstlane(pd_v.entry_start);
-        const int step0 = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd_v.chunk_begin);
-        const int pass_steps = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd_v.nchunks);
-        if (DLAGP_PREFETCH_PASS) pd_next = passes[pass + 1 < pass_end ? pass + 1 : pass];
+        // Steps of the pass: operand steps step0 + st, slots 4 st .. 4 st + 3 of a_lds[], st = st_lo .. pass_steps - 1.
+        // Voigt passes start at their first chunk (st_lo = 0); a cached pass is a tile of the cache, of which the item's
+        // first pass may start (and its last end) inside.
+        const int st_lo = CACHED ? __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * (pd_v.chunk_begin % PASS_CHUNKS)) : 0;
+        const int step0 = __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd_v.chunk_begin) - st_lo;
+        const int pass_steps = st_lo + __builtin_amdgcn_readfirstlane(DLAGP_CHUNK_STEPS * pd_v.nchunks);
+        if (DLAGP_PREFETCH_PASS) pd_next = pass_desc(pass + 1 < loop_end ? pass + 1 : pass);
 
         // window start of pixel (lane) of this pass, relative to the pass; consumed after the Voigt loop
         const int my_rel = lane < pass_steps * DLAGP_STEP_PIXELS ? lane : 0;
@@ -584,37 +656,40 @@ __device__ __forceinline__ void accumulate_mfma_body(
             // their trip to HBM / L2 ran beside those steps' MFMAs; what is left of it is hidden behind the other resident
             // wave.  Same multiplication order as the recomputing kernel: ((c_s c_b0) c_b1) c_b2 -- bit-identical.
             if (stamps) t_mark = stamp_now();
-            const int npx = pass_steps * DLAGP_STEP_PIXELS;
             double *pool_lds = raw;  // [NPOOL][64]; raw[] is otherwise unused on the cached levels
+            // the rows have landed in LDS; the ten operand loads of the step that followed them stay in flight
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // the lane part of the LDS addresses is made opaque per pass, or the compiler keeps all (slot, lane) addresses
+            // in registers across the pass loop (44 spills)
+            int lane_off = lane * 8;
+            asm volatile("" : "+v"(lane_off));
             if (pooled) {
-#pragma unroll
-                for (int t = 0; t < NPOOL; ++t) pool_lds[t * 64 + lane] = rowreg[t];
-                lds_wave_sync();
                 // Every sample picks its kd - 1 rows out of the pool: reads of four samples in flight, then their
-                // products.  The slot numbers are wave-uniform scalars; the lane part of the address is made opaque per
-                // pass, or the compiler keeps all 48 (slot, lane) addresses in registers across the pass loop (44 spills).
-                int lane_off = lane * 8;
-                asm volatile("" : "+v"(lane_off));
+                // products, written over the sample's own row.  The slot numbers are wave-uniform scalars.
                 const char *pool_bytes = reinterpret_cast<const char *>(pool_lds);
+                char *a_bytes = reinterpret_cast<char *>(a_lds);
                 auto stack = [&](auto depth) __attribute__((always_inline)) {
                     constexpr int D = decltype(depth)::value;  // stacked rows per sample = kd - 1
 #pragma unroll
                     for (int s0 = 0; s0 < 16; s0 += 4) {
-                        double r[4][D];
+                        double r[4][D], o[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
+                        for (int u = 0; u < 4; ++u) {
+                            o[u] = *reinterpret_cast<const double *>(a_bytes + ((s0 + u) * (A_STRIDE * 8) + lane_off));
 #pragma unroll
                             for (int j = 0; j < D; ++j) {
                                 const int slot_off = (int)((slot_bits[j] >> (4 * (s0 + u))) & 15) * 512;
                                 r[u][j] = *reinterpret_cast<const double *>(pool_bytes + (slot_off + lane_off));
                             }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            double prod = own[s0 + u];
+                            double prod = o[u];
 #pragma unroll
                             for (int j = 0; j < D; ++j) prod *= r[u][j];
-                            if (lane < npx) a_lds[(s0 + u) * A_STRIDE + lane] = prod;
+                            *reinterpret_cast<double *>(a_bytes + ((s0 + u) * (A_STRIDE * 8) + lane_off)) = prod;
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -624,18 +699,19 @@ __device__ __forceinline__ void accumulate_mfma_body(
                 else stack(std::integral_constant<int, 3>());
             } else {
                 // more than NPOOL distinct rows in this wave: the stacked rows level by level, 16 reads at a time
-                const int voff = pass_column(pd_v);
+                const int tile_off = (step0 / (DLAGP_CHUNK_STEPS * PASS_CHUNKS)) * TILE_BYTES;
+                char *a_bytes = reinterpret_cast<char *>(a_lds);
                 for (int j = 1; j < kd; ++j) {
 #pragma unroll
                     for (int ss = 0; ss < 16; ++ss)
                         rowreg[ss] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                                                    cache_rsrc, voff, __builtin_amdgcn_readfirstlane(row_lds[(j - 1) * 16 + ss]) * row_bytes, 0));
+                                                                    cache_rsrc, lane_off, __builtin_amdgcn_readfirstlane(row_lds[(j - 1) * 16 + ss]) + tile_off, 0));
 #pragma unroll
-                    for (int ss = 0; ss < 16; ++ss) own[ss] *= rowreg[ss];
+                    for (int ss = 0; ss < 16; ++ss) {
+                        double *dst = reinterpret_cast<double *>(a_bytes + (ss * (A_STRIDE * 8) + lane_off));
+                        *dst = *dst * rowreg[ss];
+                    }
                 }
-#pragma unroll
-                for (int ss = 0; ss < 16; ++ss)
-                    if (lane < npx) a_lds[ss * A_STRIDE + lane] = own[ss];
             }
             lds_wave_sync();
             if (stamps) t_conv += stamp_now() - t_mark;
@@ -832,7 +908,9 @@ __device__ __forceinline__ void accumulate_mfma_body(
         // (records first, then tile pairs 0..7): loads complete in order and the wait counts at the
         // loop header are the minimum over both incoming edges, so any other order here makes
         // every step wait for all eight of its predecessor's prefetches instead of the oldest.
-        {
+        // (Cached levels: the prefetch rolls on across passes -- the last step of a pass fetches the first of the next,
+        // see below -- and the very first step's operands are issued in front of the pass loop.)
+        if constexpr (!CACHED) {
             const int soff = step0 * STEP_BYTES;
             rec_ym = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff, step0 * REC_STEP_BYTES, 0));
             rec_ov = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff + 16, step0 * REC_STEP_BYTES, 0));
@@ -847,11 +925,11 @@ __device__ __forceinline__ void accumulate_mfma_body(
 
         // ---------------- phase 2: weights and MFMAs, step by step ----------------
         const double *a_row = &a_lds[s_loc * A_STRIDE + slot];
-        double a = a_row[0];
-        // One step of 4 pixel slots.  FETCH: also fetch the next step's operands (everywhere but in the cached kernel's
-        // last step of a pass, which is written out below).  A macro, not a lambda: the step loop of the Voigt kernels
+        double a = a_row[st_lo * DLAGP_STEP_PIXELS];
+        // One step of 4 pixel slots.  FETCH: also fetch the next step's operands; READ_A: and its `a` (not in the last
+        // step of a cached pass: a_lds[] is being refilled).  A macro, not a lambda: the step loop of the Voigt kernels
         // is tuned to the instruction (an inlined lambda came out 2.6 % slower on configs[1]).
-#define DLAGP_STEP_BODY(st, FETCH)                                                                                       \
+#define DLAGP_STEP_BODY(st, FETCH, READ_A)                                                                                     \
         {                                                                                                                \
             __builtin_amdgcn_s_setprio(DLAGP_PRIO_HEAD);                                                                 \
             const double a2 = a * a;                                                                                     \
@@ -863,13 +941,15 @@ __device__ __forceinline__ void accumulate_mfma_body(
             const double q = a * rh;                                                                                     \
             sum_r2 = fma(r, rh, sum_r2);                                                                                 \
             dprod.multiply(d);                                                                                           \
-            /* next step's operands; the last step of a pass re-reads its own (harmless, never used) */                  \
+            /* next step's operands; the last step of a pass re-reads its own (harmless, never used) -- on the cached */ \
+            /* levels the first step of the next pass: an item's passes are consecutive steps of the operand */          \
             const int nst = (st) + 1 < pass_steps ? (st) + 1 : (st);                                                     \
-            const int nxt = step0 + nst;                                                                                 \
+            int nxt = step0 + nst;                                                                                       \
+            if constexpr (CACHED) nxt = step0 + (st) + 1 < item_last_step ? step0 + (st) + 1 : item_last_step;          \
             if (FETCH) {                                                                                                 \
                 rec_ym = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff, nxt * REC_STEP_BYTES, 0)); \
                 rec_ov = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, rec_voff + 16, nxt * REC_STEP_BYTES, 0)); \
-                a = a_row[nst * DLAGP_STEP_PIXELS];                                                                      \
+                if (READ_A) a = a_row[nst * DLAGP_STEP_PIXELS];                                                          \
             }                                                                                                            \
             /* keep the prefetches above in front of the MFMAs: their results are not needed before */                   \
             /* the next step, 16 MFMAs (>= 1024 cycles) from here */                                                     \
@@ -900,24 +980,26 @@ __device__ __forceinline__ void accumulate_mfma_body(
             }                                                                                                            \
         }
         if constexpr (!CACHED) {
-            for (int st = 0; st < pass_steps; ++st) DLAGP_STEP_BODY(st, true)
+            for (int st = st_lo; st < pass_steps; ++st) DLAGP_STEP_BODY(st, true, true)
         } else {
             // Cached levels: the last two steps are written out so that the memory traffic of the NEXT pass can start
             // between them.  Vector-memory operations complete in order and the step loop waits for its operand
             // prefetches, so anything issued in front of it (the old place of the row reads) holds
             // up its first steps for a trip to HBM; issued here, behind the last operand prefetch of the pass, the
-            // 32 row reads of the next pass are in flight during two steps of
+            // row reads of the next pass are in flight during a step of
             // MFMAs and nothing waits for them before the next pass's products.  (Inside the loop, behind a condition,
             // the compiler's wait counts at the loop head would have to assume the worst of both paths.)
-            for (int st = 0; st + 2 < pass_steps; ++st) DLAGP_STEP_BODY(st, true)
-            DLAGP_STEP_BODY(pass_steps - 2, true)  // a pass holds an even number of steps >= 2 (chunks of 8 slots)
+            for (int st = st_lo; st + 2 < pass_steps; ++st) DLAGP_STEP_BODY(st, true, true)
+            DLAGP_STEP_BODY(pass_steps - 2, true, true)  // a pass holds an even number of steps >= 2 (chunks of 8 slots)
             // Behind this condition the wait counts of the step after the join are the minimum over the two arms -- the
-            // arm without reads -- so the last step waits for 24 of the 32 row reads (vmcnt(8) in the ISA).  Making the
-            // reads unconditional gives exact counts (vmcnt(40..32): the step runs beside the reads) and changes nothing:
-            // 8208 / 8245 us against 8205 / 8249 us on config 5 (profiles/r04_experiments.txt item 3) -- the rows' trip is
-            // waited for at the head of the next pass instead.
-            if (pass + 1 < pass_end) issue_rows(pd_next);
-            DLAGP_STEP_BODY(pass_steps - 1, false)
+            // arm without reads -- so the last step waits for most of the row reads (vmcnt(8) in the ISA).  With the
+            // reads unconditional the counts are exact (the step runs beside the reads) and nothing changes: 8208 / 8245 us
+            // against 8205 / 8249 us on config 5 (profiles/r04_experiments.txt item 3) -- the rows' trip is waited for at
+            // the head of the next pass instead.
+            if (pass + 1 < loop_end) issue_rows(pd_next);
+            // the last step's prefetch is the next pass's first step: issued behind the rows, it is back long before
+            // the products of the next pass are done, which up to round 4 were followed by a trip to L2 for it
+            DLAGP_STEP_BODY(pass_steps - 1, true, false)
         }
 #undef DLAGP_STEP_BODY
         // Level 1 of a multi-level sweep: keep the convolved profiles for the deeper levels.  Stored here, at the end of
@@ -932,7 +1014,12 @@ __device__ __forceinline__ void accumulate_mfma_body(
             // issue-bound (profiles/r03_experiments.txt): 8 instructions per pass instead of 16.  (The same for the
             // cached levels' row reads and write-backs spilled registers and ran 7 % slower: they keep 8 bytes per lane.)
             const int h = lane >> 5, j2 = 2 * (lane & 31);
-            double *dst = src.cache + ((long)b * S + sample0) * src.cache_stride + (long)step0 * DLAGP_STEP_PIXELS + j2;
+            // tiled layout of the cache (dlagp_device.h): [group][tile of 64 slots][16 points][64 slots]; a slot pair
+            // never straddles a tile (passes start on multiples of 8 slots)
+            const int x = step0 * DLAGP_STEP_PIXELS + j2;
+            const long cache_groups_1 = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
+            double *dst = src.cache + ((long)b * cache_groups_1 + group) * src.cache_group_stride +
+                          (long)(x / DLAGP_CACHE_TILE_SLOTS) * (DLAGP_MFMA_GROUP * DLAGP_CACHE_TILE_SLOTS) + (x % DLAGP_CACHE_TILE_SLOTS);
             const long valid = S - sample0 < 16 ? S - sample0 : 16;
             // streaming stores: 24 KB per sample written once and read a level later -- kept out of the L2 that
             // serves the sightline's operand
@@ -942,8 +1029,8 @@ __device__ __forceinline__ void accumulate_mfma_body(
                     const int ss = 2 * i + h;
                     if (ss < valid) {
                         const v2d row = *reinterpret_cast<const v2d *>(&a_lds[ss * A_STRIDE + j2]);
-                        if (DLAGP_CACHE_STORE_NT) __builtin_nontemporal_store(row, (gst2)(dst + ss * src.cache_stride));
-                        else *(gst2)(dst + ss * src.cache_stride) = row;
+                        if (DLAGP_CACHE_STORE_NT) __builtin_nontemporal_store(row, (gst2)(dst + ss * DLAGP_CACHE_TILE_SLOTS));
+                        else *(gst2)(dst + ss * DLAGP_CACHE_TILE_SLOTS) = row;
                     }
                 }
             }

@@ -34,6 +34,8 @@
 #define DLAGP_MAX_PASS_STEPS 14  // 56 pixels
 #define DLAGP_CHUNK_STEPS (DLAGP_CHUNK_PIXELS / DLAGP_STEP_PIXELS)
 #define DLAGP_MAX_PASS_CHUNKS (DLAGP_MAX_PASS_STEPS / DLAGP_CHUNK_STEPS)
+#define DLAGP_CACHED_PASS_CHUNKS 8  // cached levels of a sweep: passes of 64 slots (kernels_mfma.h) ...
+#define DLAGP_CACHE_TILE_SLOTS (DLAGP_CACHED_PASS_CHUNKS * DLAGP_CHUNK_PIXELS)  // ... = the tiles of the profile cache
 #define DLAGP_MAX_PIECES 255     // pieces per block of 16 samples: the finalize kernels count them in a byte
 
 namespace dlagp {
