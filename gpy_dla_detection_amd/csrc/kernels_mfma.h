@@ -513,8 +513,11 @@ __device__ __forceinline__ void accumulate_mfma_body(
     v2d frag[NPAIR];
     v2d rec_ym, rec_ov;
 
-#ifndef DLAGP_CACHE_STORE_NT
-#define DLAGP_CACHE_STORE_NT 1
+#ifndef DLAGP_CACHE_STORE_AUX
+#define DLAGP_CACHE_STORE_AUX 2  // cache policy of level 1's stores of the profiles: nt
+#endif
+#ifndef DLAGP_CONV_GROUP_L1
+#define DLAGP_CONV_GROUP_L1 4
 #endif
 #ifndef DLAGP_CACHE_LOAD_AUX
 #define DLAGP_CACHE_LOAD_AUX 2  // cache policy of the streamed rows of a cached level: nt
@@ -863,7 +866,7 @@ __device__ __forceinline__ void accumulate_mfma_body(
                 const double *raw_row = raw + s_loc * DLAGP_RAW_STRIDE;
                 double *a_dst = &a_lds[s_loc * A_STRIDE + slot];
                 // (7 with several absorbers per sample -- their running product is one more register pair per step -- spills)
-                constexpr int CONV_GROUP = PATCH == 1 && MODE == 0 ? 7 : 4;  // reads of that many steps in flight; the single-absorber kernel has the registers for 7
+                constexpr int CONV_GROUP = PATCH == 1 && MODE == 0 ? 7 : (PATCH == 1 && MODE == 1 ? DLAGP_CONV_GROUP_L1 : 4);  // reads of that many steps in flight; the single-absorber kernel has the registers for 7
                 constexpr int NW = BROADEN ? DLAGP_NUM_TAPS : 1;
 #pragma unroll
                 for (int g0 = 0; g0 < DLAGP_MAX_PASS_STEPS; g0 += CONV_GROUP) {
@@ -1008,7 +1011,6 @@ __device__ __forceinline__ void accumulate_mfma_body(
         // slower than MODE 0); from here they drain during the next pass's Voigt loop.  a_lds[] is intact until the
         // next convolution.
         if constexpr (MODE == 1) {
-            typedef __attribute__((address_space(1))) v2d *gst2;
             const int npx = pass_steps * DLAGP_STEP_PIXELS;
             // 16 bytes per lane: lane = (h, slot pair j) stores slots 2 j, 2 j + 1 of the samples 2 i + h -- stores are
             // issue-bound (profiles/r03_experiments.txt): 8 instructions per pass instead of 16.  (The same for the
@@ -1018,21 +1020,29 @@ __device__ __forceinline__ void accumulate_mfma_body(
             // never straddles a tile (passes start on multiples of 8 slots)
             const int x = step0 * DLAGP_STEP_PIXELS + j2;
             const long cache_groups_1 = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
-            double *dst = src.cache + ((long)b * cache_groups_1 + group) * src.cache_group_stride +
-                          (long)(x / DLAGP_CACHE_TILE_SLOTS) * (DLAGP_MFMA_GROUP * DLAGP_CACHE_TILE_SLOTS) + (x % DLAGP_CACHE_TILE_SLOTS);
-            const long valid = S - sample0 < 16 ? S - sample0 : 16;
+            // raw buffer stores: one scalar resource over the sightline's part of the cache (below 2^31 bytes, as the
+            // cached levels need it), the group as the scalar offset, (tile, slot) as the lane's
+            const __amdgpu_buffer_rsrc_t store_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)as_global<gptr_d>(src.cache + (long)b * cache_groups_1 * src.cache_group_stride), 0,
+                (int)(cache_groups_1 * src.cache_group_stride * 8), DLAGP_BUFFER_FLAGS);
+            const int group_off = (int)group * ((int)src.cache_group_stride * 8);
+            const int lane_store = ((x / DLAGP_CACHE_TILE_SLOTS) * (DLAGP_MFMA_GROUP * DLAGP_CACHE_TILE_SLOTS) + (x % DLAGP_CACHE_TILE_SLOTS)) * 8;
             // streaming stores: 24 KB per sample written once and read a level later -- kept out of the L2 that
-            // serves the sightline's operand
+            // serves the sightline's operand.  All eight rows are read into registers of their own before the first
+            // store: with one register set the compiler waited, before each LDS read, for the store before it to have
+            // COMPLETED (no early release of a store's data registers on this target: `s_waitcnt vmcnt`) -- eight trips
+            // to HBM one after the other per pass, 8 % of the kernel.  Rows beyond S (the last group) are written too:
+            // the cache holds whole groups of 16 rows and the cached levels never read those.
             if (j2 < npx) {
+                typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+                v2d rows[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int ss = 2 * i + h;
-                    if (ss < valid) {
-                        const v2d row = *reinterpret_cast<const v2d *>(&a_lds[ss * A_STRIDE + j2]);
-                        if (DLAGP_CACHE_STORE_NT) __builtin_nontemporal_store(row, (gst2)(dst + ss * DLAGP_CACHE_TILE_SLOTS));
-                        else *(gst2)(dst + ss * DLAGP_CACHE_TILE_SLOTS) = row;
-                    }
-                }
+                for (int i = 0; i < 8; ++i) rows[i] = *reinterpret_cast<const v2d *>(&a_lds[(2 * i + h) * A_STRIDE + j2]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, rows[i]), store_rsrc,
+                                                           lane_store + (2 * i + h) * (DLAGP_CACHE_TILE_SLOTS * 8), group_off, DLAGP_CACHE_STORE_AUX);
             }
         }
         __builtin_amdgcn_s_setprio(DLAGP_PRIO_CONV);
