@@ -671,6 +671,38 @@ def test_cached_levels_read_a_shared_row_once(restore_options):
     batch.close()
 
 
+def test_cached_levels_match_recomputed_levels_for_any_cut(restore_options):
+    """
+    The profile cache is tiled (16 points x 64 slots) and a cached level walks a work item's chunk range tile by tile --
+    the first and last pass of an item cover part of a tile when the launch plan cuts the sightline elsewhere.  Same
+    chunks, same steps, same products in the same order: whatever the cut (1 ... 9 pieces per block, rows that end
+    inside a tile, S not a multiple of 16, sightlines of different lengths in one batch) the cached sweep equals the
+    sweep that recomputes every level from the Voigt profiles, bit for bit.
+    """
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch, get_option, set_option
+
+    sights = [make_sightline(50, n_unmasked=1001, n_masked=9), make_sightline(51, n_unmasked=77, n_masked=2),
+              make_sightline(52, n_unmasked=640, n_masked=0)]
+    devs = [device_sightline(s) for s in sights]
+    batch = DeviceBatch(devs)
+    S, max_dlas = 203, 4
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    uniforms = parallel.resampling_uniforms(3, max_dlas, S, seed=5)
+    for splits in (0, 1, 2, 3, 5, 9):
+        set_option("pixel_splits", splits)
+        set_option("profile_cache", 1)
+        got = batch.sweep(zs, nhi, max_dlas, 0.002, uniforms)
+        assert get_option("last_sweep_cached") == 1
+        set_option("profile_cache", 0)
+        want = batch.sweep(zs, nhi, max_dlas, 0.002, uniforms)
+        assert get_option("last_sweep_cached") == 0
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b, err_msg="pixel_splits=%d" % splits)
+    batch.close()
+
+
 def test_sweep_workspaces_are_recycled_between_batches():
     """
     A destroyed batch leaves its sweep workspace (partial sums, profile cache: buffers above the pool's size limit) to the
