@@ -622,6 +622,7 @@ __device__ __forceinline__ void accumulate_mfma_body(
     int item_last_step = 0;  // cached levels: where the rolling operand prefetch stops
     if constexpr (CACHED) {
         issue_rows(pd_next);  // the first pass's rows
+        __builtin_amdgcn_sched_barrier(0);
         // ... and the operands of the item's first step, in the step loop's order (see there)
         const int step = DLAGP_CHUNK_STEPS * c_first;
         const int soff = step * STEP_BYTES;
@@ -999,7 +1000,11 @@ __device__ __forceinline__ void accumulate_mfma_body(
             // reads unconditional the counts are exact (the step runs beside the reads) and nothing changes: 8208 / 8245 us
             // against 8205 / 8249 us on config 5 (profiles/r04_experiments.txt item 3) -- the rows' trip is waited for at
             // the head of the next pass instead.
+            // (the products of the next pass wait with an explicit count -- the ten operand loads of the last step may
+            // stay in flight -- so nothing may move across the rows' issue)
+            __builtin_amdgcn_sched_barrier(0);
             if (pass + 1 < loop_end) issue_rows(pd_next);
+            __builtin_amdgcn_sched_barrier(0);
             // the last step's prefetch is the next pass's first step: issued behind the rows, it is back long before
             // the products of the next pass are done, which up to round 4 were followed by a trip to L2 for it
             DLAGP_STEP_BODY(pass_steps - 1, true, false)
