@@ -983,7 +983,14 @@ __device__ __forceinline__ void accumulate_mfma_body(
                 if (FETCH) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); /* VMEM read */                            \
             }                                                                                                            \
         }
-        if constexpr (!CACHED) {
+        if constexpr (MODE == 1) {
+            // Level 1 of a cached sweep stores the pass's profiles right after the step loop (below).  The last step's
+            // prefetch -- it "re-reads its own", never used -- would still be in flight there, in registers the store
+            // block's LDS reads are given next: a wait for ten L2 trips per pass (1.2 us of ~15: the whole of what this
+            // kernel cost over the one without the store).  So the last step is written out without the prefetch.
+            for (int st = st_lo; st + 1 < pass_steps; ++st) DLAGP_STEP_BODY(st, true, true)
+            DLAGP_STEP_BODY(pass_steps - 1, false, false)
+        } else if constexpr (!CACHED) {
             for (int st = st_lo; st < pass_steps; ++st) DLAGP_STEP_BODY(st, true, true)
         } else {
             // Cached levels: the last two steps are written out so that the memory traffic of the NEXT pass can start
