@@ -656,9 +656,10 @@ __device__ __forceinline__ void accumulate_mfma_body(
 
         if constexpr (CACHED) {
             // ---------------- phase 1 (cached): the product of the sample's stacked cached profiles ----------------
-            // The 32 row reads of this pass were issued during the last two steps of the pass before it (below), so
-            // their trip to HBM / L2 ran beside those steps' MFMAs; what is left of it is hidden behind the other resident
-            // wave.  Same multiplication order as the recomputing kernel: ((c_s c_b0) c_b1) c_b2 -- bit-identical.
+            // The rows of this pass were sent on their way -- memory to LDS -- between the last two steps of the pass
+            // before it (below), so their trip to HBM / L2 ran beside that step's MFMAs; what is left of it is hidden behind
+            // the other resident wave.  Same multiplication order as the recomputing kernel: ((c_s c_b0) c_b1) c_b2 --
+            // bit-identical.
             if (stamps) t_mark = stamp_now();
             double *pool_lds = raw;  // [NPOOL][64]; raw[] is otherwise unused on the cached levels
             // the rows have landed in LDS; the ten operand loads of the step that followed them stay in flight
