@@ -1187,6 +1187,37 @@ def test_device_sweep_equals_host_level_logic(path, cache, restore_options):
     np.testing.assert_allclose(got[0], want[0], rtol=1e-12)
 
 
+def test_device_sweep_with_more_samples_than_fit_in_lds(restore_options):
+    """
+    level_finish keeps a level's values, weights and cdf in LDS while 8 S bytes fit (S <= 18 000); beyond that the cdf
+    lives in global memory (`level_finish<false>`, the only form up to round 3).  S = 20 000 on a short sightline:
+    device levels == host levels (indices identical), and the profile cache (tiled, 20 000 rows) == recomputation.
+    """
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch, get_option
+
+    sights = [make_sightline(60, n_unmasked=130, n_masked=3), make_sightline(61, n_unmasked=90, n_masked=0)]
+    batch = DeviceBatch([device_sightline(s) for s in sights])
+    S, max_dlas = 20000, 3
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    min_sep = 3000.0 * 1000.0 / 299792458.0
+    want = parallel.sweep_batch(batch.eval, zs, nhi, max_dlas, min_sep, seed=4)
+    got = parallel.sweep_batch_device(batch, zs, nhi, max_dlas, min_sep, seed=4)
+    assert get_option("last_sweep_cached") == 1
+    np.testing.assert_array_equal(got[2], want[2])
+    assert got[2].max() > 0
+    assert np.array_equal(np.isnan(got[1]), np.isnan(want[1]))
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-12)
+    restore_options("profile_cache", 0)
+    again = parallel.sweep_batch_device(batch, zs, nhi, max_dlas, min_sep, seed=4)
+    assert get_option("last_sweep_cached") == 0
+    for a, b in zip(got, again):
+        np.testing.assert_array_equal(a, b)
+    batch.close()
+
+
 @pytest.mark.parametrize("tag", ["small", "full2k"])
 def test_by_sample_split_on_device_matches_reference_golden(tag):
     """
