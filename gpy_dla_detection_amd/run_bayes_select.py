@@ -19,6 +19,7 @@ Multi-GPU: `rank` / `world_size` shard the catalogue over one process per GPU, b
 every rank returns the full arrays, in catalogue order, after one all-gather per output (`parallel.gather_rows`).
 """
 from collections import namedtuple
+import os
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -306,8 +307,10 @@ def process_qso(
     if prefetch and len(bounds) > 1 and seed is not None:
         import threading
 
-        in_flight = threading.Semaphore(5)
-        prepare_pool, sweep_pool, finish_pool = (ThreadPoolExecutor(max_workers=w) for w in (1, 3, 1))
+        # DLAGP_PIPELINE="prepare,sweep,finish,in_flight" overrides the thread counts (a tuning knob, not an interface)
+        shape = [int(x) for x in os.environ.get("DLAGP_PIPELINE", "1,3,1,5").split(",")]
+        in_flight = threading.Semaphore(shape[3])
+        prepare_pool, sweep_pool, finish_pool = (ThreadPoolExecutor(max_workers=w) for w in shape[:3])
         failed = threading.Event()
 
         def stage_prepare(start, stop):
