@@ -370,7 +370,7 @@ __device__ __forceinline__ void accumulate_mfma_body(
         }
         pooled = !overflow;
         pool_used = pooled ? npool : 0;
-        // unused pool slots repeat slot 0's row: every pass issues the same number of row reads whatever the pool holds
+        // pool slots beyond the rows in use repeat slot 0's row (the rows are read four at a time, issue_rows)
         const int first = __builtin_amdgcn_readfirstlane(pool_val);
         // kept as the byte offset of the row within tile 0 of its group (issue_rows)
         const int pool_point = lane < npool ? pool_val : first;
@@ -516,9 +516,6 @@ __device__ __forceinline__ void accumulate_mfma_body(
 #ifndef DLAGP_CACHE_STORE_AUX
 #define DLAGP_CACHE_STORE_AUX 2  // cache policy of level 1's stores of the profiles: nt
 #endif
-#ifndef DLAGP_CONV_GROUP_L1
-#define DLAGP_CONV_GROUP_L1 4
-#endif
 #ifndef DLAGP_CACHE_LOAD_AUX
 #define DLAGP_CACHE_LOAD_AUX 2  // cache policy of the streamed rows of a cached level: nt
 #endif
@@ -575,7 +572,7 @@ __device__ __forceinline__ void accumulate_mfma_body(
     // time spilled a hundred registers).  The host keeps a sightline's part of the cache below 2^31 bytes.
     // Layout (dlagp_device.h): [group of 16 points][tile of 64 slots][16 points][64 slots] -- the 16 own rows of a
     // wave's pass are ONE contiguous 8 KB block and its passes follow each other in memory (round 4; with rows of
-    // n_slots doubles a pass read sixteen 512-byte pieces 24 KB apart: -2.7 % on the cached level).
+    // n_slots doubles a pass read sixteen 512-byte pieces 24 KB apart).
     const int group_bytes = (int)src.cache_group_stride * 8;
     const long cache_groups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
     const __amdgpu_buffer_rsrc_t cache_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -868,7 +865,7 @@ __device__ __forceinline__ void accumulate_mfma_body(
                 const double *raw_row = raw + s_loc * DLAGP_RAW_STRIDE;
                 double *a_dst = &a_lds[s_loc * A_STRIDE + slot];
                 // (7 with several absorbers per sample -- their running product is one more register pair per step -- spills)
-                constexpr int CONV_GROUP = PATCH == 1 && MODE == 0 ? 7 : (PATCH == 1 && MODE == 1 ? DLAGP_CONV_GROUP_L1 : 4);  // reads of that many steps in flight; the single-absorber kernel has the registers for 7
+                constexpr int CONV_GROUP = PATCH == 1 && MODE == 0 ? 7 : 4;  // reads of that many steps in flight; the single-absorber kernel has the registers for 7
                 constexpr int NW = BROADEN ? DLAGP_NUM_TAPS : 1;
 #pragma unroll
                 for (int g0 = 0; g0 < DLAGP_MAX_PASS_STEPS; g0 += CONV_GROUP) {
@@ -987,8 +984,9 @@ __device__ __forceinline__ void accumulate_mfma_body(
         if constexpr (MODE == 1) {
             // Level 1 of a cached sweep stores the pass's profiles right after the step loop (below).  The last step's
             // prefetch -- it "re-reads its own", never used -- would still be in flight there, in registers the store
-            // block's LDS reads are given next: a wait for ten L2 trips per pass (1.2 us of ~15: the whole of what this
-            // kernel cost over the one without the store).  So the last step is written out without the prefetch.
+            // block's LDS reads are given next: a wait for ten L2 trips per pass.  So the last step is written out without
+            // the prefetch (-0.9 %; what level 1 still costs over the kernel without the store is mostly the clock,
+            // profiles/r04_experiments.txt items 9, 10).
             for (int st = st_lo; st + 1 < pass_steps; ++st) DLAGP_STEP_BODY(st, true, true)
             DLAGP_STEP_BODY(pass_steps - 1, false, false)
         } else if constexpr (!CACHED) {
@@ -1044,7 +1042,8 @@ __device__ __forceinline__ void accumulate_mfma_body(
             // serves the sightline's operand.  All eight rows are read into registers of their own before the first
             // store: with one register set the compiler waited, before each LDS read, for the store before it to have
             // COMPLETED (no early release of a store's data registers on this target: `s_waitcnt vmcnt`) -- eight trips
-            // to HBM one after the other per pass, 8 % of the kernel.  Rows beyond S (the last group) are written too:
+            // to HBM one after the other per pass (-0.7 % alone, more beside other streams' kernels: the catalogue
+            // driver).  Rows beyond S (the last group) are written too:
             // the cache holds whole groups of 16 rows and the cached levels never read those.
             if (j2 < npx) {
                 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
