@@ -320,6 +320,9 @@ def parse_args(argv=None):
     ap.add_argument("--ramp-ms", type=float, default=150.0, help=argparse.SUPPRESS)  # untimed clock ramp before the warmup
     ap.add_argument("--samples", type=int, default=NUM_SAMPLES, help=argparse.SUPPRESS)
     ap.add_argument("--sightlines", type=int, default=0, help=argparse.SUPPRESS)  # tuning: override the batch width
+    # unmasked pixels per synthetic sightline (2 % masked): real DR12Q sightlines keep <= 1250, median ~685
+    # (reference set_parameters.py:33-34,58; tools/measure_frac_vs_n.py, profiles/r05_frac_vs_n.json)
+    ap.add_argument("--pixels", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-other-configs", action="store_true", help=argparse.SUPPRESS)  # headline measurement only
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)  # print that object and leave
@@ -429,14 +432,16 @@ class Workload:
     pass of the hot path over them, enqueued on torch's current stream.
     """
 
-    def __init__(self, env, config, S, nb, strong, slots):
+    def __init__(self, env, config, S, nb, strong, slots, pixels=0):
         from gpy_dla_detection_amd import sightline as sl
         from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline
 
         torch = env.torch
         self.env, self.config, self.S, self.nb, self.strong, self.slots, self.sl = env, config, S, nb, strong, slots, sl
         first = 0 if strong else env.rank * nb  # weak scaling: every rank has its own sightlines
-        self.sights = [make_sightline(first + i, n_unmasked=N_UNMASKED, n_masked=N_MASKED, k=RANK_K) for i in range(nb)]
+        n_u = pixels or N_UNMASKED
+        n_masked = N_MASKED if not pixels else max(1, round(pixels * N_MASKED / N_UNMASKED))
+        self.sights = [make_sightline(first + i, n_unmasked=n_u, n_masked=n_masked, k=RANK_K) for i in range(nb)]
         self.z_host = np.stack([make_qmc_samples(s, S)[0] for s in self.sights])
         self.nhi_dla_host = make_qmc_samples(self.sights[0], S)[2]
         self.nhi_sub_host = make_qmc_samples(self.sights[0], S, sub_dla=True)[2]
@@ -637,7 +642,7 @@ def main(argv=None) -> None:
 
     S = args.samples
     nb = args.sightlines or WORKLOADS[config]["sightlines"]
-    work = Workload(env, config, S, nb, args.strong, slots=max(steps, warmup, 1))
+    work = Workload(env, config, S, nb, args.strong, slots=max(steps, warmup, 1), pixels=args.pixels)
     sights = work.sights
 
     # the CPU baseline forks worker processes: do it before this process touches the GPU
@@ -725,7 +730,7 @@ def main(argv=None) -> None:
     # warm-up step and three timed steps each (config 3: 36 ms, config 4: 73 ms, config 5: 38 ms per step).
     others = None
     if (config == 2 and not args.strong and not args.no_other_configs and S == NUM_SAMPLES and not args.sightlines
-            and not args.splits and not args.option and not args.debug):
+            and not args.splits and not args.option and not args.debug and not args.pixels):
         others = {str(c): measure_side_config(env, c, steps=3, warmup=1) for c in (3, 4, 5)}
         strong = measure_side_config(env, 2, steps=100, warmup=20, strong=True)
 
@@ -752,7 +757,7 @@ def main(argv=None) -> None:
             "config": {
                 "workload": "configs[%d] (SURVEY 8d config %d): %s; S=%d QMC samples, n=%d pixels (n_u=%d), rank k=%d, 3 Lyman lines"
                             % (WORKLOADS[config]["baseline_index"], config, WORKLOADS[config]["what"], S, n_pixels,
-                               N_UNMASKED, rank_k),
+                               args.pixels or N_UNMASKED, rank_k),
                 "sightlines_per_gpu": nb if not args.strong else 1.0 / world,
                 "samples_per_sightline": S,
                 "evals_per_step_per_gpu": evals_per_step,

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DLAGP_LIB") or os.path.join(_HERE, "csrc", "libdlagp_hip.so")
 
 # error codes of include/dlagp.h
-DLAGP_OK, DLAGP_EINVAL, DLAGP_EDEVICE, DLAGP_ELINALG = 0, -1, -2, -3
+DLAGP_OK, DLAGP_EINVAL, DLAGP_EDEVICE, DLAGP_ELINALG, DLAGP_ENOMEM = 0, -1, -2, -3, -4
 
 # every symbol include/dlagp.h declares: name -> (restype, argtypes)
 _dp = POINTER(c_double)
@@ -55,6 +55,7 @@ SIGNATURES = {
                                             _dp, _dp, _dp, _dp, _dp, _dp, POINTER(ctypes.c_int32)]),
     "dlagp_batch_model_evidences_start": (c_int, [c_void_p, c_int64, c_int, _dp, _dp, c_int64, _dp, _dp, c_int64, c_double]),
     "dlagp_batch_model_evidences_finish": (c_int, [c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, POINTER(ctypes.c_int32)]),
+    "dlagp_batch_model_evidences_cancel": (c_int, [c_void_p]),
     "dlagp_batch_level_eval_device": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
                                               c_void_p, c_int, c_void_p, c_void_p]),
     "dlagp_sweep_state_init_device": (c_int, [c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -191,6 +192,8 @@ def check(rc: int) -> None:
         raise ValueError(msg)
     if rc == DLAGP_ELINALG:
         raise np.linalg.LinAlgError(msg)  # numpy.linalg.cholesky at reference null_gp.py:343
+    if rc == DLAGP_ENOMEM:
+        raise MemoryError(msg)  # what NumPy raises when an allocation of the reference's fails
     raise RuntimeError(msg)
 
 

@@ -55,11 +55,18 @@ class BayesModelSelect:
         finish_evidences = self._start_evidences_in_one_call(model_list)
 
         # priors of the absorber models; the null model takes what is left (reference :68-80)
-        priors = []
-        for model, num in zip(model_list, self.all_max_dlas):
-            priors.extend([np.nan] if num == 0 else list(model.log_priors(z_qso, num)))
-        log_priors = np.array(priors)
-        log_priors[0] = np.log(1 - np.exp(logsumexp(log_priors[1:])))
+        try:
+            priors = []
+            for model, num in zip(model_list, self.all_max_dlas):
+                priors.extend([np.nan] if num == 0 else list(model.log_priors(z_qso, num)))
+            log_priors = np.array(priors)
+            log_priors[0] = np.log(1 - np.exp(logsumexp(log_priors[1:])))
+        except BaseException:
+            # the call started above will never be finished: the spectrum's shared batch must not keep it pending
+            # (the GP objects go on using that batch)
+            if finish_evidences is not None:
+                finish_evidences.cancel()
+            raise
 
         # evidences: this is where the GPU sweep runs (reference :84-96)
         log_likelihoods = finish_evidences() if finish_evidences is not None else None
@@ -129,6 +136,7 @@ class BayesModelSelect:
             settle_rng_after_sweep(ev_dla[0], max_dlas, S, rng_before)
             return np.concatenate([nulls, ev_sub[0], ev_dla[0]])
 
+        finish.cancel = batch.model_evidences_cancel
         return finish
 
     @property

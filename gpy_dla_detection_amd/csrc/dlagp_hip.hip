@@ -15,6 +15,8 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -42,6 +44,42 @@ static int fail(int code, const char *fmt, ...) {
     g_last_error = buf;
     return code;
 }
+
+// Exception barrier of the C ABI (include/dlagp.h: "Nothing aborts the process").  The host side uses std::vector,
+// std::map, std::string and new; an exception that left an extern "C" function would unwind into the caller's frames --
+// ctypes, cgo, JNI -- and end in std::terminate.  Every exported function is a function-try-block whose handler turns
+// whatever was thrown into a status code and a message (DLAGP_CATCH_INT; the destroy functions swallow: DLAGP_CATCH_VOID).
+static int exception_status(const char *where) noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        try {
+            return fail(DLAGP_ENOMEM, "%s: out of host memory (std::bad_alloc)", where);
+        } catch (...) {  // the message itself could not be stored
+            return DLAGP_ENOMEM;
+        }
+    } catch (const std::length_error &e) {
+        try {
+            return fail(DLAGP_ENOMEM, "%s: a size exceeds what the host can address (%s)", where, e.what());
+        } catch (...) {
+            return DLAGP_ENOMEM;
+        }
+    } catch (const std::exception &e) {
+        try {
+            return fail(DLAGP_EINVAL, "%s: unexpected C++ exception: %s", where, e.what());
+        } catch (...) {
+            return DLAGP_EINVAL;
+        }
+    } catch (...) {
+        try {
+            return fail(DLAGP_EINVAL, "%s: unexpected C++ exception of unknown type", where);
+        } catch (...) {
+            return DLAGP_EINVAL;
+        }
+    }
+}
+#define DLAGP_CATCH_INT(name) catch (...) { return exception_status(name); }
+#define DLAGP_CATCH_VOID(name) catch (...) { (void)exception_status(name); }
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -413,6 +451,7 @@ struct dlagp_ctx {
     DeviceBuffer dense_M;      // interpolated / uploaded factor, row-major [n][k], kept for dlagp_ctx_read_model
     DeviceBuffer scratch_a, scratch_b;  // inputs of the set-up kernels, released once the set-up stream has drained
     bool setup_pending = false;         // created with DLAGP_FLAG_DEFER_SYNC and not known to be complete yet
+    std::mutex setup_mutex;             // two threads may first-use one deferred context at once (two batches sharing a member)
     hipEvent_t setup_event = nullptr;   // ... recorded behind the set-up work on the creating thread's set-up stream
     bool negative_noise = false;        // v or omega2 has a negative entry: d = omega2 a^2 + v may be negative
     std::vector<int> h_pos;    // host copy of pos[]
@@ -510,7 +549,7 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
     hipExtLaunchKernelGGL((accumulate_mfma<__VA_ARGS__>), grid, dim3(DLAGP_MFMA_THREADS), (uint32_t)prep_lds, stream, \
                           ev_start, ev_stop, 0u, table,                                                             \
                        plan->passes(), plan->items(), nb, S, kd, src, part, \
-                       status, launch_flags)
+                       status, launch_flags, fused_out)
 
 // how the line cores are handled (kernels_mfma.h): 0 tested for inside the sample loop; 1 one absorber per sample,
 // repaired once per wave; 2 several absorbers per sample, repaired pass by pass.  1 and 2 need three lines and a
@@ -523,7 +562,7 @@ static int patch_mode(const LaunchGroup &g, int kd) {
 template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, const LaunchPlan *plan, int nb,
                         long S, int kd, int num_lines, const SampleSource &src, double *part, int *status,
-                        int patch, bool lls, int launch_flags, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                        int patch, bool lls, int launch_flags, hipEvent_t ev_start, hipEvent_t ev_stop, double *fused_out) {
     // 16 samples + one spare row that the look-ahead of the sample loop may read; PATCH 2: 3 ints per (sample, absorber)
     const size_t prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * kd * (lls ? 6 : (LINES > 0 ? LINES : num_lines) + 1) * sizeof(double) +
                             (patch == 2 ? (size_t)DLAGP_MFMA_GROUP * kd * 3 * sizeof(int) : 0);
@@ -536,13 +575,30 @@ static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table
             else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, 0, true);
             return;
         }
+        // the production flavours (3 lines, broadening) also exist with the wave's own finalisation (fused_eligible)
         if (patch == 1) {  // line cores repaired outside the sample loop (kd == 1, uniform grid)
+            if constexpr (BROADEN) {
+                if (fused_out && src.cache_mode == 1) {
+                    DLAGP_LAUNCH_MFMA(3, true, false, 1, 1, false, true);
+                    return;
+                }
+                if (fused_out) {
+                    DLAGP_LAUNCH_MFMA(3, true, false, 0, 1, false, true);
+                    return;
+                }
+            }
             if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 1, 1);
             else if (g_opt_debug & 2) DLAGP_LAUNCH_MFMA(3, BROADEN, true, 0, 1);  // with per-phase cycle stamps
             else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, 1);
             return;
         }
         if (patch == 2 && !(g_opt_debug & 2)) {  // several absorbers per sample, cores repaired pass by pass
+            if constexpr (BROADEN) {
+                if (fused_out) {
+                    DLAGP_LAUNCH_MFMA(3, true, false, 0, 2, false, true);
+                    return;
+                }
+            }
             DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, 2);
             return;
         }
@@ -559,6 +615,19 @@ static bool mfma_path_serves(const LaunchGroup &g, int kd, bool cached = false) 
     const size_t mfma_prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * std::max(kd, 1) * ((g.lls_break ? 5 : g.num_lines) + 1 + 2) * sizeof(double);
     if (g.lls_break && !cached && g.num_lines != 3) return false;  // the Lyman-limit term lives in the 3-line sample loop
     return g.mfma_ok && kd >= 1 && mfma_prep_lds <= 40 * 1024 && g_opt_path != 1;
+}
+
+// Whether the accumulate waves of a launch finish their own blocks (kernels_mfma.h, FUSED): every block is ONE piece (the
+// plans of batches: more blocks than wave slots), rank 20, and the flavour is one of the production instantiations
+// that exist in that form -- 3 lines with broadening, no Lyman-limit term, the line cores repaired outside the sample
+// loop; the cached levels of a sweep.  Option "fuse_finalize" = 0 keeps the two-kernel form (the cross-check).
+static Option g_opt_fuse_finalize = 1;
+static Option g_last_launch_fused = 0;
+static bool fused_eligible(const LaunchGroup &g, const LaunchPlan *plan, int patch, int cache_mode) {
+    if (!g_opt_fuse_finalize || !plan || plan->max_parts != 1 || g.col_groups != 1 || g.k != DLAGP_FIN_K) return false;
+    if (g_opt_debug & 2) return false;  // the stamped diagnostic instantiation is unfused
+    if (cache_mode == 2) return true;
+    return g.num_lines == 3 && g.broadening && !g.lls_break && (patch == 1 || (patch == 2 && cache_mode == 0));
 }
 
 // finalisation of a general rank (above 20) from column-major rows: one wave per sample, or (option finalize_wave = 0,
@@ -604,8 +673,12 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
     const size_t nblocks = (size_t)nb * ((S + 15) / 16);
     // ranks above 20 on the MFMA path: every column group leaves rank-20-sized sums, regrouped into ws.part2 (below)
     const bool grouped = use_mfma && g.col_groups > 1;
-    const size_t part_bytes = grouped ? (size_t)g.col_groups * nparts * nblocks * DLAGP_MFMA_ROW_WIDTH * 16 * sizeof(double)
-                                      : (size_t)nparts * nblocks * g.row_width * 16 * sizeof(double);
+    const int patch = !use_mfma || src.cache_mode == 2 ? 0 : patch_mode(g, kd);
+    // single-piece plans: the accumulate waves finish their own blocks, no partial sums cross HBM (and none are allocated)
+    const bool fused = use_mfma && fused_eligible(g, plan, patch, src.cache_mode);
+    const size_t part_bytes = fused ? 0
+                              : grouped ? (size_t)g.col_groups * nparts * nblocks * DLAGP_MFMA_ROW_WIDTH * 16 * sizeof(double)
+                                        : (size_t)nparts * nblocks * g.row_width * 16 * sizeof(double);
     if (grouped && (rc = grow(g, ws.part2, nblocks * g.row_width * 16 * sizeof(double)))) return rc;
     // kernels enqueued earlier may still be using the buffer that a larger request replaces: grow() drains them
     if ((rc = grow(g, ws.part, part_bytes))) return rc;
@@ -637,13 +710,17 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
 
     int *status = status_shared ? status_shared : ws.status.as<int>();
     g_last_launch_path = use_mfma ? 2 : 1;
+    g_last_launch_fused = fused ? 1 : 0;
     if (use_mfma) {
         g_last_launch_items = plan->nitems;
         g_last_launch_parts = plan->max_parts;
         dim3 grid((unsigned)plan->nitems);
         const bool lines3 = g.num_lines == 3;
-        const int patch = src.cache_mode == 2 ? 0 : patch_mode(g, kd);
         g_last_launch_patch = patch;
+        double *fused_out = fused ? d_out : nullptr;
+        // the waves raise the non-PD flag themselves: cleared here, in front of the launch (the unfused kernel's first
+        // workgroup clears it, long before the finalisation kernel can raise it)
+        if (fused && !keep_status) HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), stream));
         const bool lls = g.lls_break;
         double *part = ws.part.as<double>();
         const int launch_flags = (keep_status ? DLAGP_LAUNCH_KEEP_STATUS : 0) | (g_opt_shared_rows ? 0 : DLAGP_LAUNCH_GENERAL_ROWS) |
@@ -651,13 +728,14 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
         if (src.cache_mode == 2) {
             // [kd - 1][16] stacked rows of the wave's samples + its pool of 16 distinct rows (ints), see accumulate_mfma_body
             const size_t prep_lds = (size_t)(DLAGP_MAX_ABSORBERS * 16) * sizeof(int);
-            DLAGP_LAUNCH_MFMA(3, true, false, 2);
+            if (fused) DLAGP_LAUNCH_MFMA(3, true, false, 2, 0, false, true);
+            else DLAGP_LAUNCH_MFMA(3, true, false, 2);
         } else if (g.broadening) {
-            if (lines3) launch_mfma<3, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags, ev_start, ev_stop);
-            else launch_mfma<0, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags, ev_start, ev_stop);
+            if (lines3) launch_mfma<3, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags, ev_start, ev_stop, fused_out);
+            else launch_mfma<0, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags, ev_start, ev_stop, fused_out);
         } else {
-            if (lines3) launch_mfma<3, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags, ev_start, ev_stop);
-            else launch_mfma<0, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags, ev_start, ev_stop);
+            if (lines3) launch_mfma<3, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags, ev_start, ev_stop, fused_out);
+            else launch_mfma<0, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags, ev_start, ev_stop, fused_out);
         }
         HIP_TRY(hipGetLastError());
     } else {
@@ -683,7 +761,9 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
         tg.armed = false;
     }
 
-    if (grouped) {
+    if (fused) {
+        // nothing to finish: the accumulate waves wrote d_out
+    } else if (grouped) {
         hipLaunchKernelGGL(regroup_native, dim3((unsigned)nblocks), dim3(256), 0, stream, ws.part.as<const double>(), nparts,
                            (long)S, table, plan->counts(), ws.part2.as<double>());
         launch_finalize_general(stream, ws.part2.as<const double>(), 1, rows, (long)S, table, d_out, status, nullptr);
@@ -1115,6 +1195,9 @@ static int setup_sync(int device) {
 // dlagp_ctx_read_model, dlagp_destroy -- waits for that event; nothing rests on "the same thread synchronised its
 // stream".
 static int wait_setup(dlagp_ctx *ctx) {
+    // the header promises "first use on ANY host thread": two first uses at once (two dlagp_batch_create calls sharing a
+    // member) must not both synchronise and destroy the one event, nor release the scratch buffers twice
+    std::lock_guard<std::mutex> lock(ctx->setup_mutex);
     if (!ctx->setup_pending) return DLAGP_OK;
     if (ctx->setup_event) {
         HIP_TRY(hipEventSynchronize(ctx->setup_event));
@@ -1389,19 +1472,19 @@ static int upload_padded(DeviceBuffer &buf, const double *src, int n, int n_pad,
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int dlagp_abi_version(void) { return 1; }
+int dlagp_abi_version(void) { return 2; }  // 2: DLAGP_ENOMEM, exception barrier on every entry point
 
-int dlagp_device_count(void) {
+int dlagp_device_count(void) try {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess) return 0;
     return count;
-}
+} DLAGP_CATCH_INT("dlagp_device_count")
 
 const char *dlagp_last_error(void) { return g_last_error.c_str(); }
 
 int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const double *mu, const double *M,
                  ptrdiff_t m_row_stride, ptrdiff_t m_col_stride, const double *omega2, const double *v,
-                 const double *wavelengths, const uint8_t *keep, int num_lines, int broadening, int device) {
+                 const double *wavelengths, const uint8_t *keep, int num_lines, int broadening, int device) try {
     if (out) *out = nullptr;
     if (!y || !mu || !M || !omega2 || !v) return fail(DLAGP_EINVAL, "NULL input array");
     return create_context(out, n, n_u, k, wavelengths, keep, num_lines, broadening, device, [&](dlagp_ctx *ctx) -> int {
@@ -1417,12 +1500,12 @@ int dlagp_create(dlagp_ctx **out, int n, int n_u, int k, const double *y, const 
             for (int c = 0; c < k; ++c) hM[(size_t)i * sl.k + c] = M[i * m_row_stride + c * m_col_stride];
         return upload_staged(ctx->dense_M.ptr, hM.data(), hM.size() * sizeof(double), ctx->device);
     });
-}
+} DLAGP_CATCH_INT("dlagp_create")
 
 int dlagp_model_create(dlagp_model **out, int n_grid, int k, const double *rest_wavelengths, const double *mu,
                        const double *M, ptrdiff_t m_row_stride, ptrdiff_t m_col_stride, const double *log_omega,
                        double log_c_0, double log_tau_0, double log_beta, double prev_tau_0, double prev_beta,
-                       int num_forest_lines, int device) {
+                       int num_forest_lines, int device) try {
     if (!out) return fail(DLAGP_EINVAL, "out is NULL");
     *out = nullptr;
     if (!rest_wavelengths || !mu || !M || !log_omega) return fail(DLAGP_EINVAL, "NULL input array");
@@ -1480,9 +1563,9 @@ int dlagp_model_create(dlagp_model **out, int n_grid, int k, const double *rest_
     }
     *out = m;
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_model_create")
 
-void dlagp_model_destroy(dlagp_model *model) {
+void dlagp_model_destroy(dlagp_model *model) try {
     if (!model) return;
     (void)hipSetDevice(model->device);
     model->grid.release();
@@ -1490,16 +1573,16 @@ void dlagp_model_destroy(dlagp_model *model) {
     model->log_omega.release();
     model->M.release();
     delete model;
-}
+} DLAGP_CATCH_VOID("dlagp_model_destroy")
 
-int dlagp_setup_sync(int device) {
+int dlagp_setup_sync(int device) try {
     int rc = ensure_device(device);
     return rc ? rc : setup_sync(device);
-}
+} DLAGP_CATCH_INT("dlagp_setup_sync")
 
 int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, int n_u, const double *x,
                             const double *y, const double *v, const double *this_wavelengths, double z_qso,
-                            const double *wavelengths, const uint8_t *keep, int num_lines, int broadening) {
+                            const double *wavelengths, const uint8_t *keep, int num_lines, int broadening) try {
     if (out) *out = nullptr;
     if (!model) return fail(DLAGP_EINVAL, "model is NULL");
     if (!x || !y || !v || !this_wavelengths) return fail(DLAGP_EINVAL, "NULL input array");
@@ -1531,9 +1614,9 @@ int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, in
         if (err != hipSuccess) return fail(DLAGP_EDEVICE, "interp_model failed: %s", hipGetErrorString(err));
         return DLAGP_OK;
     });
-}
+} DLAGP_CATCH_INT("dlagp_create_from_model")
 
-int dlagp_ctx_read_model(dlagp_ctx *ctx, double *this_mu, double *this_M, double *this_omega2) {
+int dlagp_ctx_read_model(dlagp_ctx *ctx, double *this_mu, double *this_M, double *this_omega2) try {
     if (!ctx) return fail(DLAGP_EINVAL, "context is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     if (int rc = wait_setup(ctx)) return rc;
@@ -1547,9 +1630,9 @@ int dlagp_ctx_read_model(dlagp_ctx *ctx, double *this_mu, double *this_M, double
             for (int c = 0; c < k; ++c) this_M[(size_t)i * k + c] = host[(size_t)i * ks + c];
     }
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_ctx_read_model")
 
-void dlagp_destroy(dlagp_ctx *ctx) {
+void dlagp_destroy(dlagp_ctx *ctx) try {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     // deferred set-up (DLAGP_FLAG_DEFER_SYNC) that nobody waited for: its copies and kernels may still be writing the
@@ -1583,7 +1666,7 @@ void dlagp_destroy(dlagp_ctx *ctx) {
     ctx->scratch_a.release();
     ctx->scratch_b.release();
     delete ctx;
-}
+} DLAGP_CATCH_VOID("dlagp_destroy")
 
 int dlagp_ctx_n(const dlagp_ctx *ctx) { return ctx ? ctx->sl.n : DLAGP_EINVAL; }
 int dlagp_ctx_k(const dlagp_ctx *ctx) { return ctx ? ctx->user_k : DLAGP_EINVAL; }
@@ -1597,6 +1680,15 @@ static int batch_alive(const dlagp_batch *batch) {
     return DLAGP_OK;
 }
 
+// dlagp_batch_model_evidences_start has run and _finish has not, and another call arrives on the batch: that call reuses
+// the staging memory and the sample tables the pending phase left for _finish, so the pending call is over -- its
+// kernels drain, and a later _finish reports "without a matching _start" instead of sweeping over overwritten inputs.
+static void cancel_pending(dlagp_batch *batch) {
+    if (!batch || !batch->pending.active) return;
+    batch->group.drain();
+    batch->pending.active = false;
+}
+
 static int check_eval_args(const void *ctx, int64_t S, int kd, const void *z, const void *nhi, const void *out) {
     if (!ctx) return fail(DLAGP_EINVAL, "context is NULL");
     if (S < 0) return fail(DLAGP_EINVAL, "S=%lld is negative", (long long)S);
@@ -1606,24 +1698,24 @@ static int check_eval_args(const void *ctx, int64_t S, int kd, const void *z, co
     return DLAGP_OK;
 }
 
-int dlagp_eval(dlagp_ctx *ctx, int64_t S, int kd, const double *z, const double *nhi, double *out) {
+int dlagp_eval(dlagp_ctx *ctx, int64_t S, int kd, const double *z, const double *nhi, double *out) try {
     int rc = check_eval_args(ctx, S, kd, z, nhi, out);
     if (rc) return rc;
     if (S == 0) return DLAGP_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     if ((rc = wait_setup(ctx))) return rc;
     return sweep_from_host(ctx->self, S, kd, z, nhi, out);
-}
+} DLAGP_CATCH_INT("dlagp_eval")
 
-int dlagp_null(dlagp_ctx *ctx, double *out) {
+int dlagp_null(dlagp_ctx *ctx, double *out) try {
     if (!ctx || !out) return fail(DLAGP_EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(ctx->device));
     if (int rc = wait_setup(ctx)) return rc;
     return sweep_from_host(ctx->self, 1, 0, nullptr, nullptr, out);
-}
+} DLAGP_CATCH_INT("dlagp_null")
 
 int dlagp_mvnpdf(int n, int k, const double *y, const double *mu, const double *M, ptrdiff_t m_row_stride,
-                 ptrdiff_t m_col_stride, const double *d, double *out, int device) {
+                 ptrdiff_t m_col_stride, const double *d, double *out, int device) try {
     if (!y || !mu || !M || !d || !out) return fail(DLAGP_EINVAL, "NULL argument");
     if (n <= 0) return fail(DLAGP_EINVAL, "n=%d must be positive", n);
     // a = 1, omega2 = 0, v = d: the null-model density with diagonal d
@@ -1637,9 +1729,9 @@ int dlagp_mvnpdf(int n, int k, const double *y, const double *mu, const double *
     rc = dlagp_null(ctx, out);
     dlagp_destroy(ctx);
     return rc;
-}
+} DLAGP_CATCH_INT("dlagp_mvnpdf")
 
-int dlagp_absorption(dlagp_ctx *ctx, int kd, const double *z, const double *nhi, double *out) {
+int dlagp_absorption(dlagp_ctx *ctx, int kd, const double *z, const double *nhi, double *out) try {
     int rc = check_eval_args(ctx, 1, kd, z, nhi, out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1663,19 +1755,19 @@ int dlagp_absorption(dlagp_ctx *ctx, int kd, const double *z, const double *nhi,
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, ws.out.ptr, (size_t)ctx->sl.n * sizeof(double), hipMemcpyDeviceToHost));
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_absorption")
 
 int dlagp_eval_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, const double *d_nhi, double *d_out,
-                      void *stream) {
+                      void *stream) try {
     int rc = check_eval_args(ctx, S, kd, d_z, d_nhi, d_out);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     if ((rc = wait_setup(ctx))) return rc;
     return launch_sweep(ctx->self, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0}, d_out,
                         static_cast<hipStream_t>(stream));
-}
+} DLAGP_CATCH_INT("dlagp_eval_device")
 
-int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
+int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) try {
     if (!out) return fail(DLAGP_EINVAL, "out is NULL");
     *out = nullptr;
     if (!ctxs || nb <= 0) return fail(DLAGP_EINVAL, "empty batch");
@@ -1714,9 +1806,9 @@ int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) {
     }
     *out = batch;
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_batch_create")
 
-void dlagp_batch_destroy(dlagp_batch *batch) {
+void dlagp_batch_destroy(dlagp_batch *batch) try {
     if (!batch) return;
     (void)hipSetDevice(batch->group.device);
     // the workspace goes to the next batch, which may launch on another stream
@@ -1745,32 +1837,35 @@ void dlagp_batch_destroy(dlagp_batch *batch) {
     if (parked) keep.release();
     batch->group.release();
     delete batch;
-}
+} DLAGP_CATCH_VOID("dlagp_batch_destroy")
 
 int dlagp_batch_eval_device(dlagp_batch *batch, int64_t S, int kd, const double *d_z, const double *d_nhi,
-                            double *d_out, void *stream) {
+                            double *d_out, void *stream) try {
     int rc = check_eval_args(batch, S, kd, d_z, d_nhi, d_out);
     if (rc || (rc = batch_alive(batch))) return rc;
+    cancel_pending(batch);
     HIP_TRY(hipSetDevice(batch->group.device));
     return launch_sweep(batch->group, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0}, d_out,
                         static_cast<hipStream_t>(stream));
-}
+} DLAGP_CATCH_INT("dlagp_batch_eval_device")
 
-int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, const double *nhi, double *out) {
+int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, const double *nhi, double *out) try {
     int rc = check_eval_args(batch, S, kd, z, nhi, out);
     if (rc || (rc = batch_alive(batch))) return rc;
+    cancel_pending(batch);
     if (S == 0) return DLAGP_OK;
     HIP_TRY(hipSetDevice(batch->group.device));
     return sweep_from_host(batch->group, S, kd, z, nhi, out);
-}
+} DLAGP_CATCH_INT("dlagp_batch_eval")
 
-int dlagp_batch_null(dlagp_batch *batch, double *out) {
+int dlagp_batch_null(dlagp_batch *batch, double *out) try {
     if (!batch || !out) return fail(DLAGP_EINVAL, "NULL argument");
     int rc = batch_alive(batch);
     if (rc) return rc;
+    cancel_pending(batch);
     HIP_TRY(hipSetDevice(batch->group.device));
     return sweep_from_host(batch->group, 1, 0, nullptr, nullptr, out);
-}
+} DLAGP_CATCH_INT("dlagp_batch_null")
 
 static int check_sweep_args(const dlagp_batch *batch, int64_t S, int max_dlas, const void *sample_z,
                             const void *sample_nhi, int64_t nhi_stride, const void *uniforms, const void *evidences) {
@@ -1789,21 +1884,23 @@ static int check_sweep_args(const dlagp_batch *batch, int64_t S, int max_dlas, c
 int dlagp_batch_sweep_device(dlagp_batch *batch, int64_t S, int max_dlas, const double *d_sample_z,
                              const double *d_sample_nhi, int64_t nhi_stride, double min_z_separation,
                              const double *d_uniforms, double *d_evidences, double *d_sample_ll, int32_t *d_base_inds,
-                             void *stream) {
+                             void *stream) try {
     int rc = check_sweep_args(batch, S, max_dlas, d_sample_z, d_sample_nhi, nhi_stride, d_uniforms, d_evidences);
     if (rc) return rc;
     if (!d_sample_ll || (max_dlas > 1 && !d_base_inds))
         return fail(DLAGP_EINVAL, "the device variant needs d_sample_ll and d_base_inds (they are its working state)");
+    cancel_pending(batch);
     HIP_TRY(hipSetDevice(batch->group.device));
     return sweep_levels(batch->group, S, max_dlas, d_sample_z, d_sample_nhi, nhi_stride, min_z_separation, d_uniforms,
                         d_evidences, d_sample_ll, d_base_inds, static_cast<hipStream_t>(stream));
-}
+} DLAGP_CATCH_INT("dlagp_batch_sweep_device")
 
 int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double *sample_z, const double *sample_nhi,
                       int64_t nhi_stride, double min_z_separation, const double *uniforms, double *evidences,
-                      double *sample_ll, int32_t *base_inds) {
+                      double *sample_ll, int32_t *base_inds) try {
     int rc = check_sweep_args(batch, S, max_dlas, sample_z, sample_nhi, nhi_stride, uniforms, evidences);
     if (rc) return rc;
+    cancel_pending(batch);
     LaunchGroup &g = batch->group;
     HIP_TRY(hipSetDevice(g.device));
     Workspace &ws = g.ws;
@@ -1838,7 +1935,7 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
     for (auto &p : g.parts) p->launched = false;
     if (status) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_batch_sweep")
 
 // The evidence loop of BayesModelSelect.model_selection (reference bayesian_model_selection.py:84-95) for every
 // sightline of the batch in ONE call: the one-absorber model (sub-DLAs), the occupation sweep of the DLA model and the
@@ -1846,7 +1943,7 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
 // batch instead of three of each.
 int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dlas, const double *sub_sample_z,
                                       const double *sub_sample_nhi, int64_t sub_nhi_stride, const double *sample_z,
-                                      const double *sample_nhi, int64_t nhi_stride, double min_z_separation) {
+                                      const double *sample_nhi, int64_t nhi_stride, double min_z_separation) try {
     double dummy = 0.0;  // check_sweep_args wants the output arrays of the one-call form: they come with _finish
     int rc = check_sweep_args(batch, S, max_dlas, sample_z, sample_nhi, nhi_stride, max_dlas > 1 ? &dummy : nullptr, &dummy);
     if (rc) return rc;
@@ -1854,10 +1951,7 @@ int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dla
     LaunchGroup &g = batch->group;
     HIP_TRY(hipSetDevice(g.device));
     Workspace &ws = g.ws;
-    if (batch->pending.active) {  // a call that was started and never finished: let its kernels drain
-        g.drain();
-        batch->pending.active = false;
-    }
+    cancel_pending(batch);  // a call that was started and never finished: let its kernels drain
     const size_t nb = g.ctxs.size();
     const size_t rows = nb * (size_t)S;
     const size_t n_nhi = nhi_stride ? (size_t)nhi_stride * (nb - 1) + S : (size_t)S;
@@ -1899,11 +1993,11 @@ int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dla
     batch->pending.stage_used = tr.total;
     batch->pending.stream = stream;
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_batch_model_evidences_start")
 
 int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniforms, double *null_evidences,
                                        double *sub_evidences, double *sub_sample_ll, double *evidences, double *sample_ll,
-                                       int32_t *base_inds) {
+                                       int32_t *base_inds) try {
     int rc = batch_alive(batch);
     if (rc) return rc;
     if (!batch->pending.active) return fail(DLAGP_EINVAL, "dlagp_batch_model_evidences_finish without a matching _start");
@@ -1949,13 +2043,20 @@ int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniform
     for (auto &p : g.parts) p->launched = false;
     if (status[0] || status[1]) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_batch_model_evidences_finish")
+
+int dlagp_batch_model_evidences_cancel(dlagp_batch *batch) try {
+    if (!batch) return fail(DLAGP_EINVAL, "NULL batch");
+    (void)hipSetDevice(batch->group.device);
+    cancel_pending(batch);
+    return DLAGP_OK;
+} DLAGP_CATCH_INT("dlagp_batch_model_evidences_cancel")
 
 int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, const double *sub_sample_z,
                                 const double *sub_sample_nhi, int64_t sub_nhi_stride, const double *sample_z,
                                 const double *sample_nhi, int64_t nhi_stride, double min_z_separation,
                                 const double *uniforms, double *null_evidences, double *sub_evidences,
-                                double *sub_sample_ll, double *evidences, double *sample_ll, int32_t *base_inds) {
+                                double *sub_sample_ll, double *evidences, double *sample_ll, int32_t *base_inds) try {
     if (max_dlas > 1 && !uniforms) return fail(DLAGP_EINVAL, "uniforms are required when max_dlas > 1");
     if (!null_evidences || !sub_evidences || !evidences) return fail(DLAGP_EINVAL, "NULL argument");
     int rc = dlagp_batch_model_evidences_start(batch, S, max_dlas, sub_sample_z, sub_sample_nhi, sub_nhi_stride, sample_z,
@@ -1963,14 +2064,14 @@ int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, con
     if (rc) return rc;
     return dlagp_batch_model_evidences_finish(batch, uniforms, null_evidences, sub_evidences, sub_sample_ll, evidences,
                                               sample_ll, base_inds);
-}
+} DLAGP_CATCH_INT("dlagp_batch_model_evidences")
 
 // ---- one sightline's samples split over several GPUs (SURVEY 8e "secondary", reference dla_gp.py:132-159 is
 // independent per sample, :209-218 needs all S): every rank evaluates its slice of a level, the slices are
 // all-gathered by the caller (RCCL), and every rank finishes the level on the full vector with the same uniforms
 int dlagp_batch_level_eval_device(dlagp_batch *batch, int64_t S_total, int64_t s_begin, int64_t s_count, int level,
                                   const double *d_sample_z, const double *d_sample_nhi, int64_t nhi_stride,
-                                  const int32_t *d_base_inds, int base_levels, double *d_out, void *stream) {
+                                  const int32_t *d_base_inds, int base_levels, double *d_out, void *stream) try {
     int alive = batch_alive(batch);
     if (alive) return alive;
     if (S_total <= 0 || s_begin < 0 || s_count < 0 || s_begin + s_count > S_total)
@@ -1983,13 +2084,14 @@ int dlagp_batch_level_eval_device(dlagp_batch *batch, int64_t S_total, int64_t s
         return fail(DLAGP_EINVAL, "NULL argument");
     if (s_count == 0) return DLAGP_OK;
     HIP_TRY(hipSetDevice(batch->group.device));
+    cancel_pending(batch);
     const SampleSource src{d_sample_z, d_sample_nhi, d_base_inds, 1, (long)nhi_stride, base_levels, nullptr, nullptr,
                            0, 0, 0, (long)s_begin, (long)S_total};
     return launch_sweep(batch->group, s_count, level + 1, src, d_out, static_cast<hipStream_t>(stream));
-}
+} DLAGP_CATCH_INT("dlagp_batch_level_eval_device")
 
 int dlagp_sweep_state_init_device(int nb, int64_t S, int max_dlas, double *d_sample_ll, double *d_evidences,
-                                  int32_t *d_base_inds, int32_t *d_flags, int device, void *stream_) {
+                                  int32_t *d_base_inds, int32_t *d_flags, int device, void *stream_) try {
     if (nb <= 0 || S <= 0 || max_dlas < 1 || max_dlas > DLAGP_MAX_ABSORBERS) return fail(DLAGP_EINVAL, "bad shape");
     if (!d_sample_ll || !d_evidences || !d_flags || (max_dlas > 1 && !d_base_inds)) return fail(DLAGP_EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(device));
@@ -2006,12 +2108,12 @@ int dlagp_sweep_state_init_device(int nb, int64_t S, int max_dlas, double *d_sam
                            d_base_inds, n_base, 0);
     HIP_TRY(hipGetLastError());
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_sweep_state_init_device")
 
 int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const double *d_ll, const double *d_sample_z,
                               double min_z_separation, const double *d_uniforms, double *d_sample_ll,
                               double *d_evidences, int32_t *d_base_inds, double *d_cdf_scratch, int32_t *d_flags,
-                              int device, void *stream) {
+                              int device, void *stream) try {
     if (nb <= 0 || S <= 0 || level < 0 || level >= max_dlas || max_dlas > DLAGP_MAX_ABSORBERS)
         return fail(DLAGP_EINVAL, "bad shape");
     if (!d_ll || !d_sample_z || !d_sample_ll || !d_evidences || !d_cdf_scratch || !d_flags ||
@@ -2023,10 +2125,10 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
     return launch_level_finish(nb, static_cast<hipStream_t>(stream), d_ll, (long)S, level, max_dlas, src,
                                min_z_separation, d_uniforms, d_sample_ll, d_evidences, d_base_inds, d_cdf_scratch, d_flags,
                                d_flags + nb + 1, d_flags + nb);
-}
+} DLAGP_CATCH_INT("dlagp_level_finish_device")
 
 int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, const uint8_t *d_too_close,
-                                double *d_evidence, int device, void *stream) {
+                                double *d_evidence, int device, void *stream) try {
     if (!d_ll || !d_evidence) return fail(DLAGP_EINVAL, "NULL argument");
     if (nb <= 0 || S <= 0 || level < 0) return fail(DLAGP_EINVAL, "need nb > 0, S > 0, level >= 0");
     HIP_TRY(hipSetDevice(device));
@@ -2035,9 +2137,9 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
                        std::log((double)S));
     HIP_TRY(hipGetLastError());
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_level_evidence_device")
 
-int dlagp_debug_voigt(int form, int line, int64_t n, const double *velocity, double *out, int device) {
+int dlagp_debug_voigt(int form, int line, int64_t n, const double *velocity, double *out, int device) try {
     if (!velocity || !out || n < 0) return fail(DLAGP_EINVAL, "bad argument");
     if (form < 0 || form > 1) return fail(DLAGP_EINVAL, "form must be 0 (generic kernels) or 1 (MFMA kernel)");
     if (line < 0 || line >= DLAGP_MAX_LINES) return fail(DLAGP_EINVAL, "line %d outside [0, %d)", line, DLAGP_MAX_LINES);
@@ -2060,9 +2162,9 @@ int dlagp_debug_voigt(int form, int line, int64_t n, const double *velocity, dou
     d_out.release();
     if (err != hipSuccess) return fail(DLAGP_EDEVICE, "dlagp_debug_voigt failed: %s", hipGetErrorString(err));
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_debug_voigt")
 
-int dlagp_debug_read(uint64_t *out, int n, int reset) {
+int dlagp_debug_read(uint64_t *out, int n, int reset) try {
 #ifdef DLAGP_TRACE_BUILD
     if (n > 8) {  // diagnostic build: the per-item trace of the last launches (kernels_mfma.h)
         std::vector<unsigned long long> trace(4 * 8192);
@@ -2080,9 +2182,9 @@ int dlagp_debug_read(uint64_t *out, int n, int reset) {
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(DLAGP_STAMPS), zero, sizeof(zero)));
     }
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_debug_read")
 
-int dlagp_set_option(const char *name, int64_t value) {
+int dlagp_set_option(const char *name, int64_t value) try {
     if (!name) return fail(DLAGP_EINVAL, "option name is NULL");
     if (!strcmp(name, "pixel_splits")) g_opt_pixel_splits = value;
     else if (!strcmp(name, "path")) g_opt_path = value;
@@ -2114,28 +2216,29 @@ int dlagp_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "shared_rows")) g_opt_shared_rows = value != 0;
     else if (!strcmp(name, "negative_noise_mfma")) g_opt_negative_noise_mfma = value != 0;
     else if (!strcmp(name, "finalize_wave")) g_opt_finalize_wave = value != 0;
+    else if (!strcmp(name, "fuse_finalize")) g_opt_fuse_finalize = value != 0;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_set_option")
 
-int dlagp_plan_cut(int64_t groups, double chunks, int64_t forced_splits, int *full, double *frac) {
+int dlagp_plan_cut(int64_t groups, double chunks, int64_t forced_splits, int *full, double *frac) try {
     if (!full || !frac || groups < 1 || !(chunks >= 1.0)) return fail(DLAGP_EINVAL, "bad argument");
     plan::Options opt = planner_options();
     opt.pixel_splits = forced_splits;
     plan::choose_cut((long)groups, chunks, opt, full, frac);
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_plan_cut")
 
 int dlagp_plan_debug(int nb, const int *n_u, const uint8_t *const *keep, int ntaps, int64_t S, const int64_t *options,
                      int64_t *summary, int32_t *slot_pixel, int32_t *slot_pos, int64_t slots_cap, int32_t *passes,
-                     int64_t passes_cap, int32_t *items, int64_t items_cap, uint8_t *counts, int64_t counts_cap) {
+                     int64_t passes_cap, int32_t *items, int64_t items_cap, uint8_t *counts, int64_t counts_cap) try {
     std::string err;
     const int rc = plan::debug(nb, n_u, keep, ntaps, S, options, summary, slot_pixel, slot_pos, slots_cap, passes,
                                passes_cap, items, items_cap, counts, counts_cap, err);
     return rc ? fail(rc, "%s", err.c_str()) : DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_plan_debug")
 
-int dlagp_get_option(const char *name, int64_t *value) {
+int dlagp_get_option(const char *name, int64_t *value) try {
     if (!name || !value) return fail(DLAGP_EINVAL, "NULL argument");
     if (!strcmp(name, "pixel_splits")) *value = g_opt_pixel_splits;
     else if (!strcmp(name, "path")) *value = g_opt_path;
@@ -2156,6 +2259,8 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "shared_rows")) *value = g_opt_shared_rows;
     else if (!strcmp(name, "negative_noise_mfma")) *value = g_opt_negative_noise_mfma;
     else if (!strcmp(name, "finalize_wave")) *value = g_opt_finalize_wave;
+    else if (!strcmp(name, "fuse_finalize")) *value = g_opt_fuse_finalize;
+    else if (!strcmp(name, "last_launch_fused")) *value = g_last_launch_fused;
     else if (!strcmp(name, "big_allocs")) *value = g_stat_big_allocs;
     else if (!strcmp(name, "big_frees")) *value = g_stat_big_frees;
     else if (!strcmp(name, "last_launch_path")) *value = g_last_launch_path;
@@ -2166,9 +2271,9 @@ int dlagp_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "last_launch_groups")) *value = g_last_launch_groups;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_get_option")
 
-int dlagp_timing_read(double *total_ms, int64_t *launches, int reset) {
+int dlagp_timing_read(double *total_ms, int64_t *launches, int reset) try {
     std::lock_guard<std::mutex> lock(g_timing_mutex);
     double total = 0.0;
     int64_t counted = 0;
@@ -2193,6 +2298,6 @@ int dlagp_timing_read(double *total_ms, int64_t *launches, int reset) {
         g_timing_events.clear();
     }
     return DLAGP_OK;
-}
+} DLAGP_CATCH_INT("dlagp_timing_read")
 
 }  // extern "C"

@@ -505,6 +505,76 @@ __host__ __device__ __forceinline__ int native_tile_offset(int tile, int sample,
     return ((tile * 2 + (r >> 1)) * 64 + ((sample & 3) << 4) + cc) * 2 + (r & 1);
 }
 
+// Factorisation + forward solve of ONE sample's B = I + sum_p w_p M_p M_p' (null_gp.py:339-356) by the SIXTEEN lanes of a
+// DPP row: the body of finalize_rank20<ROW16 = true, ..>, shared with the accumulate kernel's own finalisation of
+// single-piece blocks (kernels_mfma.h, FUSED).  `col`: the sample's staged columns in LDS, column c at col[c * LS] --
+// c < 210: vech(B - I); 210..229: u; 230: sum r^2/d; 231: sum log d.  Lane q of the row holds row q of the matrix (and,
+// q <= 4, row 16 + q; u rides along as row 20, so its row of the factor is t = L^-1 u).  Returns log p in lane q == 4 of
+// the row (other lanes: scratch); `bad`: a pivot was not positive (B not positive definite).  Every entry sees the same
+// operations in the same order wherever this is called from: the two finalisations agree bit for bit.
+template <int LS>
+__device__ __forceinline__ double factor_solve_row16(const double *col, int q, double n_log_2pi, bool &bad) {
+    constexpr int K = DLAGP_FIN_K;
+    constexpr int NC = DLAGP_FIN_COLS;
+        double A0[16], A1[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            // row i < 20: vech(B - I) entry (i, k), the identity added on the diagonal (null_gp.py:341); row 20: u; columns
+            // beyond the row and rows 21..31 start at zero.  Branch-free: a clamped, always valid address and a select.
+            if (k < 16) {
+                const int kc = k < q ? k : q;
+                double v = col[(q * (q + 1) / 2 + kc) * LS];
+                v = k <= q ? v : 0.0;
+                if (k == q) v += 1.0;
+                A0[k] = v;
+            }
+            const int i = 16 + q, ic = i < K ? i : K;
+            const int kc = ic < K ? (k < ic ? k : ic) : k;
+            double v = col[(ic < K ? ic * (ic + 1) / 2 + kc : NC + k) * LS];
+            v = (i < K ? k <= i : i == K) ? v : 0.0;
+            if (k == i) v += 1.0;
+            A1[k] = v;
+        }
+        LogProduct pivots;
+        auto row_bcast = [](double v, auto lane_c) __attribute__((always_inline)) {
+            constexpr int ctrl = 0x150 + decltype(lane_c)::value;  // DPP row_newbcast: lane L of every row of 16 lanes
+            // every lane is written (full row and bank masks): the "old" operand is never kept, so hand in the source
+            const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), ctrl, 0xf, 0xf, false);
+            const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), ctrl, 0xf, 0xf, false);
+            return __hiloint2double(hi, lo);
+        };
+        // fully unrolled: every register index and DPP control below is a compile-time constant
+        auto column = [&](auto j_c) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_c)::value;
+            double s;
+            if constexpr (j < 16) s = row_bcast(A0[j], std::integral_constant<int, j>{});
+            else s = row_bcast(A1[j], std::integral_constant<int, j - 16>{});
+            if (s <= 0.0) bad = true;  // NaN pivots propagate silently, as LAPACK's do
+            pivots.multiply(s);        // log det B = sum log L_ii^2
+            const double inv = fast_rsqrt(s);
+            if constexpr (j < 16) A0[j] *= inv;  // rows > j: L_ij (row j itself and the rows above it: scratch)
+            A1[j] *= inv;
+            auto update = [&](auto k_c) __attribute__((always_inline)) {
+                constexpr int k = decltype(k_c)::value;
+                double lkj;
+                if constexpr (k < 16) lkj = row_bcast(A0[j], std::integral_constant<int, k>{});
+                else lkj = row_bcast(A1[j], std::integral_constant<int, k - 16>{});
+                if constexpr (k < 16) A0[k] = fma(-A0[j], lkj, A0[k]);
+                A1[k] = fma(-A1[j], lkj, A1[k]);
+            };
+            static_for<j + 1, K>(update);
+            __builtin_amdgcn_sched_barrier(0);  // columns in program order (the scheduler otherwise interleaves several)
+        };
+        static_for<0, K>(column);
+        double tt = 0.0;
+#pragma unroll
+        for (int m = 0; m < K; ++m) tt = fma(A1[m], A1[m], tt);
+        const double sum_r2 = col[(NC + K) * LS];
+        const double sum_logd = col[(NC + K + 1) * LS];
+        double result = -0.5 * ((sum_r2 - tt) + (sum_logd + pivots.log_value()) + n_log_2pi);
+        return result;
+}
+
 // Ranks above 20 on the MFMA path.  Column group g of a (piece, block) leaves its sums in the native layout above, at
 // piece index g nparts + piece of a buffer of DLAGP_MFMA_ROW_WIDTH-wide rows.  This kernel adds a block's pieces in piece
 // order and sorts the groups' columns into ONE column-major row of the sightline's own width -- the generic kernel's
@@ -690,65 +760,9 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     // the diagonal and rows 21..31 are scratch: updated like everything else, never read by a real entry.
         const int smp = tid >> 4, q = tid & 15;
         const double *col = fin_lds + smp;
-        double A0[16], A1[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            // row i < 20: vech(B - I) entry (i, k), the identity added on the diagonal (null_gp.py:341); row 20: u; columns
-            // beyond the row and rows 21..31 start at zero.  Branch-free: a clamped, always valid address and a select.
-            if (k < 16) {
-                const int kc = k < q ? k : q;
-                double v = col[(q * (q + 1) / 2 + kc) * LS];
-                v = k <= q ? v : 0.0;
-                if (k == q) v += 1.0;
-                A0[k] = v;
-            }
-            const int i = 16 + q, ic = i < K ? i : K;
-            const int kc = ic < K ? (k < ic ? k : ic) : k;
-            double v = col[(ic < K ? ic * (ic + 1) / 2 + kc : NC + k) * LS];
-            v = (i < K ? k <= i : i == K) ? v : 0.0;
-            if (k == i) v += 1.0;
-            A1[k] = v;
-        }
-        LogProduct pivots;
         bool bad = false;
-        auto row_bcast = [](double v, auto lane_c) __attribute__((always_inline)) {
-            constexpr int ctrl = 0x150 + decltype(lane_c)::value;  // DPP row_newbcast: lane L of every row of 16 lanes
-            // every lane is written (full row and bank masks): the "old" operand is never kept, so hand in the source
-            const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), ctrl, 0xf, 0xf, false);
-            const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), ctrl, 0xf, 0xf, false);
-            return __hiloint2double(hi, lo);
-        };
-        // fully unrolled: every register index and DPP control below is a compile-time constant
-        auto column = [&](auto j_c) __attribute__((always_inline)) {
-            constexpr int j = decltype(j_c)::value;
-            double s;
-            if constexpr (j < 16) s = row_bcast(A0[j], std::integral_constant<int, j>{});
-            else s = row_bcast(A1[j], std::integral_constant<int, j - 16>{});
-            if (s <= 0.0) bad = true;  // NaN pivots propagate silently, as LAPACK's do
-            pivots.multiply(s);        // log det B = sum log L_ii^2
-            const double inv = fast_rsqrt(s);
-            if constexpr (j < 16) A0[j] *= inv;  // rows > j: L_ij (row j itself and the rows above it: scratch)
-            A1[j] *= inv;
-            auto update = [&](auto k_c) __attribute__((always_inline)) {
-                constexpr int k = decltype(k_c)::value;
-                double lkj;
-                if constexpr (k < 16) lkj = row_bcast(A0[j], std::integral_constant<int, k>{});
-                else lkj = row_bcast(A1[j], std::integral_constant<int, k - 16>{});
-                if constexpr (k < 16) A0[k] = fma(-A0[j], lkj, A0[k]);
-                A1[k] = fma(-A1[j], lkj, A1[k]);
-            };
-            static_for<j + 1, K>(update);
-            __builtin_amdgcn_sched_barrier(0);  // columns in program order (the scheduler otherwise interleaves several)
-        };
-        static_for<0, K>(column);
+        double result = factor_solve_row16<LS>(col, q, col[(NC + K + 2) * LS], bad);
         if (q != 4 || smp >= valid) return;  // row 20 = t sits in lane 4; samples beyond S hold unwritten partials
-        double tt = 0.0;
-#pragma unroll
-        for (int m = 0; m < K; ++m) tt = fma(A1[m], A1[m], tt);
-        const double sum_r2 = col[(NC + K) * LS];
-        const double sum_logd = col[(NC + K + 1) * LS];
-        const double n_log_2pi = col[(NC + K + 2) * LS];
-        double result = -0.5 * ((sum_r2 - tt) + (sum_logd + pivots.log_value()) + n_log_2pi);
         if (bad) {
             result = __builtin_nan("");
             atomicOr(status, 1);

@@ -247,11 +247,16 @@ __device__ __forceinline__ void lds_wave_sync() {
 // by stepping ulps around limit (1 + z), so that the in-loop test `lambda >= T` reproduces the reference's
 // `rest_wavelengths > lambda_Lyman_limit` (:280) exactly without a division per entry.
 //
-template <int LINES, bool BROADEN, bool STAMPS, int MODE, int PATCH, bool LLS>
+// FUSED (launch plans with ONE piece per block: batches of sightlines): the wave also finishes its block -- the
+// factorisation, solve and log-density of finalize_rank20 -- and writes log p to `out`; its partial sums never leave the
+// chip.  A block's sums are 33 KB: written and read back by a second kernel they are 676 MB per level of a batch of 32
+// (2.9 TB/s, HBM-bound, 235 us) -- 2.6 % of a level at n = 3000 pixels but 10 % at the 685 of a median DR12Q sightline and
+// 19 % at 300 (profiles/r05_frac_vs_n.json).  See the epilogue.
+template <int LINES, bool BROADEN, bool STAMPS, int MODE, int PATCH, bool LLS, bool FUSED>
 __device__ __forceinline__ void accumulate_mfma_body(
     const SightlineDev *__restrict__ sightlines, const PassDesc *__restrict__ passes,
     const WorkItem *__restrict__ items, int nb, long S, int kd,
-    SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags) {
+    SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags, double *__restrict__ out) {
     constexpr bool CACHED = MODE == 2;
     constexpr int NPOOL = 16;  // distinct cached rows a wave holds per pass (cached levels)
     // Pixel slots a pass holds.  Voigt passes: 7 chunks, what a 64-entry profile window covers behind the 7-tap
@@ -260,8 +265,11 @@ __device__ __forceinline__ void accumulate_mfma_body(
     // sums stay bit-identical to the recomputing kernel's -- in 1/8 fewer passes).
     constexpr int PASS_CHUNKS = CACHED ? DLAGP_CACHED_PASS_CHUNKS : DLAGP_MAX_PASS_CHUNKS;
     constexpr int A_STRIDE = 4 * PASS_CHUNKS * DLAGP_CHUNK_STEPS + 2;  // 58 (66 cached): stride/2 odd -> conflict-free b64 reads
-    __shared__ double raw[16 * DLAGP_RAW_STRIDE];
-    __shared__ double a_lds[16 * A_STRIDE];
+    // one array: the wave's own finalisation (FUSED) stages its block's sums over both
+    __shared__ double wave_lds[16 * DLAGP_RAW_STRIDE + 16 * A_STRIDE] __attribute__((aligned(16)));
+    double *const raw = wave_lds;
+    double *const a_lds = wave_lds + 16 * DLAGP_RAW_STRIDE;
+    static_assert((16 * DLAGP_RAW_STRIDE) % 2 == 0, "a_lds[] is read and filled 16 bytes at a time");
     __shared__ int pos_lds[64];
     constexpr int NPAIR_MAX = PATCH ? 48 : 1;  // (sample, line) pairs of a wave and absorber
     constexpr int NCAND = 7;                   // candidate entries per pair, see below
@@ -276,7 +284,8 @@ __device__ __forceinline__ void accumulate_mfma_body(
     typedef double v4d_a16 __attribute__((ext_vector_type(4), aligned(16)));
 
     // finalize raises it; a later launch of a heterogeneous batch's level leaves the flag of the earlier ones alone
-    if (blockIdx.x == 0 && threadIdx.x == 0 && !(launch_flags & DLAGP_LAUNCH_KEEP_STATUS)) *status = 0;
+    // (FUSED: the waves of this launch raise it themselves, so the host clears it in front of the launch)
+    if (!FUSED && blockIdx.x == 0 && threadIdx.x == 0 && !(launch_flags & DLAGP_LAUNCH_KEEP_STATUS)) *status = 0;
 #ifdef DLAGP_TRACE_BUILD
     const unsigned long long trace_start = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -659,8 +668,14 @@ __device__ __forceinline__ void accumulate_mfma_body(
             // bit-identical.
             if (stamps) t_mark = stamp_now();
             double *pool_lds = raw;  // [NPOOL][64]; raw[] is otherwise unused on the cached levels
-            // the rows have landed in LDS; the ten operand loads of the step that followed them stay in flight
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            // the rows have landed in LDS; the operand loads of the step that followed them -- two record loads and NPAIR
+            // tile pairs, issued behind the rows both in front of the pass loop and in the last step of every pass
+            // (DLAGP_STEP_BODY with FETCH) -- stay in flight.  The count is tied to the step body's loads here: a step
+            // that fetched more (or fewer) would make the products read a_lds[] and the pool before the DMA has landed.
+            constexpr int kOperandLoadsPerStep = 2 + NPAIR;
+            static_assert(kOperandLoadsPerStep == 10 && NPAIR == DLAGP_MFMA_PAIRS,
+                          "the step body issues 2 record loads + NPAIR operand loads: keep this wait count in step with it");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOperandLoadsPerStep) : "memory");
             __builtin_amdgcn_wave_barrier();
             // the lane part of the LDS addresses is made opaque per pass, or the compiler keeps all (slot, lane) addresses
             // in registers across the pass loop (44 spills)
@@ -1072,6 +1087,53 @@ __device__ __forceinline__ void accumulate_mfma_body(
     // first and left in 56 stores of 8 bytes per lane.
     // a (piece, block) of partial sums is DLAGP_MFMA_ROW_WIDTH x 16 doubles whatever the rank (= row_width at rank 20);
     // column group g's pieces follow those of group g - 1: [group][piece][block]
+    if constexpr (FUSED) {
+        // ---------------- epilogue (FUSED): this wave finishes its own block ----------------
+        // Four rounds of four samples: round r is component r of every accumulator tile (the MFMA's D layout: lane holds
+        // column lane & 15 of sample 4 r + (lane >> 4)), staged into LDS as [column][sample of the round] -- 233 columns x
+        // stride 5 over raw[] / a_lds[], which nothing reads any more -- and factored by the SIXTEEN lanes of each DPP row
+        // exactly as finalize_rank20<ROW16> factors it (factor_solve_row16: the same operations in the same order, and a
+        // single piece has nothing to add up -- bit-identical to the two-kernel form, tests/test_gpu_parity.py).
+        constexpr int FLS = 5, NC = DLAGP_FIN_COLS, K = DLAGP_FIN_K;
+        static_assert(DLAGP_FIN_STAGED * FLS <= 16 * DLAGP_RAW_STRIDE + 16 * A_STRIDE, "the staged block must fit the wave's LDS");
+        static_assert(K == DLAGP_MFMA_RANK && NC == DLAGP_MFMA_SMALL_W_COL + 2, "column layout of the rank-20 tiles");
+        double logd = dprod.log_value();
+        sum_r2 += __shfl_xor(sum_r2, 16);
+        sum_r2 += __shfl_xor(sum_r2, 32);
+        logd += __shfl_xor(logd, 16);
+        logd += __shfl_xor(logd, 32);
+        const double n_log_2pi = sl.n * DLAGP_LOG_2PI;
+        double *const fin = wave_lds;
+        static_for<0, 4>([&](auto r_c) __attribute__((always_inline)) {
+            constexpr int r = decltype(r_c)::value;
+            double *const mine = fin + slot;  // sample 4 r + slot of the block; slot = lane >> 4
+#pragma unroll
+            for (int t = 0; t < DLAGP_MFMA_NT; ++t)
+                mine[((t < DLAGP_MFMA_NTW ? 16 * t : NC) + s_loc) * FLS] = acc[t][r];  // tile 13: u 0..15
+            // 4x4x4 outputs: lane = row * 16 + block * 4 + column  ->  sample = block * 4 + row; this round is block r
+            if (((lane >> 2) & 3) == r) {
+                const int j = lane & 3;
+                if (j < 2) mine[(DLAGP_MFMA_SMALL_W_COL + j) * FLS] = acc_sw;  // vech columns 208, 209
+                mine[(NC + DLAGP_MFMA_SMALL_Q_COL + j) * FLS] = acc_sq;          // u 16..19
+            }
+            if (slot == 0 && (s_loc >> 2) == r) {  // after the shuffles every lane of sample s_loc holds its totals
+                fin[(NC + K) * FLS + (s_loc & 3)] = sum_r2;
+                fin[(NC + K + 1) * FLS + (s_loc & 3)] = logd;
+            }
+            lds_wave_sync();
+            bool bad = false;
+            double result = factor_solve_row16<FLS>(mine, s_loc, n_log_2pi, bad);
+            const long smp = sample0 + 4 * r + slot;
+            if (s_loc == 4 && smp < S) {  // row 20 = t sits in lane 4 of the row
+                if (bad) {
+                    result = __builtin_nan("");
+                    atomicOr(status, 1);
+                }
+                out[gb * S + smp] = result;
+            }
+            lds_wave_sync();  // the next round's staging overwrites what this one read
+        });
+    } else {
     const int rw = DLAGP_MFMA_ROW_WIDTH;
     const long rows_left = S - sample0;  // valid samples of this wave
     const long ngroups = (S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
@@ -1104,6 +1166,7 @@ __device__ __forceinline__ void accumulate_mfma_body(
         base[DLAGP_NATIVE_EXTRAS + 7 * 16 + s_loc] = logd;
         base[DLAGP_NATIVE_EXTRAS + 8 * 16 + s_loc] = split == 0 ? sl.n * DLAGP_LOG_2PI : 0.0;
     }
+    }
 #ifdef DLAGP_TRACE_BUILD
     if (threadIdx.x == 0 && blockIdx.x < 8192) {
         unsigned hw_id, xcc_id;
@@ -1129,12 +1192,13 @@ __device__ __forceinline__ void accumulate_mfma_body(
 }
 
 // The kernel: one wave per work item, see accumulate_mfma_body.
-template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, int PATCH = 0, bool LLS = false>
+template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, int PATCH = 0, bool LLS = false, bool FUSED = false>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *__restrict__ passes,
     const WorkItem *__restrict__ items, int nb, long S, int kd,
-    SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags) {
-    accumulate_mfma_body<LINES, BROADEN, STAMPS, MODE, PATCH, LLS>(sightlines, passes, items, nb, S, kd, src, part, status, launch_flags);
+    SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags, double *__restrict__ out) {
+    accumulate_mfma_body<LINES, BROADEN, STAMPS, MODE, PATCH, LLS, FUSED>(sightlines, passes, items, nb, S, kd, src, part, status,
+                                                                         launch_flags, out);
 }
 
 // Diagnostic (dlagp_debug_voigt): the Voigt profile V(v; sigma, gamma_l) = Re w((v + i gamma_l)/(sqrt2 sigma)) /

@@ -390,6 +390,12 @@ class DeviceBatch:
         return (nulls, (sub_ev, sub_ll.transpose(0, 2, 1), np.zeros((nb, 0, S), dtype=np.int32)),
                 (evidences, sample_ll.transpose(0, 2, 1), base))
 
+    def model_evidences_cancel(self) -> None:
+        """give up a `model_evidences_start` that will not be finished (the caller's own work in between raised)"""
+        self._pending = None
+        if getattr(self, "_handle", None):
+            _lib.check(_lib.load().dlagp_batch_model_evidences_cancel(self._handle))
+
     def sweep_device(self, S: int, max_dlas: int, d_sample_z: int, d_sample_nhi: int, nhi_stride: int,
                      min_z_separation: float, d_uniforms: int, d_evidences: int, d_sample_ll: int, d_base_inds: int,
                      stream: int = 0) -> None:

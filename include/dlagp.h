@@ -25,7 +25,10 @@
  * Conventions
  *   - all floating point is IEEE-754 float64; `keep` is one byte per pixel (0/1)
  *   - every function returns 0 on success, a negative DLAGP_E* code on failure; the message is
- *     available from dlagp_last_error() (thread-local).  Nothing aborts the process.
+ *     available from dlagp_last_error() (thread-local).  Nothing aborts the process: every entry
+ *     point is an exception barrier -- a C++ exception raised inside the library (std::bad_alloc,
+ *     std::length_error, anything else) comes back as DLAGP_ENOMEM / DLAGP_EINVAL, never as an
+ *     unwinding into the caller's frames (ctypes, cgo, JNI).
  *   - the caller owns all host buffers; the library copies what it needs to the device in
  *     dlagp_create and owns that device memory until dlagp_destroy.
  *   - a context is not thread-safe; use one per (sightline, host thread).
@@ -45,6 +48,7 @@ extern "C" {
 #define DLAGP_EINVAL (-1)  /* bad argument (shape, NULL pointer, unsupported size)          */
 #define DLAGP_EDEVICE (-2) /* no GPU, HIP runtime error, out of device memory               */
 #define DLAGP_ELINALG (-3) /* B = I + M' D^-1 M not positive definite (numpy LinAlgError)   */
+#define DLAGP_ENOMEM (-4)  /* out of HOST memory / a size the host cannot address (ABI >= 2)  */
 
 #define DLAGP_MAX_ABSORBERS 8 /* absorbers per sample (the reference sweeps 1..4)            */
 #define DLAGP_MAX_RANK 64     /* largest k of the low-rank factor                            */
@@ -72,7 +76,7 @@ typedef struct dlagp_ctx dlagp_ctx;     /* one sightline's model + data, residen
 typedef struct dlagp_batch dlagp_batch; /* a launch group of sightlines on one device       */
 typedef struct dlagp_model dlagp_model; /* the learned GP model (rest-frame grid), in HBM   */
 
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature or status-code change.  2: DLAGP_ENOMEM. */
 int dlagp_abi_version(void);
 
 /* Number of visible HIP devices (0 if none / runtime unusable). */
@@ -248,13 +252,16 @@ int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, con
  * _start uploads the samples and enqueues the sub-DLA sweep, which needs no random numbers, and returns at once; _finish
  * takes the uniforms and the output arrays, enqueues the occupation sweep and the null evidences, waits and copies back.
  * _start followed by _finish IS dlagp_batch_model_evidences (bit for bit).  Both from the same host thread; the batch
- * must not be used in between; a _start that is never finished is drained by the batch's next call. */
+ * must not be used in between: ANY other call on the batch between the two -- or dlagp_batch_model_evidences_cancel --
+ * ends the pending call (its kernels drain), and a later _finish returns DLAGP_EINVAL. */
 int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dlas, const double *sub_sample_z,
                                       const double *sub_sample_nhi, int64_t sub_nhi_stride, const double *sample_z,
                                       const double *sample_nhi, int64_t nhi_stride, double min_z_separation);
 int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniforms, double *null_evidences,
                                        double *sub_evidences, double *sub_sample_ll, double *evidences, double *sample_ll,
                                        int32_t *base_inds);
+/* gives up a _start that will not be finished (the caller's own work in between failed); a no-op without one */
+int dlagp_batch_model_evidences_cancel(dlagp_batch *batch);
 
 /*
  * Level evidence on the device (reference dla_gp.py:155-190), for sweeps whose results stay in HBM.

@@ -26,7 +26,7 @@ def test_header_and_binding_agree():
 
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(_lib.LIB_PATH), "build with `make -C gpy_dla_detection_amd/csrc`"
-    assert _lib.load().dlagp_abi_version() == 1  # first: it maps the one HIP runtime this process is to have
+    assert _lib.load().dlagp_abi_version() == 2  # first: it maps the one HIP runtime this process is to have
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
@@ -61,6 +61,43 @@ def test_argument_errors_do_not_need_a_gpu():
         _lib.check(_lib.DLAGP_ELINALG)
     with pytest.raises(RuntimeError):
         _lib.check(_lib.DLAGP_EDEVICE)
+
+
+def test_cpp_exceptions_come_back_as_status_codes():
+    """
+    include/dlagp.h: "Nothing aborts the process".  Every exported function is an exception barrier
+    (dlagp_hip.hip exception_status): a std::bad_alloc raised inside the library must come back through ctypes as
+    DLAGP_ENOMEM with a message, not unwind into the caller and end in std::terminate.  Forced here without a GPU and
+    without touching memory: the planner is asked for the piece counts of 2^58 blocks of samples (one vector of 2^58
+    bytes, which no allocator grants).  In a child process, so that a missing barrier reads as a failed test.
+    """
+    import subprocess
+    import sys
+
+    code = """
+import ctypes, numpy as np
+from gpy_dla_detection_amd import _lib
+lib = _lib.load()
+keep = np.ones(64, dtype=np.uint8)
+n_u = (ctypes.c_int * 1)(64)
+keeps = (ctypes.POINTER(ctypes.c_ubyte) * 1)(keep.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+summary = (ctypes.c_int64 * 8)()
+rc = lib.dlagp_plan_debug(1, n_u, keeps, 7, 2 ** 62, None, summary, None, None, 0, None, 0, None, 0, None, 0)
+print(rc, _lib.last_error())
+try:
+    _lib.check(rc)
+except MemoryError as exc:
+    print("MemoryError")
+# the library is still usable afterwards
+rc = lib.dlagp_plan_debug(1, n_u, keeps, 7, 100, None, summary, None, None, 0, None, 0, None, 0, None, 0)
+print(rc, summary[2])
+"""
+    res = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, (res.returncode, res.stderr[-2000:])
+    lines = res.stdout.strip().splitlines()
+    assert lines[0].startswith("%d " % _lib.DLAGP_ENOMEM) and "dlagp_plan_debug" in lines[0] and "memory" in lines[0], lines
+    assert lines[1] == "MemoryError"
+    assert lines[2].split()[0] == "0" and int(lines[2].split()[1]) >= 7
 
 
 def test_one_hip_runtime_per_process_whatever_the_import_order():

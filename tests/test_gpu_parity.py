@@ -784,6 +784,7 @@ def restore_options():
     set_option("shared_rows", 1)
     set_option("negative_noise_mfma", 0)
     set_option("finalize_wave", 1)
+    set_option("fuse_finalize", 1)
 
 
 @pytest.mark.parametrize("shape", [dict(index=4, n_unmasked=1250, n_masked=28, k=20),
@@ -2203,6 +2204,90 @@ def test_both_finalisations_give_the_same_numbers(restore_options):
                 neg.eval(z[:64], nhi[:64])
         finally:
             set_option("finalize_row16_blocks", default)
+
+
+def test_accumulate_waves_finish_their_own_blocks_bit_for_bit(restore_options):
+    """
+    Launch plans with ONE piece per block (batches: more blocks than wave slots; any launch with pixel_splits = 1): the
+    accumulate wave factors its own block (kernels_mfma.h FUSED) and no partial sums cross HBM.  The same operations in
+    the same order as finalize_rank20's 16-lane form (one shared routine), and a single piece has nothing to add up: the
+    results equal the two-kernel form's BIT FOR BIT -- one absorber, several absorbers per sample, every level of a
+    cached and of a recomputed sweep (base indices and evidences with them), S not a multiple of 16, ragged sightlines,
+    a by-sample slice -- and the non-PD flag is raised by the wave itself.
+    """
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch, DeviceSightline, get_option, set_option
+
+    sights = [make_sightline(60, n_unmasked=685, n_masked=14), make_sightline(61, n_unmasked=300, n_masked=6),
+              make_sightline(62, n_unmasked=1250, n_masked=25), make_sightline(63, n_unmasked=58, n_masked=1)]
+    devs = [device_sightline(s) for s in sights]
+    batch = DeviceBatch(devs)
+    S, max_dlas = 1003, 4
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    uniforms = parallel.resampling_uniforms(len(sights), max_dlas, S, seed=9)
+    z3 = np.stack([zs, zs[:, ::-1], np.roll(zs, 7, axis=1)], axis=2)
+    n3 = np.stack([np.broadcast_to(nhi, zs.shape), np.broadcast_to(nhi[::-1], zs.shape), np.broadcast_to(np.roll(nhi, 7), zs.shape)], axis=2)
+    set_option("pixel_splits", 1)  # one piece per block whatever the launch's size
+
+    def everything():
+        out = {"one": batch.eval(zs, np.broadcast_to(nhi, zs.shape)), "three": batch.eval(z3, n3)}
+        fused = [get_option("last_launch_fused")]
+        for cache in (1, 0):
+            set_option("profile_cache", cache)
+            ev, ll, base = batch.sweep(zs, nhi, max_dlas, 0.002, uniforms)
+            fused.append(get_option("last_launch_fused"))
+            out["sweep%d" % cache] = (ev, np.array(ll), base)
+        set_option("profile_cache", 1)
+        out["single"] = devs[0].eval(zs[0], nhi)
+        return out, fused
+
+    set_option("fuse_finalize", 1)
+    got, fused = everything()
+    assert fused == [1, 1, 1]
+    set_option("fuse_finalize", 0)
+    want, unfused = everything()
+    assert unfused == [0, 0, 0]
+    set_option("fuse_finalize", 1)
+    for key in want:
+        if isinstance(want[key], tuple):
+            for a, b in zip(got[key], want[key]):
+                np.testing.assert_array_equal(a, b, err_msg=key)
+        else:
+            np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+    # the fused numbers against the oracle, directly
+    from oracle import ref_like as R
+
+    for b in (0, 3):
+        st = oracle_state(sights[b])
+        for i in (0, 500, S - 1):
+            want_ll = R.sample_log_likelihood_k_dlas(st, z3[b, i], n3[b, i])
+            assert abs(got["three"][b, i] - want_ll) <= RTOL_LL * abs(want_ll)
+    # automatic plans: a launch with more blocks than wave slots is single-piece and fused, a small one is not
+    set_option("pixel_splits", 0)
+    big = 9000
+    zb = np.stack([make_qmc_samples(s, big)[0] for s in sights])
+    nb_ = make_qmc_samples(sights[0], big)[2]
+    first = batch.eval(zb, np.broadcast_to(nb_, zb.shape))
+    assert get_option("last_launch_parts") == 1 and get_option("last_launch_fused") == 1
+    devs[0].eval(zs[0], nhi)
+    assert get_option("last_launch_parts") > 1 and get_option("last_launch_fused") == 0
+    set_option("fuse_finalize", 0)
+    np.testing.assert_array_equal(first, batch.eval(zb, np.broadcast_to(nb_, zb.shape)))
+    set_option("fuse_finalize", 1)
+    # a matrix that is not positive definite: the wave raises the flag (LinAlgError, numpy's at null_gp.py:343)
+    set_option("negative_noise_mfma", 1)
+    neg = DeviceSightline(sights[0].y, sights[0].this_mu, 10.0 * sights[0].this_M, sights[0].this_omega2,
+                          -np.abs(sights[0].v), sights[0].padded_wavelengths, sights[0].keep)
+    set_option("negative_noise_mfma", 0)
+    set_option("pixel_splits", 1)
+    with pytest.raises(np.linalg.LinAlgError):
+        neg.eval(zs[0, :64], nhi[:64])
+    assert get_option("last_launch_fused") == 1
+    # ... and the next launch on a healthy sightline starts from a clear flag
+    np.testing.assert_array_equal(devs[0].eval(zs[0], nhi), got["single"])
+    neg.close()
+    batch.close()
 
 
 def test_long_sightline_and_concurrent_context_creation():

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""
+Efficiency of the accumulate kernels against the sightline length (round 5).
+
+Real DR12Q sightlines keep n <= 1250 pixels of the modelled window (reference set_parameters.py:33-34,58,
+null_gp.py:139-152; median ~685 for a DR12Q-like redshift spread), the bench's synthetic ones 3000.  For a batch of
+`--sightlines` (default 32) synthetic sightlines of n_u = `--pixels` unmasked pixels, S = 10 000 QMC points, ONE stream:
+
+  sub_dla      one-absorber sweep without the profile cache (the sub-DLA model / DLA(1) of configs 3 and 4)
+  level1       level 1 of a cached multi-level sweep (also stores the profiles)
+  cached       one deeper level of that sweep
+
+each as {ms per launch (HIP events on the launch's dispatch packet), evals per launch, frac of 78.6 TFLOP/s from
+F = n k (k + 1) + 2 n k per eval}, plus the wall time of a whole step (finalisation, level_finish included), the launch
+plan's shape and -- with --stamps -- the per-phase cycle stamps of the one-absorber kernel.
+
+    python3 tools/measure_frac_vs_n.py --pixels 685 [--sightlines 32] [--steps 5] [--stamps] [--option name=value ...]
+    rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 tools/measure_frac_vs_n.py --pixels 685
+
+Prints one JSON object.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from gpy_dla_detection_amd import parallel  # noqa: E402
+from gpy_dla_detection_amd import sightline as sl  # noqa: E402
+from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline  # noqa: E402
+
+PEAK = 78.6
+MIN_Z_SEPARATION = 3000.0e3 / 299792458.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pixels", type=int, default=685, help="unmasked pixels n_u of every sightline (2 %% of them masked)")
+    ap.add_argument("--spread", type=float, default=0.0,
+                    help="> 0: n_u drawn uniformly from [pixels (1 - spread), pixels (1 + spread)] per sightline")
+    ap.add_argument("--sightlines", type=int, default=32)
+    ap.add_argument("--samples", type=int, default=10000)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--stamps", action="store_true")
+    ap.add_argument("--option", action="append", default=[])
+    ap.add_argument("--no-cached", action="store_true", help="skip the multi-level sweeps")
+    args = ap.parse_args()
+
+    nb, S = args.sightlines, args.samples
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    sights = []
+    for i in range(nb):
+        n_u = args.pixels if args.spread <= 0 else int(round(args.pixels * (1 + args.spread * (2 * rng.random() - 1))))
+        sights.append(make_sightline(i, n_unmasked=n_u, n_masked=max(1, round(n_u * 61 / 3061)), k=20))
+    n_mean = float(np.mean([s.n for s in sights]))
+    flops = float(np.mean([s.n * 20 * 21 + 2 * s.n * 20 for s in sights]))
+    devs = [sl.DeviceSightline.from_state(s, device=0) for s in sights]
+    batch = sl.DeviceBatch(devs)
+    for item in args.option:
+        name, value = item.split("=")
+        sl.set_option(name, int(value))
+    f64 = dict(dtype=torch.float64, device=dev)
+    z = torch.from_numpy(np.stack([make_qmc_samples(s, S)[0] for s in sights])).to(dev)
+    nhi_dla = torch.from_numpy(make_qmc_samples(sights[0], S)[2]).to(dev)
+    nhi_sub = torch.from_numpy(make_qmc_samples(sights[0], S, sub_dla=True)[2]).to(dev)
+    uniforms = torch.from_numpy(parallel.resampling_uniforms(nb, 4, S, seed=0)).to(dev)
+    evid = torch.zeros(nb * 4, **f64)
+    sample_ll = torch.empty((nb, 4, S), **f64)
+    base = torch.zeros((nb, 3, S), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def sweep(max_dlas, nhi):
+        batch.sweep_device(S, max_dlas, z.data_ptr(), nhi.data_ptr(), 0, MIN_Z_SEPARATION,
+                           uniforms.data_ptr() if max_dlas > 1 else 0, evid.data_ptr(), sample_ll.data_ptr(),
+                           base.data_ptr() if max_dlas > 1 else 0, stream)
+
+    def timed(fn, steps):
+        """(wall ms per step, accumulate ms per step, accumulate launches per step)"""
+        fn()
+        torch.cuda.synchronize()
+        t_ramp = time.perf_counter()
+        while (time.perf_counter() - t_ramp) < 0.15:  # clock ramp
+            fn()
+            torch.cuda.synchronize()
+        sl.set_option("timing", 1)
+        sl.timing_read(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) * 1e3 / steps
+        sl.set_option("timing", 0)
+        ms, launches = sl.timing_read(reset=True)
+        return wall, ms / steps, launches // steps
+
+    def entry(ms, evals):
+        tf = evals * flops / (ms * 1e-3) / 1e12
+        return {"ms_per_launch": ms, "evals_per_launch": evals, "tflops": tf, "frac": tf / PEAK}
+
+    out = {"pixels_unmasked": args.pixels, "spread": args.spread, "n_kept_mean": n_mean, "sightlines": nb, "samples": S,
+           "flop_per_eval": flops, "options": args.option}
+    evals = float(nb) * S
+    wall1, acc1, _ = timed(lambda: sweep(1, nhi_sub), args.steps)
+    out["sub_dla"] = entry(acc1, evals)
+    out["sub_dla"]["step_wall_ms"] = wall1
+    out["sub_dla"]["other_kernels_share"] = 1.0 - acc1 / wall1
+    out["sub_dla"]["step_frac"] = evals * flops / (wall1 * 1e-3) / 1e12 / PEAK  # finalisation and level_finish included
+    out["sub_dla"]["fused_finalize"] = sl.get_option("last_launch_fused")
+    out["plan"] = {"work_items": sl.get_option("last_launch_items"), "pieces_per_block": sl.get_option("last_launch_parts"),
+                   "slots_mean": float(np.mean([-(-s.n // 8) * 8 for s in sights]))}
+    if args.stamps:
+        sl.set_option("debug", 2)
+        sl.debug_read(reset=True)
+        sweep(1, nhi_sub)
+        torch.cuda.synchronize()
+        st = sl.debug_read()
+        sl.set_option("debug", 0)
+        if st[5]:
+            names = ["voigt", "conv", "mfma_loop", "epilogue", "passes_and_epilogue", None, "prologue"]
+            out["stamps_cycles_per_wave"] = {n: st[i] / st[5] for i, n in enumerate(names) if n}
+            out["stamps_cycles_per_wave"]["waves"] = st[5]
+    if not args.no_cached:
+        wall2, acc2, l2 = timed(lambda: sweep(2, nhi_dla), args.steps)
+        wall4, acc4, l4 = timed(lambda: sweep(4, nhi_dla), args.steps)
+        cached = (acc4 - acc2) / 2.0
+        out["cached_level"] = entry(cached, evals)
+        out["level1_with_store"] = entry(acc2 - cached, evals)
+        out["sweep4"] = {"step_wall_ms": wall4, "accumulate_ms": acc4, "launches": l4,
+                         "other_kernels_share": 1.0 - acc4 / wall4, "frac": 4 * evals * flops / (acc4 * 1e-3) / 1e12 / PEAK,
+                         "step_frac": 4 * evals * flops / (wall4 * 1e-3) / 1e12 / PEAK,
+                         "cached": sl.get_option("last_sweep_cached"), "fused_finalize": sl.get_option("last_launch_fused")}
+    print(json.dumps(out))
+    batch.close()
+    for d in devs:
+        d.close()
+
+
+if __name__ == "__main__":
+    main()
