@@ -221,14 +221,51 @@ def host_description():
     return info
 
 
+def _default_threads_child(conn, sight, evals, seconds, cores):
+    """
+    Variant (ii) in a FRESH interpreter (multiprocessing "spawn"): this process has never limited its BLAS pools, so
+    "default threads" is what a user who simply runs the reference gets on this job's share of the host -- the
+    affinity mask is narrowed to that share BEFORE NumPy is imported, which is where OpenBLAS sizes its pool.
+    """
+    try:
+        try:
+            os.sched_setaffinity(0, set(cores))
+        except (OSError, AttributeError):
+            pass
+        global _CPU_STATE
+        from oracle import ref_like
+
+        _CPU_STATE = (ref_like, ref_like.SpectrumState(sight.y, sight.v, sight.this_mu, sight.this_M, sight.this_omega2,
+                                                       sight.padded_wavelengths, sight.unmasked_wavelengths, sight.keep))
+        _single_process_rate(evals, 0.5)  # imports, BLAS start-up
+        rate, done = _single_process_rate(evals, seconds)
+        threads = 1
+        try:
+            from threadpoolctl import threadpool_info
+
+            threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] + [1])
+        except Exception:
+            pass
+        conn.send({"value": rate, "evals": done, "blas_threads_used": threads})
+    except Exception as exc:  # noqa: BLE001 -- reported, never fatal for the bench line
+        conn.send({"error": "%s: %s" % (type(exc).__name__, exc)})
+    finally:
+        conn.close()
+
+
 def cpu_baseline(sight, evals, chunks: int = 5, chunk_seconds: float = 2.0, single_seconds: float = 3.0):
     """
     BASELINE.md §3 on a bounded sample of the step's evals (`evals`: parameter sets drawn from the workload):
       (iii) one process per core of this job's share (`host_cpu_share`), each PINNED to its own physical core, BLAS
-            limited to 1 thread: `value` = the MEDIAN over `chunks` equal chunks of (evals of the chunk / wall time
-            of the chunk); per-chunk rates, the per-core rate from the workers' own clocks and the spread are listed
-      (i)   1 process x 1 BLAS thread, (ii) 1 process x default BLAS threads: under `variants`
-    About chunks x chunk_seconds + 2 x single_seconds of wall time in total.
+            limited to 1 thread: `value` = the MEDIAN over `chunks` equal timed chunks of (evals of the chunk / wall
+            time of the chunk), after ONE untimed chunk of the same size (the first chunk of a run is a ramp: page
+            faults of the workers' first full pass, the cores' clocks -- round 4's driver line read 17 / 22 / 27 / 26 / 25 k
+            where the committed one read 27-30 k throughout); per-chunk rates, the untimed chunk's rate, the per-core
+            rate from the workers' own clocks and the spread are listed
+      (i)   1 process x 1 BLAS thread (this process, limited for the duration of the measurement only),
+      (ii)  1 process x default BLAS threads, measured in a FRESH interpreter whose affinity is this job's share: the
+            thread count reported is the one its BLAS actually ran with
+    About (chunks + 1) x chunk_seconds + 2 x single_seconds + start-up of wall time in total.
     """
     import multiprocessing as mp
 
@@ -252,39 +289,63 @@ def cpu_baseline(sight, evals, chunks: int = 5, chunk_seconds: float = 2.0, sing
         t0 = time.perf_counter()
         pool.map(_cpu_worker_eval, chunk_args(16, 0), chunksize=1)
         per_worker = max(16, int(16 * chunk_seconds / max(time.perf_counter() - t0, 1e-3)))
-        rates, busy, done, cursor = [], [], 0, 0
-        for _ in range(chunks):
+        rates, busy, done, cursor, untimed_rate = [], [], 0, 0, None
+        for index in range(chunks + 1):
             t0 = time.perf_counter()
             results = pool.map(_cpu_worker_eval, chunk_args(per_worker, cursor), chunksize=1)
             wall = time.perf_counter() - t0
             cursor += per_worker * workers
             count = sum(r[0] for r in results)
+            if index == 0:  # the ramp: measured, reported, not part of the value
+                untimed_rate = count / wall
+                continue
             done += count
             rates.append(count / wall)
             busy.extend(r[0] / r[1] for r in results)  # each worker's own rate while it ran
     variants = {}
-    _cpu_worker_init(sight)  # this process: BLAS limited to one thread ...
-    rate_i, n_i = _single_process_rate(evals, single_seconds)
-    variants["i_one_process_one_blas_thread"] = {"value": rate_i, "cores": 1, "evals": n_i}
-    try:  # ... and with the default thread count
-        from threadpoolctl import threadpool_info, threadpool_limits
+    # (i): this process with its BLAS pools limited to one thread for the duration of the measurement ONLY
+    global _CPU_STATE
+    from oracle import ref_like
 
-        default_threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-        with threadpool_limits(limits=workers):
-            rate_ii, n_ii = _single_process_rate(evals, single_seconds)
-        variants["ii_one_process_default_blas_threads"] = {"value": rate_ii, "cores": workers, "evals": n_ii,
-                                                           "blas_threads_seen": default_threads}
+    _CPU_STATE = (ref_like, ref_like.SpectrumState(sight.y, sight.v, sight.this_mu, sight.this_M, sight.this_omega2,
+                                                   sight.padded_wavelengths, sight.unmasked_wavelengths, sight.keep))
+    try:
+        from threadpoolctl import threadpool_limits
+
+        with threadpool_limits(limits=1):
+            rate_i, n_i = _single_process_rate(evals, single_seconds)
+        variants["i_one_process_one_blas_thread"] = {"value": rate_i, "cores": 1, "evals": n_i}
     except Exception:
         pass
+    try:  # (ii): a fresh interpreter with the default thread count
+        spawn = mp.get_context("spawn")
+        parent, child = spawn.Pipe(duplex=False)
+        proc = spawn.Process(target=_default_threads_child, args=(child, sight, evals, single_seconds, cores))
+        proc.start()
+        child.close()
+        answer = parent.recv() if parent.poll(120.0) else {"error": "no answer within 120 s"}
+        proc.join(30.0)
+        if proc.is_alive():
+            proc.kill()  # the exact child started above
+        if "value" in answer:
+            variants["ii_one_process_default_blas_threads"] = {
+                "value": answer["value"], "cores": answer["blas_threads_used"], "evals": answer["evals"],
+                "blas_threads_used": answer["blas_threads_used"], "affinity_cores": workers}
+        else:
+            variants["ii_one_process_default_blas_threads"] = answer
+    except Exception as exc:  # noqa: BLE001
+        variants["ii_one_process_default_blas_threads"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     rates_sorted = sorted(rates)
     return {
         "value": float(np.median(rates)),
         "unit": "evals/s",
         "cores": workers,
         "kind": "port",
-        "sample": "%d evals drawn from the %d parameter sets of one step's workload: %d chunks of %d evals on each of %d "
-                  "pinned processes x 1 BLAS thread; value = median chunk rate" % (done, len(evals), chunks, per_worker, workers),
+        "sample": "%d evals drawn from the %d parameter sets of one step's workload: %d timed chunks of %d evals on each of %d "
+                  "pinned processes x 1 BLAS thread after one untimed chunk of the same size; value = median chunk rate"
+                  % (done, len(evals), chunks, per_worker, workers),
         "chunk_rates": rates,
+        "untimed_first_chunk_rate": untimed_rate,
         "spread": (rates_sorted[-1] - rates_sorted[0]) / float(np.median(rates)),
         "per_core": float(np.median(busy)),
         "cores_why": why,

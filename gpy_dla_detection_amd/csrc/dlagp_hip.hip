@@ -2,8 +2,19 @@
 // translation unit that instantiates every kernel (one HIP module per device).
 //
 // Build: make -C gpy_dla_detection_amd/csrc   (hipcc --offload-arch=gfx950)
+#ifndef DLAGP_FAKE_DEVICE
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#else
+// host-only sanitizer build of THIS file's host side (runtime_replay.cpp, `make sanitize`): a stand-in for the HIP runtime
+// API with the stream / allocation semantics the bookkeeping below relies on; the kernels do not exist there.  Test
+// infrastructure -- libdlagp_hip.so is never built this way.
+#include "fake_device.h"
+#define DLAGP_DEVICE_CHECK_IDLE(p) ((void)fake::check_idle((p), "DeviceBuffer::release"))
+#endif
+#ifndef DLAGP_DEVICE_CHECK_IDLE
+#define DLAGP_DEVICE_CHECK_IDLE(p) ((void)0)
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -23,10 +34,15 @@
 
 #include "../../include/dlagp.h"
 #include "dlagp_device.h"
+#include "host_shared.h"
+#ifndef DLAGP_FAKE_DEVICE
 #include "kernels_common.h"
 #include "kernels_generic.h"
 #include "kernels_mfma.h"
 #include "voigt_device.h"
+#else
+#include "fake_kernels.h"
+#endif
 
 using namespace dlagp;
 
@@ -249,6 +265,10 @@ struct DeviceBuffer {
     }
     void release() {
         if (!ptr) return;
+        // a buffer that goes back to the pool (or to the allocator) must be idle: the caller has drained whatever stream
+        // its last launch ran on.  Checked by the host-only sanitizer build's fake device (fake_device.h); nothing here
+        // in the library proper.
+        DLAGP_DEVICE_CHECK_IDLE(ptr);
         bool parked = false;
         if (bytes <= kPoolMaxBuffer) {
             int device = 0;
@@ -1447,14 +1467,17 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
             ctx->setup_event = nullptr;  // wait_setup falls back to a device-wide wait
         }
     }
-    if (!defer_sync) {
-        ctx->scratch_a.release();
-        ctx->scratch_b.release();
-    }
     if (rc) {
+        // finish_group failed before its synchronisation (the descriptor table could not be allocated): the set-up kernels
+        // may still be reading the scratch inputs, which dlagp_destroy hands back to the pool -- wait first.  (Found by the
+        // host-only sanitizer replay with injected allocation failures, round 5: the scratch used to be released above this.)
         (void)setup_sync(device);
         dlagp_destroy(ctx);
         return rc;
+    }
+    if (!defer_sync) {  // finish_group has synchronised the set-up stream: the kernels' inputs are idle
+        ctx->scratch_a.release();
+        ctx->scratch_b.release();
     }
     *out = ctx;
     return DLAGP_OK;

@@ -1,6 +1,7 @@
 // Kernels shared by every evaluation path: the shared-operand builder and the per-sample
 // finalisation (k x k Cholesky, triangular solve, log-determinant, assembly).
 #pragma once
+#include "host_shared.h"
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -82,17 +83,6 @@ __global__ void build_shared_operand(const double *__restrict__ M_dev, int n, in
 // Outputs in the layout dlagp_create builds from host arrays: mu, omega2 padded to n_pad with zeros,
 // M dense row-major [n][k_out] (columns >= k zero).
 // ---------------------------------------------------------------------------------------------
-struct ModelDev {
-    int n_grid, k, num_forest_lines;
-    const double *grid;       // [n_grid] rest wavelengths, increasing
-    const double *mu;         // [n_grid]
-    const double *log_omega;  // [n_grid]
-    const double *M;          // [k][n_grid]: one contiguous column per eigenvector
-    double prev_beta, beta, c_0;
-    double lines[DLAGP_MAX_LINES];        // series wavelengths, Angstrom
-    double scale_prev[DLAGP_MAX_LINES];   // prev_tau_0 f_l/f_0 lambda_l/lambda_0
-    double scale_noise[DLAGP_MAX_LINES];  // tau_0        f_l/f_0 lambda_l/lambda_0
-};
 
 __device__ __forceinline__ double numpy_row_sum(const double *t, int n) {
     if (n < 8) {
@@ -122,8 +112,6 @@ __device__ __forceinline__ double numpy_interp(const double *__restrict__ xp, co
 // `pow` calls: one thread per pixel doing all 62 of them made this a 127 us kernel, the longest step of context
 // creation), thread 0 sums them in numpy's order and forms the two factors, then the 32 threads share the pixel's
 // k + 2 interpolations.  Arithmetic per value unchanged.
-#define DLAGP_INTERP_PIXELS 8
-#define DLAGP_INTERP_THREADS (32 * DLAGP_INTERP_PIXELS)
 static_assert(DLAGP_MAX_LINES <= 32, "one thread per series member");
 
 __global__ __launch_bounds__(DLAGP_INTERP_THREADS) void interp_model(
@@ -198,9 +186,6 @@ __global__ __launch_bounds__(DLAGP_INTERP_THREADS) void interp_model(
 // 210 + 20 useful columns ride on 14 x 64 + 2 x 16 = 928 MFMA cycles per step instead of 16 x 64 = 1024.
 // Padding slots (slot_pixel < 0) are zero rows.  M_dev is dense row-major [n][20].
 // ---------------------------------------------------------------------------------------------
-#define DLAGP_MFMA_BIG_TILES 14
-#define DLAGP_MFMA_W_TILES 13      // full tiles weighted by w; tile 13 is weighted by q
-#define DLAGP_MFMA_PAIRS 8
 #define DLAGP_MFMA_SMALL_W_COL 208  // first vech column carried by the small w-MFMA
 #define DLAGP_MFMA_SMALL_Q_COL 16   // first column of M carried by the small q-MFMA
 
@@ -214,8 +199,6 @@ __device__ __forceinline__ void vech_invert(int col, int &a, int &b) {
 // Ranks above 20 (K = the rank, `colgroups` > 1): the same layout once per column group g, group after group; group g
 // carries vech columns 210 g .. 210 g + 209 (13 full tiles + the small w-MFMA's two) and columns 20 g .. 20 g + 19 of M (tile
 // 13 + the small q-MFMA's four); columns beyond k (k + 1) / 2 resp. k are zero.
-#define DLAGP_MFMA_GROUP_W_COLS 210
-#define DLAGP_MFMA_GROUP_Q_COLS 20
 __global__ void build_mfma_operand(const double *__restrict__ M_dev, const int *__restrict__ slot_pixel, int n_slots,
                                    double *__restrict__ Pm, int K, int colgroups) {
     const long per_group = (long)n_slots * DLAGP_MFMA_PAIRS * 16 * 2;  // (slot, pair, lane-in-slot 0..15, half)
@@ -288,7 +271,6 @@ __global__ void fill_records(int n_slots, const int *__restrict__ slot_pixel, co
 // NaN inputs propagate to a NaN result without raising, as in the reference.
 // KT > 0: compile-time rank, everything in registers.  KT == 0: runtime rank, local arrays.
 // ---------------------------------------------------------------------------------------------
-#define DLAGP_FINALIZE_THREADS 64
 template <int KT>
 __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const double *__restrict__ part, int nsplit, long rows, long S,
                                  const SightlineDev *__restrict__ sightlines,
@@ -381,8 +363,6 @@ __global__ __launch_bounds__(DLAGP_FINALIZE_THREADS) void finalize_samples(const
 // solve, and updates its row's trailing entries.  Same formula as null_gp.py:343-358, another summation order than
 // finalize_samples (agreement to rounding).  blockDim = 64 x DLAGP_FINW_SAMPLES; dynamic LDS: that many matrices.
 // ---------------------------------------------------------------------------------------------
-#define DLAGP_FINW_SAMPLES 2
-__host__ __device__ __forceinline__ int finalize_wave_lds_doubles(int k) { return k * (k + 1) / 2 + k; }
 // one wave's LDS writes before another lane's reads: the LDS serves a wave's operations in issue order, so program order
 // (the asm's memory clobber) and an lgkmcnt wait are all it takes
 __device__ __forceinline__ void finw_sync() {
@@ -468,20 +448,10 @@ __global__ __launch_bounds__(64 * DLAGP_FINW_SAMPLES) void finalize_wave(
 // Same results as finalize_samples<20> to rounding; ~15x faster on 10 000 samples.
 // Dynamic LDS: DLAGP_FINALIZE_LDS_DOUBLES doubles.
 // ---------------------------------------------------------------------------------------------
-#define DLAGP_FIN_K 20
-#define DLAGP_FIN_COLS (DLAGP_FIN_K * (DLAGP_FIN_K + 1) / 2)
-#define DLAGP_FIN_SAMPLES 16   // samples per workgroup: small, so that every CU pulls partial sums
-#define DLAGP_FIN_THREADS 256
-#define DLAGP_FIN_STAGED (DLAGP_FIN_COLS + DLAGP_FIN_K + 3)  // vech(B - I), u, 3 scalars
-#define DLAGP_FIN_LDS_STRIDE 17  // doubles per staged column in LDS: odd, so that columns two apart fall on different banks
-#define DLAGP_FINALIZE_LDS_DOUBLES (DLAGP_FIN_STAGED * DLAGP_FIN_LDS_STRIDE)
 // launches of up to this many blocks of 16 samples factor with 16 lanes per sample, larger ones with one lane per
 // sample (option finalize_row16_blocks).  The 16-lane form was written for small launches (few workgroups per CU: the
 // dependent chain of the one-lane form is what they wait for) but is the faster one on large ones too -- 442 against
 // 471 us on 40 000 blocks, 240 against 251 us on 20 000 (profiles/r03_experiments.txt item 18) -- so the default is "all".
-#ifndef DLAGP_FIN_ROW16_MAX_BLOCKS
-#define DLAGP_FIN_ROW16_MAX_BLOCKS (1L << 40)
-#endif
 
 // f(integral_constant<int, I>) for I = BEGIN .. END - 1, unrolled at compile time (DPP controls and register indices
 // must be constants)
@@ -826,7 +796,6 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
 //   evidence = nanmax + log(nanmean(exp(ll - nanmax))) - level * log S      (:180-190)
 // All-NaN levels give NaN, as np.nanmax / np.nanmean do.
 // ---------------------------------------------------------------------------------------------
-#define DLAGP_EVIDENCE_THREADS 1024
 
 __global__ __launch_bounds__(DLAGP_EVIDENCE_THREADS) void level_evidence(double *__restrict__ ll, long S, int level,
                                                                        const unsigned char *__restrict__ too_close,
@@ -938,7 +907,6 @@ __global__ __launch_bounds__(DLAGP_EVIDENCE_THREADS) void level_evidence(double 
 //      is a parallel scan: its rounding differs from NumPy's sequential one at the 1e-16 level, far
 //      below the 1e-13 differences of the log-likelihoods themselves.
 // ---------------------------------------------------------------------------------------------
-#define DLAGP_LEVEL_THREADS 1024
 
 __device__ __forceinline__ double block_reduce(double x, bool take_max, double *red) {
     for (int off = 32; off > 0; off >>= 1) {

@@ -19,7 +19,6 @@
 
 namespace dlagp {
 
-#define DLAGP_GENERIC_THREADS 256
 
 // Absorption vector of one sample into LDS a[0..n_pad) (padding pixels get 1).
 // raw[] is scratch of num_entries doubles; mult[] of DLAGP_MAX_LINES doubles.

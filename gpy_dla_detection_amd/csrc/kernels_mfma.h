@@ -47,18 +47,10 @@ namespace dlagp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-#define DLAGP_MFMA_RANK 20
 #define DLAGP_MFMA_NTW DLAGP_MFMA_W_TILES    // 13 full tiles weighted by w
 #define DLAGP_MFMA_NT DLAGP_MFMA_BIG_TILES   // 14 full tiles; two 4x4x4 MFMAs carry the remaining 2 + 4 columns
-#define DLAGP_MFMA_THREADS 64
 #define DLAGP_RAW_STRIDE 67      // doubles per sample row in LDS; odd -> conflict-free ds_read2_b64 windows
-#define DLAGP_AUX_FIELDS 8       // per-pixel record: y, mu, omega2, v, window start, 3 spare
 #define DLAGP_BUFFER_FLAGS 0x00020000  // word 3 of a raw buffer resource on gfx9-family targets
-#define DLAGP_LAUNCH_PIECES_MASK 0xff       // launch_flags, low byte: pieces per block of the launch plan (the partial sums'
-                                           // stride between column groups)
-#define DLAGP_MFMA_ROW_WIDTH ((14 + 2) * DLAGP_TILE_COLS + DLAGP_ROW_EXTRA)  // 264: row_width of a rank-20 sightline (ntw 14, ntq 2)
-#define DLAGP_LAUNCH_KEEP_STATUS 0x10000   // launch_flags: do not clear the non-PD flag (see accumulate_mfma)
-#define DLAGP_LAUNCH_GENERAL_ROWS 0x20000  // cached levels: 16 row reads per pass even where one would do (option shared_rows = 0)
 // DLAGP_MFMA_GROUP (16 samples per wave), DLAGP_PASS_ENTRIES, DLAGP_CHUNK_PIXELS, DLAGP_MAX_PASS_STEPS / _CHUNKS and the
 // PassDesc / WorkItem records of the launch plan: plan_host.h (shared with the host-only planner build)
 
@@ -770,6 +762,27 @@ __device__ __forceinline__ void accumulate_mfma_body(
                     // one running LDS address (hipcc otherwise rebuilds lane * 8 + offset for every sample)
                     __attribute__((address_space(3))) double *raw_w = (__attribute__((address_space(3))) double *)raw + lane;
                     asm volatile("" : "+v"(raw_w));
+#ifdef DLAGP_KO_PAIR
+                    // timing knock-out (wrong results): rows ss and ss + 8 share one optical depth, two column densities
+                    if constexpr (PATCH == 1 && !LLS) {
+#pragma unroll 1
+                    for (int ss = 0; ss < 8; ++ss) {
+                        const double xs[3] = {fma(lam, m0, x_offset), fma(lam, m1, x_offset), fma(lam, m2, x_offset)};
+                        __builtin_amdgcn_sched_barrier(0);
+                        const v4d nxt = sp4[(ss + 1) * kd];
+                        const double ncol_b = reinterpret_cast<const double *>(sp4 + (ss + 8) * kd)[3];
+                        m0 = nxt.x;
+                        m1 = nxt.y;
+                        m2 = nxt.z;
+                        __builtin_amdgcn_sched_barrier(0);
+                        const double tau = optical_depth<LINES, false>(lam, nullptr, 3, w3v, xs);
+                        raw_w[0] = fast_exp2_table(-ncol * tau, DLAGP_LINES.exp2c, c8v);
+                        raw_w[8 * DLAGP_RAW_STRIDE] = fast_exp2_table(-ncol_b * tau, DLAGP_LINES.exp2c, c8v);
+                        raw_w += DLAGP_RAW_STRIDE;
+                        ncol = nxt.w;
+                    }
+                    } else
+#endif
 #pragma unroll 1
                     for (int ss = 0; ss < 16; ++ss) {
                         const double xs[3] = {fma(lam, m0, x_offset), fma(lam, m1, x_offset), fma(lam, m2, x_offset)};

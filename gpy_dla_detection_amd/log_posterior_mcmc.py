@@ -5,7 +5,10 @@ Mirror of the reference's functional interface (gpy_dla_detection/log_posterior_
 `log_prior`, `log_posterior(theta, ...)` with the argument list `DLAGP.run_mcmc` hands to
 emcee (dla_gp.py:265-287), and `sample_log_likelihood_k_dlas`.  The likelihood is the same
 device path as the QMC sweep (`dlagp_eval`); the sightline context is built from the arrays on
-first use and reused while the same arrays are passed (emcee calls with identical `args`).
+first use and reused while arrays of the same CONTENT are passed (emcee calls with identical `args`).
+The reference re-reads its arrays on every call (:139-250), so an in-place edit of `y` between two
+calls changes its answer; the cache key is therefore the arrays' bytes (a memcmp of a few hundred KB
+per call), not their identity, and the cache is guarded by a lock (emcee pools may call from threads).
 
 `log_posterior_vectorized` is the form for `emcee.EnsembleSampler(..., vectorize=True)`: all
 walkers of an ensemble step in one launch -- the way to use the GPU for MCMC.  Unlike the
@@ -13,11 +16,15 @@ reference's TODO (:66), theta may hold k absorbers: (z_1..z_k, logN_1..logN_k).
 """
 from typing import Callable, Optional, Tuple
 
+import threading
+
 import numpy as np
 
 from . import sightline as _sl
+from .null_gp import _content
 
 _cache = {"key": None, "dev": None}
+_cache_lock = threading.Lock()  # the cached sightline is built, replaced and evaluated under it (a context is not thread-safe)
 
 
 def log_prior(z_dla: float, log_nhi: float, min_z_dla: float, max_z_dla: float, min_log_nhi: float,
@@ -31,19 +38,24 @@ def log_prior(z_dla: float, log_nhi: float, min_z_dla: float, max_z_dla: float, 
 
 def _device_sightline(y, v, padded_wavelengths, this_mu, this_M, this_omega2, pixel_mask, ind_unmasked,
                       num_lines, device: int = 0) -> _sl.DeviceSightline:
-    arrays = (y, v, padded_wavelengths, this_mu, this_M, this_omega2, pixel_mask, ind_unmasked)
-    key = _cache["key"]
-    fresh = (
-        key is None or key[1] != (int(num_lines), int(device)) or any(a is not b for a, b in zip(key[0], arrays))
-    )
-    if fresh:
+    """the cached HBM copy of these arrays, rebuilt whenever their CONTENT differs; call with `_cache_lock` held"""
+    key = (int(num_lines), int(device),
+           _content(y, v, padded_wavelengths, this_mu, this_M, this_omega2, pixel_mask, ind_unmasked))
+    if _cache["dev"] is None or _cache["key"] != key:
         if _cache["dev"] is not None:
             _cache["dev"].close()
+            _cache["dev"] = _cache["key"] = None
         keep = ~np.asarray(pixel_mask)[np.asarray(ind_unmasked)]  # reference :196
         _cache["dev"] = _sl.DeviceSightline(y, this_mu, this_M, this_omega2, v, padded_wavelengths, keep,
                                             num_lines=int(num_lines), broadening=True, device=device)
-        _cache["key"] = (arrays, (int(num_lines), int(device)))
+        _cache["key"] = key
     return _cache["dev"]
+
+
+def _evaluate(z: np.ndarray, nhi: np.ndarray, arrays, num_lines, device: int = 0) -> np.ndarray:
+    """log-likelihoods of the rows of (z, nhi) on the cached sightline of `arrays`"""
+    with _cache_lock:
+        return _device_sightline(*arrays, num_lines, device).eval(z, nhi)
 
 
 def sample_log_likelihood_k_dlas(z_dlas: np.ndarray, nhis: np.ndarray, y: np.ndarray, v: np.ndarray,
@@ -52,11 +64,10 @@ def sample_log_likelihood_k_dlas(z_dlas: np.ndarray, nhis: np.ndarray, y: np.nda
                                  num_lines: int) -> float:
     """log p(y | {z_dla, N_HI}_1..k) (reference :98-136); the broadened profile, as there (:179-186)"""
     assert len(z_dlas) == len(nhis)
-    dev = _device_sightline(y, v, padded_wavelengths, this_mu, this_M, this_omega2, pixel_mask, ind_unmasked,
-                            num_lines)
     z = np.asarray(z_dlas, dtype=np.float64)[None, :]
     n = np.asarray(nhis, dtype=np.float64)[None, :]
-    return float(dev.eval(z, n)[0])
+    arrays = (y, v, padded_wavelengths, this_mu, this_M, this_omega2, pixel_mask, ind_unmasked)
+    return float(_evaluate(z, n, arrays, num_lines)[0])
 
 
 def log_posterior(theta: Tuple, this_wavelengths: np.ndarray, y: np.ndarray, v: np.ndarray, z_qso: float,
@@ -93,7 +104,7 @@ def log_posterior_vectorized(thetas: np.ndarray, this_wavelengths: np.ndarray, y
     out = np.full(W, -np.inf)
     live = np.isfinite(lp)
     if live.any():
-        dev = _device_sightline(y, v, padded_wavelengths, this_mu, this_M, this_omega2, pixel_mask, ind_unmasked,
-                                num_lines, device)
-        out[live] = lp[live] + dev.eval(np.ascontiguousarray(z[live]), np.ascontiguousarray(10.0 ** log_nhi[live]))
+        arrays = (y, v, padded_wavelengths, this_mu, this_M, this_omega2, pixel_mask, ind_unmasked)
+        out[live] = lp[live] + _evaluate(np.ascontiguousarray(z[live]), np.ascontiguousarray(10.0 ** log_nhi[live]),
+                                         arrays, num_lines, device)
     return out

@@ -1761,6 +1761,59 @@ def test_log_posterior_mcmc_matches_reference_golden():
     assert abs(mc.log_posterior_vectorized(pair, *args)[0] - want) <= 1e-12 * abs(want)
 
 
+def test_log_posterior_mcmc_sees_in_place_edits_like_the_reference():
+    """
+    The reference's `log_posterior` re-reads its arrays on every call (log_posterior_mcmc.py:139-250): editing `y` in
+    place between two calls changes the answer.  The device route keeps one HBM copy of the arrays and keys it by their
+    CONTENT (round 5; by identity before: the edit went unseen): same arrays object, new bytes -> new sightline, the
+    oracle's value on the edited flux; the edit undone -> the first value again, bit for bit; calls from several
+    threads at once (an emcee pool) share the cache under its lock.
+    """
+    import threading
+
+    from gpy_dla_detection_amd import log_posterior_mcmc as mc
+    from oracle import ref_like as R
+    from tests.golden_inputs import mcmc_pdf, mcmc_thetas
+
+    sight = make_sightline(3, n_unmasked=350, n_masked=7)
+    z_lo, z_hi = sight.z_range()
+    thetas = mcmc_thetas(z_lo, z_hi)
+    live = [t for t in thetas if z_lo < t[0] < z_hi and 20.0 < t[1] < 23.0][:3]
+    assert live
+    pixel_mask = ~sight.keep
+    ind_unmasked = np.ones(sight.keep.shape[0], dtype=bool)
+    y = sight.y.copy()
+    args = (sight.this_wavelengths, y, sight.v, sight.z_qso, z_lo, z_hi, 20.0, 23.0, mcmc_pdf,
+            sight.padded_wavelengths, sight.this_mu, sight.this_M, sight.this_omega2, pixel_mask, ind_unmasked, 3)
+
+    def oracle_value(t):
+        st = R.SpectrumState(y, sight.v, sight.this_mu, sight.this_M, sight.this_omega2, sight.padded_wavelengths,
+                             sight.unmasked_wavelengths, sight.keep)
+        return R.sample_log_likelihood_k_dlas(st, [t[0]], [10.0 ** t[1]]) + np.log(mcmc_pdf(t[1]))
+
+    t = tuple(live[0])
+    before = mc.log_posterior(t, *args)
+    assert abs(before - oracle_value(t)) <= RTOL_LL * abs(before)
+    y[40:60] *= 0.5  # in place: the same array object
+    after = mc.log_posterior(t, *args)
+    assert after != before
+    assert abs(after - oracle_value(t)) <= RTOL_LL * abs(after)
+    y[40:60] *= 2.0  # exact: a factor of two
+    assert mc.log_posterior(t, *args) == before
+    # threads: every call sees the arrays it was given
+    got = {}
+
+    def worker(i):
+        got[i] = [mc.log_posterior(tuple(th), *args) for th in live]
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert all(got[i] == got[0] for i in range(4)) and got[0][0] == before
+
+
 # ------------------------------------------------------------------------------------------------
 # f4: Lyman-limit-system profile (reference voigt_lls.py) behind DLAGP_FLAG_LLS_BREAK
 # ------------------------------------------------------------------------------------------------
@@ -2265,7 +2318,7 @@ def test_accumulate_waves_finish_their_own_blocks_bit_for_bit(restore_options):
             assert abs(got["three"][b, i] - want_ll) <= RTOL_LL * abs(want_ll)
     # automatic plans: a launch with more blocks than wave slots is single-piece and fused, a small one is not
     set_option("pixel_splits", 0)
-    big = 9000
+    big = 8192  # 4 x 512 blocks = the chip's 2048 wave slots: one piece per block is the planner's own choice
     zb = np.stack([make_qmc_samples(s, big)[0] for s in sights])
     nb_ = make_qmc_samples(sights[0], big)[2]
     first = batch.eval(zb, np.broadcast_to(nb_, zb.shape))

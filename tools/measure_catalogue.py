@@ -1,9 +1,19 @@
 #!/usr/bin/env python3
 """
 End-to-end catalogue throughput on one GPU: raw spectra -> run_bayes_select.process_qso ->
-the reference's output arrays.  Synthetic SDSS-like spectra (4600 pixels at 1e-4 dex, z_qso in
-[2.2, 3.4], n ~ 1000-1250 pixels in the modelled range -- the size of real DR12Q sightlines),
+the reference's output arrays.  Synthetic SDSS-like spectra (4600 pixels at 1e-4 dex from 3631 A),
 S = 10 000 QMC samples, max_dlas = 4.  Prints one JSON object with spectra/s and a phase split.
+
+    python3 tools/measure_catalogue.py [spectra] [S] [batch size] [mix]
+
+The kept pixels n of a spectrum follow z_qso through the modelled window 911.75-1215.75 A (reference
+set_parameters.py:33-34, null_gp.py:139-152): the window is entered at z_qso ~ 2.0 and fully covered, n = 1250, from
+z_qso ~ 2.98.  Two redshift mixes:
+  uniform  z_qso uniform in [2.2, 3.4]: n = 300 ... 1250, mean ~ 920 (rounds 1-4; their docstring said "n ~ 1000-1250",
+           which only holds above z_qso ~ 2.8)
+  dr12q    z_qso = 2.15 + Gamma(2, 0.22), the DR12Q-like spread of tests/test_host_logic.py
+           (test_cost_balanced_partition_of_a_redshift_ordered_catalogue): n = 250 ... 1250, median ~ 685
+The output lists the n statistics of the spectra it ran on.
 """
 import json
 import os
@@ -26,7 +36,7 @@ class FixedPrior:
         return 731.0, 9265.0
 
 
-def make_inputs(num, k=20, seed=7):
+def make_inputs(num, k=20, seed=7, mix="uniform"):
     rng = np.random.default_rng(seed)
     rest_grid = np.arange(911.75, 1215.75 + 1e-9, 0.25)
     mu = 1 + 0.2 * np.cos(rest_grid / 30.0)
@@ -36,7 +46,10 @@ def make_inputs(num, k=20, seed=7):
     obs = 10.0 ** (3.5600 + 1e-4 * np.arange(4600))
     spectra, z_qsos = [], []
     for i in range(num):
-        z_qso = 2.2 + 1.2 * rng.random()
+        if mix == "dr12q":
+            z_qso = float(np.clip(2.15 + rng.gamma(2.0, 0.22), 2.15, 5.5))
+        else:
+            z_qso = 2.2 + 1.2 * rng.random()
         rest = obs / (1 + z_qso)
         flux = 3.0 + 0.5 * np.sin(rest / 40.0)
         if i % 3:
@@ -52,11 +65,17 @@ def main():
     num = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
     batch_size = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    mix = sys.argv[4] if len(sys.argv) > 4 else "uniform"
+    if mix not in ("uniform", "dr12q"):
+        raise SystemExit("mix must be uniform or dr12q")
     params = Parameters(num_dla_samples=S)
     u = halton(S, 3)
     dla = DLASamples(params, None, halton(S, 2), 20.0 + 3.0 * u)
     sub = SubDLASamples(params, None, halton(S, 2), 19.5 + 0.5 * u, Z_dla=1.0, Z_lls=0.25)
-    learned, spectra, z_qsos = make_inputs(num)
+    learned, spectra, z_qsos = make_inputs(num, mix=mix)
+    from gpy_dla_detection_amd.run_bayes_select import kept_pixel_counts
+
+    kept = kept_pixel_counts(params, spectra, z_qsos)
     for item in os.environ.get("DLAGP_OPTIONS", "").split(","):  # e.g. DLAGP_OPTIONS=shared_work_stream=0
         if item:
             from gpy_dla_detection_amd.sightline import set_option
@@ -78,7 +97,10 @@ def main():
     t = time.perf_counter() - t0
     free_after = torch.cuda.mem_get_info()[0]
     out = {
-        "spectra": num, "S": S, "max_dlas": 4, "batch_size": batch_size, "seconds": t,
+        "spectra": num, "S": S, "max_dlas": 4, "batch_size": batch_size, "seconds": t, "mix": mix,
+        "kept_pixels": {"min": int(kept.min()), "median": float(np.median(kept)), "mean": float(kept.mean()), "max": int(kept.max())},
+        # algorithmic FLOP of the run (n k (k + 1) + 2 n k per eval, 5 S evals per spectrum) / wall time / peak
+        "whole_run_frac_of_fp64_peak": float(kept.sum()) * (20 * 21 + 40) * 5 * S / t / 78.6e12,
         "spectra_per_s": num / t, "evals_per_s": num * (1 + 5 * S) / t,
         "argmax_counts": np.bincount(np.argmax(res["model_posteriors"], axis=1), minlength=6).tolist(),
         # device memory held by the library's pools after the warm-up, and what the timed run added to it
