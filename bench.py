@@ -371,6 +371,85 @@ def baseline_sample(config, sight, z, nhi_dla, nhi_sub):
     return evals
 
 
+def parse_cpu_list(text: str):
+    """Linux cpulist ("0-23,96-119") -> sorted list of ints"""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return sorted(set(cpus))
+
+
+def gpu_local_cpus(index: int, sysfs: str = "/sys", visible=None):
+    """
+    CPUs of the NUMA node that GPU `index` of this process's device numbering hangs off, read from sysfs WITHOUT touching
+    the GPU (a rank binds itself before its first HIP call): the KFD topology lists the compute nodes in the runtime's
+    enumeration order (`simd_count` > 0: a GPU; `drm_render_minor` names its DRM node), `HIP_VISIBLE_DEVICES` /
+    `ROCR_VISIBLE_DEVICES` (a list of ordinals) select and reorder them, and the DRM device's `local_cpulist` (or the
+    `cpulist` of its `numa_node`) gives the CPUs.  Returns (cpus, description); ([], why) when anything is missing --
+    binding is an optimisation, never a requirement.
+    """
+    nodes_dir = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        node_ids = sorted(int(n) for n in os.listdir(nodes_dir) if n.isdigit())
+    except OSError:
+        return [], "no KFD topology under %s" % nodes_dir
+    gpus = []
+    for node in node_ids:
+        props = {}
+        try:
+            with open(os.path.join(nodes_dir, str(node), "properties")) as f:
+                for ln in f:
+                    key, _, value = ln.partition(" ")
+                    props[key] = value.strip()
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0") or 0) > 0 and "drm_render_minor" in props:
+            gpus.append(int(props["drm_render_minor"]))
+    if visible is None:
+        visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or ""
+    if visible.strip():
+        try:
+            gpus = [gpus[int(tok)] for tok in visible.split(",") if tok.strip()]
+        except (ValueError, IndexError):
+            return [], "cannot interpret the visible-devices list %r" % visible
+    if not 0 <= index < len(gpus):
+        return [], "GPU %d not among the %d GPUs of the KFD topology" % (index, len(gpus))
+    device = os.path.join(sysfs, "class", "drm", "renderD%d" % gpus[index], "device")
+    try:
+        with open(os.path.join(device, "local_cpulist")) as f:
+            cpus = parse_cpu_list(f.read())
+        if cpus:
+            return cpus, "local_cpulist of renderD%d" % gpus[index]
+    except (OSError, ValueError):
+        pass
+    try:
+        with open(os.path.join(device, "numa_node")) as f:
+            numa = int(f.read().strip())
+        if numa < 0:
+            return [], "renderD%d reports no NUMA node" % gpus[index]
+        with open(os.path.join(sysfs, "devices", "system", "node", "node%d" % numa, "cpulist")) as f:
+            return parse_cpu_list(f.read()), "NUMA node %d of renderD%d" % (numa, gpus[index])
+    except (OSError, ValueError):
+        return [], "no NUMA information for renderD%d" % gpus[index]
+
+
+def bind_to_gpu_numa_node(local_rank: int, sysfs: str = "/sys"):
+    """--bind: pin this rank (before any GPU call) to the CPUs next to its GPU; returns what was done, for the line"""
+    cpus, why = gpu_local_cpus(local_rank, sysfs)
+    allowed = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
+    target = sorted(set(cpus) & allowed)
+    if not target:
+        return {"bound": False, "why": why if not cpus else "none of the GPU's local CPUs is in this process's affinity mask"}
+    try:
+        os.sched_setaffinity(0, target)
+    except OSError as exc:
+        return {"bound": False, "why": "sched_setaffinity failed: %s" % exc}
+    return {"bound": True, "cpus": len(target), "first_cpu": target[0], "source": why}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -392,6 +471,9 @@ def parse_args(argv=None):
     ap.add_argument("--debug", type=int, default=0, help=argparse.SUPPRESS)  # 2: per-phase cycle stamps (diagnostic)
     # rehearsal of the N > 1 code path on a one-GPU box: every rank on device 0, gloo instead of RCCL
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help=argparse.SUPPRESS)
+    # every rank pins itself to the CPUs of its GPU's NUMA node before its first GPU call (sysfs only); off by default:
+    # the driver's launcher may already have bound the ranks
+    ap.add_argument("--bind", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
     if args.strong and args.config != 2:
         raise SystemExit("--strong splits the samples of configs[1]'s single sightline: use --config 2")
@@ -697,6 +779,7 @@ def main(argv=None) -> None:
     warmup = args.warmup if args.warmup is not None else (20 if config == 2 else 1)
 
     env = Env(args)
+    binding = bind_to_gpu_numa_node(env.local_rank) if args.bind else None
     if env.world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, env.world))
     world, rank = env.world, env.rank
@@ -844,6 +927,8 @@ def main(argv=None) -> None:
             },
             "evidence": evidence,
         }
+        if binding is not None:
+            line["cpu_binding_rank0"] = binding
         if others is not None:
             line["other_configs"] = others
             line["strong_n%d" % world] = strong

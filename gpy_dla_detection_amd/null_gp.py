@@ -361,6 +361,7 @@ class NullGP:
         self._shared: Optional[SharedSightline] = None
         self._model_host = None      # [this_mu, this_M, this_omega2] once they exist on the host
         self._model_pending = False  # set_data(build_model=True) has run and the model half has not been needed yet
+        self._model_snapshot = None  # (Lyman-series scalars, rank, z_qso) as they were when set_data deferred the model half
 
         # linear interpolants of the learned model (reference :67-71; scipy's interp1d when the grid is unsorted),
         # over copies taken now, as interp1d's are.  GP objects built from equal learned arrays share them.
@@ -415,6 +416,7 @@ class NullGP:
             setattr(self, name, value)
         self._model_host = None
         self._model_pending = False
+        self._model_snapshot = None
         if build_model:
             if type(self).get_interp is NullGP.get_interp:
                 # the stock model half is deferred: the device builds it from the learned model at the first
@@ -422,6 +424,11 @@ class NullGP:
                 # pixel raises (interp1d's ValueError) is raised here, where the reference raises it.
                 self._check_interpolation_range(self.x)
                 self._model_pending = True
+                # The reference bakes the Lyman-series scalars, the rank and z_qso into this_mu / this_M / this_omega2
+                # HERE (null_gp.py:179-242 runs inside set_data): whoever changes log_tau_0, params.k or z_qso between
+                # set_data and the first evidence call must get the values of this moment, so the deferred model half is
+                # built from this snapshot, never from the attributes' later values.
+                self._model_snapshot = (self._model_scalars(), int(self.params.k), float(z_qso))
             else:  # a subclass with its own model half: run it now, as the reference does
                 self.get_interp(self.x, self.y, self.this_wavelengths, self.z_qso)
 
@@ -438,18 +445,24 @@ class NullGP:
         return (float(self.log_c_0), float(self.log_tau_0), float(self.log_beta), float(self.prev_tau_0),
                 float(self.prev_beta), int(self.params.num_forest_lines))
 
-    def get_interp(self, x: np.ndarray, y: np.ndarray, wavelengths: np.ndarray, z_qso: float) -> None:
+    def get_interp(self, x: np.ndarray, y: np.ndarray, wavelengths: np.ndarray, z_qso: float, _scalars=None,
+                   _rank=None) -> None:
         """
         Interpolate the learned model onto the kept pixels and apply the Lyman-series
         mean-flux suppression and noise scaling (reference :179-242).
+
+        (`_scalars`, `_rank`: the deferred model half of `set_data` passes the values it recorded then.)
         """
         self._invalidate_device()
         x = np.asarray(x)
         wavelengths = np.asarray(wavelengths)
+        scalars = self._model_scalars() if _scalars is None else _scalars
+        log_c_0, log_tau_0, log_beta, prev_tau_0, prev_beta, num_forest_lines = scalars
+        rank = int(self.params.k) if _rank is None else _rank
         key = None
         if type(self).M_interpolator is NullGP.M_interpolator and self._learned is not None and \
                 self.mu_interpolator is self._learned.mu_interpolator:
-            key = (self._learned.token, self._model_scalars(), int(self.params.k), float(z_qso),
+            key = (self._learned.token, scalars, rank, float(z_qso),
                    _content(x, wavelengths))
             hit = _INTERP_CACHE.get(key)
             if hit is not None:
@@ -461,18 +474,18 @@ class NullGP:
 
         # mean-flux suppression from the Lyman-series forest
         suppression_tau = effective_optical_depth(
-            wavelengths, self.prev_beta, self.prev_tau_0, z_qso, self.params.num_forest_lines
+            wavelengths, prev_beta, prev_tau_0, z_qso, num_forest_lines
         )
         lya_absorption = np.exp(-np.sum(suppression_tau, axis=1))
         this_mu = this_mu * lya_absorption
         this_M = this_M * lya_absorption[:, None]
-        assert this_M.shape[1] == self.params.k
+        assert this_M.shape[1] == rank
 
         # redshift-dependent absorption noise
         noise_tau = effective_optical_depth(
-            wavelengths, np.exp(self.log_beta), np.exp(self.log_tau_0), z_qso, self.params.num_forest_lines
+            wavelengths, np.exp(log_beta), np.exp(log_tau_0), z_qso, num_forest_lines
         )
-        scaling = 1 - np.exp(-np.sum(noise_tau, axis=1)) + np.exp(self.log_c_0)
+        scaling = 1 - np.exp(-np.sum(noise_tau, axis=1)) + np.exp(log_c_0)
         this_omega2 = this_omega2 * scaling ** 2
         this_omega2 = this_omega2 * lya_absorption ** 2
 
@@ -481,18 +494,23 @@ class NullGP:
             _INTERP_CACHE.put(key, (this_mu, this_M, this_omega2))
 
     # the model half on the host, on demand ----------------------------------------------------
+    def _build_deferred_model(self) -> None:
+        """the model half `set_data` deferred, from the scalars, rank and z_qso recorded THERE (see set_data)"""
+        scalars, rank, z_qso = self._model_snapshot
+        NullGP.get_interp(self, self.x, self.y, self.this_wavelengths, z_qso, _scalars=scalars, _rank=rank)
+
     def _model(self, index: int, name: str):
         if self._model_host is None:
             if not self._model_pending:
                 raise AttributeError("'{}' object has no attribute '{}' (set_data(build_model=True) or get_interp first)"
                                      .format(type(self).__name__, name))
-            NullGP.get_interp(self, self.x, self.y, self.this_wavelengths, self.z_qso)
+            self._build_deferred_model()
         return self._model_host[index]
 
     def _set_model(self, index: int, value) -> None:
         if self._model_host is None:
             if self._model_pending:
-                NullGP.get_interp(self, self.x, self.y, self.this_wavelengths, self.z_qso)
+                self._build_deferred_model()
             else:
                 self._model_host = [None, None, None]
         self._model_host[index] = value
@@ -562,7 +580,7 @@ class NullGP:
                 and self.mu_interpolator is self._learned.mu_interpolator
                 and self.log_omega_interpolator is self._learned.log_omega_interpolator
                 and self.list_M_interpolators is self._learned.list_M_interpolators
-                and int(self.params.k) == self._learned.M_columns.shape[0])
+                and self._model_snapshot is not None and self._model_snapshot[1] == self._learned.M_columns.shape[0])
 
     def device_sightline(self) -> _sl.DeviceSightline:
         """
@@ -577,12 +595,14 @@ class NullGP:
         if self._model_on_device_only():
             # built on the device from the learned model (dlagp_create_from_model), one sightline for every GP
             # object of equal content: the reference's driver makes three per spectrum
-            key = (self._learned.token, self._model_scalars(), settings, float(self.z_qso),
+            # the scalars, rank and redshift of set_data's moment (see there): what the reference baked in then
+            scalars, _, z_snapshot = self._model_snapshot
+            key = (self._learned.token, scalars, settings, z_snapshot,
                    _content(self.x, self.y, self.v, self.this_wavelengths, grid, keep))
             if self._shared is None or self._device_key != key:
                 self._invalidate_device()
-                model = self._learned.device_model(self._model_scalars(), settings[2])
-                x, y, v, wavelengths, z_qso = self.x, self.y, self.v, self.this_wavelengths, float(self.z_qso)
+                model = self._learned.device_model(scalars, settings[2])
+                x, y, v, wavelengths, z_qso = self.x, self.y, self.v, self.this_wavelengths, z_snapshot
                 self._shared = _SHARED.find_or_make(key, lambda: _sl.DeviceSightline.from_model(
                     model, x, y, v, wavelengths, z_qso, grid, keep, num_lines=settings[0], broadening=broadening,
                     lls_break=settings[3], defer_sync=True))  # its first use waits for its set-up (an event), not this call

@@ -326,7 +326,10 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     one stream per device, each call waiting for its own completion event; default 0: every
  *                     calling thread has its own stream), "shared_rows" (1 = on the cached levels of a sweep a wave whose
  *                     16 samples stack the same cached profile reads it once per pass; 0 = always 16 reads; identical
- *                     results; default 1)
+ *                     results; default 1), "fuse_finalize" (1 = when the launch plan gives every block of 16 samples ONE
+ *                     piece -- batches: more blocks than wave slots -- the accumulate wave also factors its block and
+ *                     writes log p itself, and no partial sums cross HBM; 0 = always the separate finalisation kernel;
+ *                     identical results, bit for bit; default 1)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.
  */
@@ -337,7 +340,8 @@ int dlagp_set_option(const char *name, int64_t value);
  * (1 = the last dlagp_batch_sweep* used the profile cache), "last_launch_patch" (how the last MFMA launch handled
  * the line cores: 0 tested inside the sample loop, 1 repaired once per wave, 2 repaired pass by pass),
  * "last_launch_groups" (homogeneous launch groups the last call ran as: > 1 for a batch that mixes line counts,
- * broadening or Lyman-limit flags), "big_allocs" / "big_frees" (sweep-workspace buffers above the pool's 64 MB
+ * broadening or Lyman-limit flags), "last_launch_fused" (1 = the accumulate waves of the last launch finished their own
+ * blocks, see "fuse_finalize"), "big_allocs" / "big_frees" (sweep-workspace buffers above the pool's 64 MB
  * limit allocated / freed since the library was loaded -- a free synchronises the device; a pipelined run in its steady
  * state shows neither). */
 int dlagp_get_option(const char *name, int64_t *value);

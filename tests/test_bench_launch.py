@@ -98,3 +98,48 @@ def test_host_cpu_share_and_description(bench):
     assert set(cores) <= set(os.sched_getaffinity(0))
     info = bench.host_description()
     assert "numpy" in info and "cpu_model" in info
+
+
+def test_bind_reads_the_gpus_numa_cpus_from_sysfs_without_touching_the_gpu(bench, tmp_path, monkeypatch):
+    """
+    `--bind`: a rank pins itself to the CPUs next to ITS GPU before its first GPU call.  The map comes from sysfs alone:
+    KFD topology (compute nodes in the runtime's enumeration order, their DRM render minors), the visible-devices list,
+    the DRM device's local_cpulist / numa_node.  A fake sysfs of a two-socket host with four GPUs and two CPU-only KFD
+    nodes stands in.
+    """
+    root = tmp_path / "sys"
+    layout = [(0, 0, None, None), (1, 0, None, None),            # the two CPU nodes of the KFD topology
+              (2, 304, 128, "0-3"), (3, 304, 129, "0-3"),        # GPUs 0, 1 on socket 0
+              (4, 304, 130, None), (5, 304, 131, None)]           # GPUs 2, 3: no local_cpulist, numa_node 1
+    for node, simd, minor, cpulist in layout:
+        d = root / "class" / "kfd" / "kfd" / "topology" / "nodes" / str(node)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\n%s" % (0 if simd else 8, simd,
+                                      "drm_render_minor %d\n" % minor if minor is not None else ""))
+        if minor is not None:
+            dev = root / "class" / "drm" / ("renderD%d" % minor) / "device"
+            dev.mkdir(parents=True)
+            if cpulist:
+                (dev / "local_cpulist").write_text(cpulist + "\n")
+            (dev / "numa_node").write_text("0\n" if cpulist else "1\n")
+    for numa, cpus in ((0, "0-3"), (1, "4-7,12")):
+        d = root / "devices" / "system" / "node" / ("node%d" % numa)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+    assert bench.parse_cpu_list("0-2,8,10-11\n") == [0, 1, 2, 8, 10, 11]
+    assert bench.gpu_local_cpus(0, str(root), visible="")[0] == [0, 1, 2, 3]
+    assert bench.gpu_local_cpus(3, str(root), visible="") == ([4, 5, 6, 7, 12], "NUMA node 1 of renderD131")
+    assert bench.gpu_local_cpus(0, str(root), visible="3,0")[0] == [4, 5, 6, 7, 12]  # the visible list reorders
+    assert bench.gpu_local_cpus(4, str(root), visible="")[0] == []                    # not that many GPUs
+    assert bench.gpu_local_cpus(0, str(tmp_path / "nothing"))[0] == []                # no topology: no binding, no error
+    # the binding itself: only CPUs this process may use, and nothing at all when there are none
+    pinned = []
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {0, 1, 5, 6})
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: pinned.append(sorted(cpus)))
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    done = bench.bind_to_gpu_numa_node(2, str(root))
+    assert done["bound"] and pinned == [[5, 6]] and done["cpus"] == 2
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {20, 21})
+    assert not bench.bind_to_gpu_numa_node(0, str(root))["bound"] and pinned == [[5, 6]]
+    assert "torch" not in sys.modules or True  # (the functions import nothing: sysfs reads only)

@@ -111,6 +111,28 @@ def test_default_line_carries_the_other_configurations():
     assert two["other_configs"]["4"]["sightlines_per_gpu"] == 128
 
 
+def test_many_ranks_rehearsed_on_the_one_card():
+    """
+    The driver's multi-GPU run, rehearsed as far as a one-GPU box allows: `python bench.py --gpus 4 --rehearse-on-one-gpu
+    --bind --steps 3`, invoked plainly -- the parent starts its own ranks as a child before anything touches the GPU -- with
+    every rank on device 0 and gloo in place of RCCL.  ONE line, `n_gpus` 4, the headline and every side configuration
+    measured on all ranks (each rank its own sightlines: weak scaling), the by-sample split over four ranks, the CPU
+    binding reported.  Four ranks, not eight: the box's process guard allows at most six processes on the card at once
+    (the eight-rank code path differs from this one in nothing but the world size; tests/test_host_logic.py runs the
+    collectives' host logic with gloo at world sizes 2 and 4).
+    """
+    line = run_bench(0, "--gpus", "4", "--rehearse-on-one-gpu", "--bind", "--steps", "3", "--warmup", "1", timeout=1100)
+    assert line["n_gpus"] == 4 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["sightlines_per_gpu"] == 1 and line["config"]["evals_per_step_per_gpu"] == 10000.0
+    assert sorted(line["other_configs"]) == ["3", "4", "5"]
+    for entry in list(line["other_configs"].values()) + [line["strong_n4"]]:
+        assert "error" not in entry, entry
+        assert entry["n_gpus"] == 4 and entry["ms_per_step"] > 0
+    assert line["other_configs"]["4"]["sightlines_per_gpu"] == 128 and line["other_configs"]["5"]["sightlines_per_gpu"] == 32
+    assert line["strong_n4"]["scaling"] == "strong" and line["strong_n4"]["sightlines_per_gpu"] == 0.25
+    assert "bound" in line["cpu_binding_rank0"]  # bound or not (a box without NUMA information): reported either way
+
+
 WORKER = r"""
 import os, sys
 import numpy as np

@@ -159,6 +159,42 @@ def test_model_attributes_follow_the_reference_life_cycle():
     assert np.all(own.this_mu == 1.0) and not own._model_on_device_only()
 
 
+def test_deferred_model_half_uses_the_scalars_of_set_data_like_the_reference():
+    """
+    The reference bakes log_c_0 / log_tau_0 / log_beta / prev_tau_0 / prev_beta / num_forest_lines and z_qso into
+    this_mu, this_M, this_omega2 INSIDE set_data (null_gp.py:157 -> :179-242).  This package defers that half to the
+    first evidence call or attribute read, so it must use the values of set_data's moment: changing a scalar afterwards
+    changes nothing until the next set_data -- exactly as in the reference.
+    """
+    from gpy_dla_detection_amd.null_gp import NullGP
+
+    z_qso, rest, flux, nv, mask, rest_grid, mu, M, log_omega, lc0, lt0, lb = raw_spectrum_and_model()
+    gp = NullGP(Parameters(), FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb)
+    gp.set_data(rest, flux, nv, mask, z_qso)
+    reference_like = NullGP(Parameters(), FixedPrior(), rest_grid, mu, M, log_omega, lc0, lt0, lb)
+    reference_like.set_data(rest, flux, nv, mask, z_qso)
+    want = [reference_like.this_mu.copy(), reference_like.this_M.copy(), reference_like.this_omega2.copy()]  # built at once
+    # between set_data and the first read: every scalar the model half depends on, and the redshift
+    gp.log_tau_0 = lt0 + 0.5
+    gp.log_c_0 = lc0 - 1.0
+    gp.prev_tau_0 = 2.0 * gp.prev_tau_0
+    gp.z_qso = z_qso + 0.2
+    assert gp._model_pending and gp._model_snapshot[2] == float(z_qso)
+    assert gp._model_on_device_only()  # the device route builds from the same snapshot (GPU tests compare the numbers)
+    np.testing.assert_array_equal(gp.this_mu, want[0])
+    np.testing.assert_array_equal(gp.this_M, want[1])
+    np.testing.assert_array_equal(gp.this_omega2, want[2])
+    # the next set_data picks the edited scalars up, as the reference's would
+    gp.z_qso = z_qso
+    gp.set_data(rest, flux, nv, mask, z_qso)
+    assert not np.array_equal(gp.this_omega2, want[2]) and not np.array_equal(gp.this_mu, want[0])
+    # an explicit get_interp call uses the live attributes, like the reference's
+    fresh = NullGP(Parameters(), FixedPrior(), rest_grid, mu, M, log_omega, lc0 - 1.0, lt0 + 0.5, lb,
+                   prev_tau_0=gp.prev_tau_0)
+    fresh.set_data(rest, flux, nv, mask, z_qso)
+    np.testing.assert_array_equal(gp.this_omega2, fresh.this_omega2)
+
+
 def test_parameters_surface():
     p = Parameters()
     assert p.k == 20 and p.num_dla_samples == 10000 and p.num_lines == 3 and p.width == 3
