@@ -70,7 +70,7 @@ def measured_hbm_traffic(config: int):
     HBM bytes per accumulate-kernel launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, collected in
     their own rocprofv3 runs of this same command, gfx950 read-side correction applied).  None when absent.
     """
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 data = json.load(f)
@@ -624,6 +624,7 @@ class Workload:
             self.uniforms = (torch.from_numpy(parallel.resampling_uniforms(nb, self.max_dlas, S, seed=0)).to(env.device)
                              if self.max_dlas > 1 else None)
             self.sample_ll = torch.empty((nb, self.max_dlas, S), **f64)
+            self.sample_ll_sub = torch.empty((nb, 1, S), **f64) if self.config in (3, 4) else None
             self.base = torch.zeros((nb, max(self.max_dlas - 1, 1), S), dtype=torch.int32, device=env.device)
         return self
 
@@ -656,9 +657,10 @@ class Workload:
             batch.sweep_device(S, 4, z, self.nhi_dla.data_ptr(), 0, MIN_Z_SEPARATION, self.uniforms.data_ptr(), ev,
                                self.sample_ll.data_ptr(), self.base.data_ptr(), stream)
             return
-        batch.sweep_device(S, 1, z, self.nhi_sub.data_ptr(), 0, MIN_Z_SEPARATION, 0, ev, self.sample_ll.data_ptr(), 0, stream)
-        batch.sweep_device(S, 1, z, self.nhi_dla.data_ptr(), 0, MIN_Z_SEPARATION, 0, ev + 8 * nb,
-                           self.sample_ll.data_ptr(), 0, stream)
+        # the sub-DLA model and DLA(1) sample the same redshifts: one call, and -- the batch's shape allowing -- one launch
+        # with one Voigt optical depth per QMC point for both (dlagp_batch_two_model_sweep_device)
+        batch.two_model_sweep_device(S, 1, z, self.nhi_sub.data_ptr(), 0, self.nhi_dla.data_ptr(), 0, MIN_Z_SEPARATION, 0,
+                                     ev, self.sample_ll_sub.data_ptr(), ev + 8 * nb, self.sample_ll.data_ptr(), 0, stream)
         if config == 4:  # NullGP.log_model_evidence of every member: one launch, host-pointer entry
             self.evidences[slot * self.per_step + 2 * nb: slot * self.per_step + 3 * nb] = \
                 torch.from_numpy(batch.nulls()).to(env.device)
@@ -682,7 +684,7 @@ class Workload:
             dev.close()
         self.devs = self.batch = None
         for name in ("z", "nhi_dla", "nhi_sub", "evidences", "gathered", "out", "local", "everything", "uniforms",
-                     "sample_ll", "base"):
+                     "sample_ll", "sample_ll_sub", "base"):
             if hasattr(self, name):
                 delattr(self, name)
 

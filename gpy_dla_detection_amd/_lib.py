@@ -51,6 +51,9 @@ SIGNATURES = {
                                   POINTER(ctypes.c_int32)]),
     "dlagp_batch_sweep_device": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_double, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dlagp_batch_two_model_sweep_device": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                                   c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                   c_void_p]),
     "dlagp_batch_model_evidences": (c_int, [c_void_p, c_int64, c_int, _dp, _dp, c_int64, _dp, _dp, c_int64, c_double,
                                             _dp, _dp, _dp, _dp, _dp, _dp, POINTER(ctypes.c_int32)]),
     "dlagp_batch_model_evidences_start": (c_int, [c_void_p, c_int64, c_int, _dp, _dp, c_int64, _dp, _dp, c_int64, c_double]),

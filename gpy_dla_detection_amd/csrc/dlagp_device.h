@@ -95,10 +95,24 @@ struct SampleSource {
     long sample_offset;
     long table_S;
     long cache_group_stride;  // doubles from one group of 16 points to the next: 16 cache_stride
+    // Pair launch (round 5).  The sub-DLA model and level 1 of the DLA model are both ONE absorber per sample at the SAME
+    // redshift samples -- MATLAB: one `sample_z_dlas(i)` for both (multi_dlas/process_qsos_multiple_dlas_meanflux.m:335-373);
+    // Python: dla_samples.py:94-104 and subdla_samples.py:115-125 are the same formula on the same offsets -- and differ
+    // only in the column density.  One launch evaluates both: a wave's 16 MFMA rows are 8 QMC points x 2 column
+    // densities, the Voigt optical depth tau(z, lambda) is formed once per point (three quarters of the sample loop) and
+    // exponentiated twice.  pair_S > 0 marks such a launch: its S is 16 ceil(pair_S / 8) "virtual" samples, virtual
+    // sample v = 16 block + r is point 8 block + (r & 7) of model r >> 3 (0: nhi, 1: nhi2); indexed mode, kd = 1.
+    const double *nhi2;  // the second model's column densities
+    long nhi2_stride;    // 0 when all sightlines share one table, else the table's stride (as nhi_stride)
+    long pair_S;         // QMC points per sightline of a pair launch; 0 = an ordinary launch
 };
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ long sample_point(const SampleSource &src, long b, long s, int j, long S, int kd) {
+    if (src.pair_S) {  // pair launch: the point behind virtual sample s (rows beyond the last point repeat it; never stored)
+        const long p = (s >> 4) * 8 + (s & 7);
+        return p < src.pair_S ? p : src.pair_S - 1;
+    }
     if (!src.indexed) return (b * S + s) * kd + j;
     const long T = src.table_S ? src.table_S : S;
     const long g = s + src.sample_offset;
@@ -106,10 +120,12 @@ __device__ __forceinline__ long sample_point(const SampleSource &src, long b, lo
 }
 __device__ __forceinline__ double sample_z(const SampleSource &src, long b, long s, int j, long S, int kd) {
     const long p = sample_point(src, b, s, j, S, kd);
+    if (src.pair_S) return src.z[b * src.pair_S + p];
     return src.indexed ? src.z[b * (src.table_S ? src.table_S : S) + p] : src.z[p];
 }
 __device__ __forceinline__ double sample_nhi(const SampleSource &src, long b, long s, int j, long S, int kd) {
     const long p = sample_point(src, b, s, j, S, kd);
+    if (src.pair_S) return (s & 8) ? src.nhi2[b * src.nhi2_stride + p] : src.nhi[b * src.nhi_stride + p];
     return src.indexed ? src.nhi[b * src.nhi_stride + p] : src.nhi[p];
 }
 #endif

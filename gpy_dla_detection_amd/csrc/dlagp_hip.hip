@@ -326,6 +326,7 @@ struct Workspace {
     DeviceBuffer level_ll, cdf, alive, uniforms, evidences, sample_ll, base;
     DeviceBuffer cache;  // profile cache of the multi-level sweep, [nb][S][max n_slots]
     DeviceBuffer sub_z, sub_nhi, sub_evidences, sub_ll;  // the one-absorber model of dlagp_batch_model_evidences
+    DeviceBuffer sub_level_ll, sub_alive;  // pair launches: the one-absorber model's raw level and its per-sightline flags
     PinnedBuffer stage;           // host staging of the host-pointer entry points
     void release() {
         stage.release();
@@ -347,6 +348,8 @@ struct Workspace {
         sub_nhi.release();
         sub_evidences.release();
         sub_ll.release();
+        sub_level_ll.release();
+        sub_alive.release();
     }
 };
 
@@ -492,6 +495,9 @@ struct dlagp_batch {
         double min_z_separation = 0.0;
         size_t stage_used = 0;          // staging bytes of the first phase: the second phase's lie behind them
         hipStream_t stream = nullptr;   // the calling thread's kernel stream: _finish must come from the same thread
+        bool pair = false;              // the sub-DLA sweep rode in level 1's launch (pair launch): _finish resumes that sweep
+        int64_t sub_nhi_stride = 0;
+        int cached = 0;                 // ... and whether it keeps level-1 profiles (decided in _start)
     } pending;
 };
 
@@ -569,7 +575,7 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
     hipExtLaunchKernelGGL((accumulate_mfma<__VA_ARGS__>), grid, dim3(DLAGP_MFMA_THREADS), (uint32_t)prep_lds, stream, \
                           ev_start, ev_stop, 0u, table,                                                             \
                        plan->passes(), plan->items(), nb, S, kd, src, part, \
-                       status, launch_flags, fused_out)
+                       status, launch_flags, fused_out, fused_out2)
 
 // how the line cores are handled (kernels_mfma.h): 0 tested for inside the sample loop; 1 one absorber per sample,
 // repaired once per wave; 2 several absorbers per sample, repaired pass by pass.  1 and 2 need three lines and a
@@ -582,7 +588,8 @@ static int patch_mode(const LaunchGroup &g, int kd) {
 template <int LINES, bool BROADEN>
 static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table, const LaunchPlan *plan, int nb,
                         long S, int kd, int num_lines, const SampleSource &src, double *part, int *status,
-                        int patch, bool lls, int launch_flags, hipEvent_t ev_start, hipEvent_t ev_stop, double *fused_out) {
+                        int patch, bool lls, int launch_flags, hipEvent_t ev_start, hipEvent_t ev_stop, double *fused_out,
+                        double *fused_out2) {
     // 16 samples + one spare row that the look-ahead of the sample loop may read; PATCH 2: 3 ints per (sample, absorber)
     const size_t prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * kd * (lls ? 6 : (LINES > 0 ? LINES : num_lines) + 1) * sizeof(double) +
                             (patch == 2 ? (size_t)DLAGP_MFMA_GROUP * kd * 3 * sizeof(int) : 0);
@@ -598,6 +605,13 @@ static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table
         // the production flavours (3 lines, broadening) also exist with the wave's own finalisation (fused_eligible)
         if (patch == 1) {  // line cores repaired outside the sample loop (kd == 1, uniform grid)
             if constexpr (BROADEN) {
+                if (src.pair_S) {  // pair launch (two one-absorber models, shared optical depth)
+                    if (fused_out && src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, true, false, 1, 1, false, true, true);
+                    else if (fused_out) DLAGP_LAUNCH_MFMA(3, true, false, 0, 1, false, true, true);
+                    else if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, true, false, 1, 1, false, false, true);
+                    else DLAGP_LAUNCH_MFMA(3, true, false, 0, 1, false, false, true);
+                    return;
+                }
                 if (fused_out && src.cache_mode == 1) {
                     DLAGP_LAUNCH_MFMA(3, true, false, 1, 1, false, true);
                     return;
@@ -650,6 +664,19 @@ static bool fused_eligible(const LaunchGroup &g, const LaunchPlan *plan, int pat
     return g.num_lines == 3 && g.broadening && !g.lls_break && (patch == 1 || (patch == 2 && cache_mode == 0));
 }
 
+// Pair launches (SampleSource::pair_S): the sub-DLA sweep and level 1 of the DLA sweep in ONE launch of 16 ceil(S / 8)
+// virtual samples when both models sample the same redshifts.  Needs the one-absorber production kernel (3 lines,
+// broadening, cores repaired once per wave, rank 20, a homogeneous batch); finished by the waves themselves on single-piece
+// plans and by finalize_rank20 otherwise.  Option "pair_models" = 0 keeps the two launches (the cross-check).
+static Option g_opt_pair_models = 1;
+static Option g_last_sweep_paired = 0;
+static int64_t pair_virtual_samples(int64_t S) { return 16 * ((S + 7) / 8); }
+static bool pair_eligible(LaunchGroup &g, int64_t S) {
+    if (!g_opt_pair_models || !g.parts.empty() || (g_opt_debug & 2)) return false;
+    return mfma_path_serves(g, 1) && patch_mode(g, 1) == 1 && g.broadening && !g.lls_break && g.col_groups == 1 &&
+           g.k == DLAGP_FIN_K && S >= 1;
+}
+
 // finalisation of a general rank (above 20) from column-major rows: one wave per sample, or (option finalize_wave = 0,
 // the cross-check) one thread per sample
 static void launch_finalize_general(hipStream_t stream, const double *part, int nsplit, long rows, long S,
@@ -669,7 +696,7 @@ static void launch_finalize_general(hipStream_t stream, const double *part, int 
 // group's own unless the caller shares one between the parts of a heterogeneous batch); `keep_status`: this launch
 // must not clear it (an earlier part of the same level may have raised it).
 static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src, double *d_out, hipStream_t stream,
-                      int *status_shared = nullptr, bool keep_status = false) {
+                      int *status_shared = nullptr, bool keep_status = false, double *d_out2 = nullptr) {
     if (S <= 0) return DLAGP_OK;
     Workspace &ws = g.ws;
     const int nb = (int)g.ctxs.size();
@@ -696,6 +723,9 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
     const int patch = !use_mfma || src.cache_mode == 2 ? 0 : patch_mode(g, kd);
     // single-piece plans: the accumulate waves finish their own blocks, no partial sums cross HBM (and none are allocated)
     const bool fused = use_mfma && fused_eligible(g, plan, patch, src.cache_mode);
+    if (src.pair_S && !(use_mfma && patch == 1 && d_out2 && kd == 1 && g.num_lines == 3 && g.broadening && !g.lls_break &&
+                        g.col_groups == 1 && g.k == DLAGP_FIN_K && !(g_opt_debug & 2)))
+        return fail(DLAGP_EINVAL, "internal: a pair launch needs the one-absorber 3-line MFMA kernel (see pair_eligible)");
     const size_t part_bytes = fused ? 0
                               : grouped ? (size_t)g.col_groups * nparts * nblocks * DLAGP_MFMA_ROW_WIDTH * 16 * sizeof(double)
                                         : (size_t)nparts * nblocks * g.row_width * 16 * sizeof(double);
@@ -738,6 +768,7 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
         const bool lines3 = g.num_lines == 3;
         g_last_launch_patch = patch;
         double *fused_out = fused ? d_out : nullptr;
+        double *fused_out2 = src.pair_S ? d_out2 : nullptr;
         // the waves raise the non-PD flag themselves: cleared here, in front of the launch (the unfused kernel's first
         // workgroup clears it, long before the finalisation kernel can raise it)
         if (fused && !keep_status) HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), stream));
@@ -750,12 +781,13 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
             const size_t prep_lds = (size_t)(DLAGP_MAX_ABSORBERS * 16) * sizeof(int);
             if (fused) DLAGP_LAUNCH_MFMA(3, true, false, 2, 0, false, true);
             else DLAGP_LAUNCH_MFMA(3, true, false, 2);
+            (void)fused_out2;
         } else if (g.broadening) {
-            if (lines3) launch_mfma<3, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags, ev_start, ev_stop, fused_out);
-            else launch_mfma<0, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags, ev_start, ev_stop, fused_out);
+            if (lines3) launch_mfma<3, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags, ev_start, ev_stop, fused_out, fused_out2);
+            else launch_mfma<0, true>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags, ev_start, ev_stop, fused_out, fused_out2);
         } else {
-            if (lines3) launch_mfma<3, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags, ev_start, ev_stop, fused_out);
-            else launch_mfma<0, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags, ev_start, ev_stop, fused_out);
+            if (lines3) launch_mfma<3, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, patch, lls, launch_flags, ev_start, ev_stop, fused_out, fused_out2);
+            else launch_mfma<0, false>(grid, stream, table, plan, nb, S, kd, g.num_lines, src, part, status, false, false, launch_flags, ev_start, ev_stop, fused_out, fused_out2);
         }
         HIP_TRY(hipGetLastError());
     } else {
@@ -795,7 +827,7 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
                          : (use_mfma ? finalize_rank20<false, true> : finalize_rank20<false, false>);
         hipLaunchKernelGGL(fin, dim3((unsigned)nblocks), dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
                            ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
-                           plan ? plan->counts() : nullptr);
+                           plan ? plan->counts() : nullptr, src.pair_S ? d_out2 : nullptr, (long)src.pair_S);
     } else {
         launch_finalize_general(stream, ws.part.as<const double>(), nparts, rows, (long)S, table, d_out, status,
                                 plan ? plan->counts() : nullptr);
@@ -1052,9 +1084,22 @@ static int launch_level_finish(int nb, hipStream_t stream, const double *ll, lon
 // The whole occupation sweep of reference dla_gp.py:92-225 for every sightline of the group, enqueued on
 // `stream` with no host round trip between levels: per level one accumulate + finalize + level_finish.
 // All pointers are device addresses; d_base may not be NULL when max_dlas > 1.
+// `pair`: the one-absorber model that shares the sweep's redshift samples (the sub-DLA model beside the DLA model): its
+// sweep rides in level 1's launch (pair launch, pair_eligible), its level is finished right behind it.
+// `phase`: SWEEP_ALL; or the two halves of the two-phase call -- SWEEP_START: initialisation, level 1's launch, the paired
+// model's evidence (none of which needs random numbers); SWEEP_FINISH: level 1's evidence and resampling, the deeper levels.
+// `cache_decision`: START writes whether the profile cache is in use, FINISH reads it (the decision depends on the free
+// memory of the moment).
+struct PairSpec {
+    const double *d_nhi;
+    int64_t nhi_stride;
+    double *d_evidences, *d_sample_ll;
+};
+enum { SWEEP_ALL = 0, SWEEP_START = 1, SWEEP_FINISH = 2 };
 static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d_sample_z, const double *d_sample_nhi,
                         int64_t nhi_stride, double min_z_separation, const double *d_uniforms, double *d_evidences,
-                        double *d_sample_ll, int *d_base, hipStream_t stream, bool keep_sticky_flag = false) {
+                        double *d_sample_ll, int *d_base, hipStream_t stream, bool keep_sticky_flag = false,
+                        const PairSpec *pair = nullptr, int phase = SWEEP_ALL, int *cache_decision = nullptr) {
     Workspace &ws = g.ws;
     const int nb = (int)g.ctxs.size();
     const size_t rows = (size_t)nb * S;
@@ -1063,14 +1108,22 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     if ((rc = grow(g, ws.level_ll, rows * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.cdf, rows * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.alive, (size_t)(nb + 1) * sizeof(int)))) return rc;  // [nb] = sticky non-PD flag
+    if (pair && (rc = grow(g, ws.sub_level_ll, rows * sizeof(double)))) return rc;
+    if (pair && (rc = grow(g, ws.sub_alive, (size_t)(nb + 1) * sizeof(int)))) return rc;
     const long n_ll = (long)rows * max_dlas, n_base = (long)rows * (max_dlas - 1);
     g.last_stream = stream;  // the fills below already use the group's scratch
     g.launched = true;
-    // a second sweep of the same call adds to the first one's non-PD flag (keep_sticky_flag)
-    hipLaunchKernelGGL(sweep_init, dim3((unsigned)std::max<long>(1, std::min<long>((std::max(n_ll, n_base) + 255) / 256, 2048))),
-                       dim3(256), 0, stream, d_sample_ll, n_ll, d_evidences, (long)nb * max_dlas, ws.alive.as<int>(),
-                       (long)nb, keep_sticky_flag ? 0 : 1, n_base > 0 ? d_base : nullptr, n_base);
-    HIP_TRY(hipGetLastError());
+    if (phase != SWEEP_FINISH) {
+        // a second sweep of the same call adds to the first one's non-PD flag (keep_sticky_flag)
+        hipLaunchKernelGGL(sweep_init, dim3((unsigned)std::max<long>(1, std::min<long>((std::max(n_ll, n_base) + 255) / 256, 2048))),
+                           dim3(256), 0, stream, d_sample_ll, n_ll, d_evidences, (long)nb * max_dlas, ws.alive.as<int>(),
+                           (long)nb, keep_sticky_flag ? 0 : 1, n_base > 0 ? d_base : nullptr, n_base);
+        if (pair)  // the paired model's own state: one level, its own alive flags (the sticky flag is the sweep's)
+            hipLaunchKernelGGL(sweep_init, dim3((unsigned)std::max<long>(1, std::min<long>(((long)rows + 255) / 256, 2048))), dim3(256),
+                               0, stream, pair->d_sample_ll, (long)rows, pair->d_evidences, (long)nb, ws.sub_alive.as<int>(),
+                               (long)nb, 1, (int *)nullptr, 0L);
+        HIP_TRY(hipGetLastError());
+    }
     const SampleSource src0{d_sample_z, d_sample_nhi, d_base, 1, (long)nhi_stride, max_dlas - 1, nullptr, nullptr, 0, 0, 0, 0, 0};
     // the homogeneous launch groups of this sweep: the batch itself, or the parts of a batch of mixed flavours
     struct Target {
@@ -1092,6 +1145,7 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
         Workspace &tws = tg.ws;
         // (ranks above 20 run every block once per column group: each would store / stream the rows again -- they recompute)
         bool use_cache = g_opt_profile_cache != 0 && max_dlas > 1 && tg.col_groups == 1;
+        if (phase == SWEEP_FINISH && cache_decision) use_cache = use_cache && *cache_decision != 0;  // as START decided
         for (int level = 0; level < max_dlas; ++level) use_cache = use_cache && mfma_path_serves(tg, level + 1, level > 0);
         // tiled layout (dlagp_device.h): rows padded to whole tiles of 64 slots, points to whole groups of 16
         const size_t cache_row = ((size_t)tg.max_slots + DLAGP_CACHE_TILE_SLOTS - 1) / DLAGP_CACHE_TILE_SLOTS * DLAGP_CACHE_TILE_SLOTS;
@@ -1122,15 +1176,37 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
         }
     }
     g_last_sweep_cached = all_cached ? 1 : 0;
+    if (cache_decision && phase != SWEEP_FINISH) *cache_decision = all_cached ? 1 : 0;
+    g_last_sweep_paired = pair ? 1 : 0;
     for (int level = 0; level < max_dlas; ++level) {
         bool first = true;
+        const bool launch = !(phase == SWEEP_FINISH && level == 0);  // FINISH: level 1 was launched by START
         for (Target &t : targets) {
+            if (!launch) break;
             t.src.cache_mode = t.use_cache ? (level == 0 ? 1 : 2) : 0;
-            if (g.parts.empty()) rc = launch_one(g, S, level + 1, t.src, ws.level_ll.as<double>(), stream);
+            if (pair && level == 0) {
+                // both one-absorber models in one launch: rows 0..7 of every wave the paired model, rows 8..15 this sweep's
+                SampleSource both = t.src;
+                both.nhi = pair->d_nhi;
+                both.nhi_stride = (long)pair->nhi_stride;
+                both.nhi2 = d_sample_nhi;
+                both.nhi2_stride = (long)nhi_stride;
+                both.pair_S = (long)S;
+                rc = launch_one(g, pair_virtual_samples(S), 1, both, ws.sub_level_ll.as<double>(), stream, nullptr, false,
+                                ws.level_ll.as<double>());
+            } else if (g.parts.empty()) rc = launch_one(g, S, level + 1, t.src, ws.level_ll.as<double>(), stream);
             else rc = launch_one(*t.g, S, level + 1, t.src, ws.level_ll.as<double>(), stream, ws.status.as<int>(), !first);
             if (rc) return rc;
             first = false;
         }
+        if (pair && level == 0 && launch) {
+            const SampleSource sub0{d_sample_z, pair->d_nhi, nullptr, 1, (long)pair->nhi_stride, 0, nullptr, nullptr, 0, 0, 0, 0, 0};
+            if ((rc = launch_level_finish(nb, stream, ws.sub_level_ll.as<const double>(), (long)S, 0, 1, sub0, min_z_separation,
+                                          nullptr, pair->d_sample_ll, pair->d_evidences, nullptr, ws.cdf.as<double>(),
+                                          ws.sub_alive.as<int>(), ws.status.as<const int>(), ws.alive.as<int>() + nb)))
+                return rc;
+        }
+        if (phase == SWEEP_START) return DLAGP_OK;  // level 1's own evidence and resampling wait for the uniforms
         if ((rc = launch_level_finish(nb, stream, ws.level_ll.as<const double>(), (long)S, level, max_dlas, src0,
                                       min_z_separation, d_uniforms, d_sample_ll, d_evidences, d_base, ws.cdf.as<double>(),
                                       ws.alive.as<int>(), ws.status.as<const int>(), ws.alive.as<int>() + nb)))
@@ -1918,6 +1994,34 @@ int dlagp_batch_sweep_device(dlagp_batch *batch, int64_t S, int max_dlas, const 
                         d_evidences, d_sample_ll, d_base_inds, static_cast<hipStream_t>(stream));
 } DLAGP_CATCH_INT("dlagp_batch_sweep_device")
 
+int dlagp_batch_two_model_sweep_device(dlagp_batch *batch, int64_t S, int max_dlas, const double *d_sample_z,
+                                       const double *d_sub_nhi, int64_t sub_nhi_stride, const double *d_sample_nhi,
+                                       int64_t nhi_stride, double min_z_separation, const double *d_uniforms,
+                                       double *d_sub_evidences, double *d_sub_sample_ll, double *d_evidences,
+                                       double *d_sample_ll, int32_t *d_base_inds, void *stream_) try {
+    int rc = check_sweep_args(batch, S, max_dlas, d_sample_z, d_sample_nhi, nhi_stride, d_uniforms, d_evidences);
+    if (rc) return rc;
+    if ((rc = check_sweep_args(batch, S, 1, d_sample_z, d_sub_nhi, sub_nhi_stride, nullptr, d_sub_evidences))) return rc;
+    if (!d_sample_ll || !d_sub_sample_ll || (max_dlas > 1 && !d_base_inds))
+        return fail(DLAGP_EINVAL, "the device variant needs the sample_ll arrays and d_base_inds (they are its working state)");
+    cancel_pending(batch);
+    LaunchGroup &g = batch->group;
+    HIP_TRY(hipSetDevice(g.device));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if ((rc = enter_stream(g, stream))) return rc;
+    if (pair_eligible(g, S)) {
+        const PairSpec sub{d_sub_nhi, sub_nhi_stride, d_sub_evidences, d_sub_sample_ll};
+        return sweep_levels(g, S, max_dlas, d_sample_z, d_sample_nhi, nhi_stride, min_z_separation, d_uniforms, d_evidences,
+                            d_sample_ll, d_base_inds, stream, false, &sub);
+    }
+    // not a pair launch's shape (a single sightline, a mixed batch, another line count ...): the two sweeps one after the other
+    rc = sweep_levels(g, S, 1, d_sample_z, d_sub_nhi, sub_nhi_stride, min_z_separation, nullptr, d_sub_evidences, d_sub_sample_ll,
+                      nullptr, stream);
+    if (rc) return rc;
+    return sweep_levels(g, S, max_dlas, d_sample_z, d_sample_nhi, nhi_stride, min_z_separation, d_uniforms, d_evidences,
+                        d_sample_ll, d_base_inds, stream, /*keep_sticky_flag=*/true);
+} DLAGP_CATCH_INT("dlagp_batch_two_model_sweep_device")
+
 int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double *sample_z, const double *sample_nhi,
                       int64_t nhi_stride, double min_z_separation, const double *uniforms, double *evidences,
                       double *sample_ll, int32_t *base_inds) try {
@@ -1993,9 +2097,15 @@ int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dla
     if ((rc = grow(g, ws.out, nb * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.alive, (nb + 1) * sizeof(int)))) return rc;  // [nb]: the sweeps' sticky non-PD flag
     if ((rc = grow(g, ws.status, sizeof(int)))) return rc;            // the null launch's
+    if ((rc = grow(g, ws.sub_level_ll, rows * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.sub_alive, (nb + 1) * sizeof(int)))) return rc;
+    // Both models at the same redshift samples (the reference's loaders build them by one formula from one set of offsets,
+    // dla_samples.py:94-104 / subdla_samples.py:115-125; compared by content here): the sub-DLA sweep rides in level 1's
+    // launch of the DLA sweep, one optical depth per QMC point for both (pair launch).
+    const bool pair = std::memcmp(sub_sample_z, sample_z, rows * sizeof(double)) == 0 && pair_eligible(g, S);
     Transfers tr(ws.stage, g.device);
     const hipStream_t stream = tr.compute;
-    tr.upload(ws.sub_z.ptr, sub_sample_z, rows * sizeof(double));
+    if (!pair) tr.upload(ws.sub_z.ptr, sub_sample_z, rows * sizeof(double));
     tr.upload(ws.sub_nhi.ptr, sub_sample_nhi, n_sub_nhi * sizeof(double));
     tr.upload(ws.z.ptr, sample_z, rows * sizeof(double));
     tr.upload(ws.nhi.ptr, sample_nhi, n_nhi * sizeof(double));
@@ -2004,9 +2114,18 @@ int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dla
     const size_t second_phase = (n_base + 2 * nb + rows + nb * max_dlas + rows * max_dlas) * sizeof(double) +
                                 n_base * sizeof(int32_t) + 2 * sizeof(int) + 16 * 256;
     if ((rc = tr.reserve(second_phase)) || (rc = tr.run_uploads())) return rc;
-    // model order of the reference's model list (run_bayes_select.py:189): the one-absorber model before the DLA model
-    rc = sweep_levels(g, S, 1, ws.sub_z.as<double>(), ws.sub_nhi.as<double>(), sub_nhi_stride, min_z_separation, nullptr,
-                      ws.sub_evidences.as<double>(), ws.sub_ll.as<double>(), nullptr, stream);
+    batch->pending.pair = pair;
+    batch->pending.sub_nhi_stride = sub_nhi_stride;
+    if (pair) {
+        const PairSpec sub{ws.sub_nhi.as<double>(), sub_nhi_stride, ws.sub_evidences.as<double>(), ws.sub_ll.as<double>()};
+        rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), nhi_stride, min_z_separation, nullptr,
+                          ws.evidences.as<double>(), ws.sample_ll.as<double>(), ws.base.as<int>(), stream, false, &sub,
+                          SWEEP_START, &batch->pending.cached);
+    } else {
+        // model order of the reference's model list (run_bayes_select.py:189): the one-absorber model before the DLA model
+        rc = sweep_levels(g, S, 1, ws.sub_z.as<double>(), ws.sub_nhi.as<double>(), sub_nhi_stride, min_z_separation, nullptr,
+                          ws.sub_evidences.as<double>(), ws.sub_ll.as<double>(), nullptr, stream);
+    }
     if (rc) return rc;
     batch->pending.active = true;
     batch->pending.S = S;
@@ -2053,9 +2172,17 @@ int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniform
     if ((rc = tr.reserve())) return rc;
     if (ws.stage.bytes != capacity) return fail(DLAGP_EDEVICE, "internal: the staging buffer grew between the two phases");
     if ((rc = tr.run_uploads())) return rc;
-    rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), batch->pending.nhi_stride,
-                      batch->pending.min_z_separation, ws.uniforms.as<double>(), ws.evidences.as<double>(),
-                      ws.sample_ll.as<double>(), ws.base.as<int>(), stream, /*keep_sticky_flag=*/true);
+    if (batch->pending.pair) {
+        const PairSpec sub{ws.sub_nhi.as<double>(), batch->pending.sub_nhi_stride, ws.sub_evidences.as<double>(), ws.sub_ll.as<double>()};
+        rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), batch->pending.nhi_stride,
+                          batch->pending.min_z_separation, ws.uniforms.as<double>(), ws.evidences.as<double>(),
+                          ws.sample_ll.as<double>(), ws.base.as<int>(), stream, /*keep_sticky_flag=*/true, &sub, SWEEP_FINISH,
+                          &batch->pending.cached);
+    } else {
+        rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), batch->pending.nhi_stride,
+                          batch->pending.min_z_separation, ws.uniforms.as<double>(), ws.evidences.as<double>(),
+                          ws.sample_ll.as<double>(), ws.base.as<int>(), stream, /*keep_sticky_flag=*/true);
+    }
     if (rc) return rc;
     // the null model last: its launch leaves its own flag in ws.status, which the sweeps' launches would reset
     rc = launch_sweep(g, 1, 0, SampleSource{nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0},
@@ -2240,6 +2367,7 @@ int dlagp_set_option(const char *name, int64_t value) try {
     else if (!strcmp(name, "negative_noise_mfma")) g_opt_negative_noise_mfma = value != 0;
     else if (!strcmp(name, "finalize_wave")) g_opt_finalize_wave = value != 0;
     else if (!strcmp(name, "fuse_finalize")) g_opt_fuse_finalize = value != 0;
+    else if (!strcmp(name, "pair_models")) g_opt_pair_models = value != 0;
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 } DLAGP_CATCH_INT("dlagp_set_option")
@@ -2284,6 +2412,8 @@ int dlagp_get_option(const char *name, int64_t *value) try {
     else if (!strcmp(name, "finalize_wave")) *value = g_opt_finalize_wave;
     else if (!strcmp(name, "fuse_finalize")) *value = g_opt_fuse_finalize;
     else if (!strcmp(name, "last_launch_fused")) *value = g_last_launch_fused;
+    else if (!strcmp(name, "pair_models")) *value = g_opt_pair_models;
+    else if (!strcmp(name, "last_sweep_paired")) *value = g_last_sweep_paired;
     else if (!strcmp(name, "big_allocs")) *value = g_stat_big_allocs;
     else if (!strcmp(name, "big_frees")) *value = g_stat_big_frees;
     else if (!strcmp(name, "last_launch_path")) *value = g_last_launch_path;

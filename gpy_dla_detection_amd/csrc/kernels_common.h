@@ -593,7 +593,8 @@ template <bool ROW16, bool NATIVE>
 __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const double *__restrict__ part, int nsplit, long rows, long S,
                                                       const SightlineDev *__restrict__ sightlines,
                                                       double *__restrict__ out, int *__restrict__ status,
-                                                      const unsigned char *__restrict__ part_counts) {
+                                                      const unsigned char *__restrict__ part_counts,
+                                                      double *__restrict__ out2 = nullptr, long pair_S = 0) {
     extern __shared__ double fin_lds[];
     constexpr int K = DLAGP_FIN_K;
     constexpr int NC = DLAGP_FIN_COLS;
@@ -606,6 +607,16 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
     const long b = block / ngroups, g = block % ngroups;
     const long row0 = sightlines[b].batch_index * S + g * NS;  // first output row of this workgroup (the caller's arrays)
     const int valid = (int)((S - g * NS) < NS ? (S - g * NS) : NS);
+    // Pair launch (SampleSource::pair_S, dlagp_device.h): the block's rows 0..7 are points 8 g .. 8 g + 7 of the first model
+    // (-> out), rows 8..15 the same points of the second (-> out2); S is then the launch's virtual sample count.
+    auto store = [&](int smp, double result) __attribute__((always_inline)) {
+        if (pair_S) {
+            const long point = g * 8 + (smp & 7);
+            if (point < pair_S) (smp >= 8 ? out2 : out)[sightlines[b].batch_index * pair_S + point] = result;
+        } else if (smp < valid) {
+            out[row0 + smp] = result;
+        }
+    };
     const SightlineDev &sl = sightlines[b];
     const int rw = sl.row_width;
     const int qbase = sl.ntw * DLAGP_TILE_COLS;
@@ -737,12 +748,11 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
             result = __builtin_nan("");
             atomicOr(status, 1);
         }
-        out[row0 + smp] = result;
+        store(smp, result);
         return;
     }
     // ---- factor + solve, one lane per sample (launches of many blocks: fewest instructions per sample)
     if (tid >= valid) return;  // lanes beyond the sightline's last sample hold unwritten partials
-    const long row = row0 + tid;
     double *mine = fin_lds + tid;
 
     double t[K], inv_diag[K];
@@ -786,7 +796,7 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
         result = __builtin_nan("");
         atomicOr(status, 1);
     }
-    out[row] = result;
+    store(tid, result);
 }
 
 // ---------------------------------------------------------------------------------------------

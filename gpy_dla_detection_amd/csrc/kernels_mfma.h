@@ -244,11 +244,16 @@ __device__ __forceinline__ void lds_wave_sync() {
 // chip.  A block's sums are 33 KB: written and read back by a second kernel they are 676 MB per level of a batch of 32
 // (2.9 TB/s, HBM-bound, 235 us) -- 2.6 % of a level at n = 3000 pixels but 10 % at the 685 of a median DR12Q sightline and
 // 19 % at 300 (profiles/r05_frac_vs_n.json).  See the epilogue.
-template <int LINES, bool BROADEN, bool STAMPS, int MODE, int PATCH, bool LLS, bool FUSED>
+// PAIR: a pair launch (SampleSource::pair_S, dlagp_device.h) -- the wave's rows r and r + 8 are the SAME
+// QMC point under two column densities (sub-DLA model / DLA model): the sample loop runs 8 times, forms the optical depth
+// once and exponentiates it twice; level 1's cache store keeps the DLA model's rows only; the finalisation -- the wave's
+// own (FUSED) or finalize_rank20 -- writes rows 0..7 to the first model's output, rows 8..15 to the second's.
+template <int LINES, bool BROADEN, bool STAMPS, int MODE, int PATCH, bool LLS, bool FUSED, bool PAIR>
 __device__ __forceinline__ void accumulate_mfma_body(
     const SightlineDev *__restrict__ sightlines, const PassDesc *__restrict__ passes,
     const WorkItem *__restrict__ items, int nb, long S, int kd,
-    SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags, double *__restrict__ out) {
+    SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags, double *__restrict__ out,
+    double *__restrict__ out2) {
     constexpr bool CACHED = MODE == 2;
     constexpr int NPOOL = 16;  // distinct cached rows a wave holds per pass (cached levels)
     // Pixel slots a pass holds.  Voigt passes: 7 chunks, what a 64-entry profile window covers behind the 7-tap
@@ -273,6 +278,8 @@ __device__ __forceinline__ void accumulate_mfma_body(
     static_assert(!PATCH || (LINES == 3 && MODE != 2), "the core patch is written for the 3-line Voigt loop");
     static_assert(PATCH != 2 || MODE == 0, "several absorbers per sample never meet the profile cache's level 1");
     static_assert(!LLS || LINES == 3, "the Lyman-limit term is implemented in the 3-line sample loop");
+    static_assert(!PAIR || (PATCH == 1 && LINES == 3 && !LLS && MODE != 2),
+                  "pair launches: one absorber per sample on the 3-line kernel, cores repaired once per wave");
     typedef double v4d_a16 __attribute__((ext_vector_type(4), aligned(16)));
 
     // finalize raises it; a later launch of a heterogeneous batch's level leaves the flag of the earlier ones alone
@@ -762,27 +769,26 @@ __device__ __forceinline__ void accumulate_mfma_body(
                     // one running LDS address (hipcc otherwise rebuilds lane * 8 + offset for every sample)
                     __attribute__((address_space(3))) double *raw_w = (__attribute__((address_space(3))) double *)raw + lane;
                     asm volatile("" : "+v"(raw_w));
-#ifdef DLAGP_KO_PAIR
-                    // timing knock-out (wrong results): rows ss and ss + 8 share one optical depth, two column densities
-                    if constexpr (PATCH == 1 && !LLS) {
+                    if constexpr (PAIR) {
+                        // rows ss and ss + 8: one QMC point, two column densities.  The optical depth per unit column -- the
+                        // wing polynomials and the shared reciprocal, three quarters of the body -- is formed once.
 #pragma unroll 1
-                    for (int ss = 0; ss < 8; ++ss) {
-                        const double xs[3] = {fma(lam, m0, x_offset), fma(lam, m1, x_offset), fma(lam, m2, x_offset)};
-                        __builtin_amdgcn_sched_barrier(0);
-                        const v4d nxt = sp4[(ss + 1) * kd];
-                        const double ncol_b = reinterpret_cast<const double *>(sp4 + (ss + 8) * kd)[3];
-                        m0 = nxt.x;
-                        m1 = nxt.y;
-                        m2 = nxt.z;
-                        __builtin_amdgcn_sched_barrier(0);
-                        const double tau = optical_depth<LINES, false>(lam, nullptr, 3, w3v, xs);
-                        raw_w[0] = fast_exp2_table(-ncol * tau, DLAGP_LINES.exp2c, c8v);
-                        raw_w[8 * DLAGP_RAW_STRIDE] = fast_exp2_table(-ncol_b * tau, DLAGP_LINES.exp2c, c8v);
-                        raw_w += DLAGP_RAW_STRIDE;
-                        ncol = nxt.w;
-                    }
+                        for (int ss = 0; ss < 8; ++ss) {
+                            const double xs[3] = {fma(lam, m0, x_offset), fma(lam, m1, x_offset), fma(lam, m2, x_offset)};
+                            __builtin_amdgcn_sched_barrier(0);
+                            const v4d nxt = sp4[(ss + 1) * kd];
+                            const double ncol_b = reinterpret_cast<const double *>(sp4 + (ss + 8) * kd)[3];
+                            m0 = nxt.x;
+                            m1 = nxt.y;
+                            m2 = nxt.z;
+                            __builtin_amdgcn_sched_barrier(0);
+                            const double tau = optical_depth<LINES, false>(lam, nullptr, 3, w3v, xs);
+                            raw_w[0] = fast_exp2_table(-ncol * tau, DLAGP_LINES.exp2c, c8v);                        // voigt.py:309
+                            raw_w[8 * DLAGP_RAW_STRIDE] = fast_exp2_table(-ncol_b * tau, DLAGP_LINES.exp2c, c8v);
+                            raw_w += DLAGP_RAW_STRIDE;
+                            ncol = nxt.w;
+                        }
                     } else
-#endif
 #pragma unroll 1
                     for (int ss = 0; ss < 16; ++ss) {
                         const double xs[3] = {fma(lam, m0, x_offset), fma(lam, m1, x_offset), fma(lam, m2, x_offset)};
@@ -1073,6 +1079,28 @@ __device__ __forceinline__ void accumulate_mfma_body(
             // to HBM one after the other per pass (-0.7 % alone, more beside other streams' kernels: the catalogue
             // driver).  Rows beyond S (the last group) are written too:
             // the cache holds whole groups of 16 rows and the cached levels never read those.
+            if constexpr (PAIR) {
+                // pair launch: only rows 8..15 are the DLA model's profiles -- points 8 group .. 8 group + 7, i.e. rows
+                // 8 (group & 1) .. of the cache's group (group >> 1) of 16 points; four stores per lane
+                const long cache_groups_p = (src.pair_S + DLAGP_MFMA_GROUP - 1) / DLAGP_MFMA_GROUP;
+                const __amdgpu_buffer_rsrc_t pair_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)as_global<gptr_d>(src.cache + (long)b * cache_groups_p * src.cache_group_stride), 0,
+                    (int)(cache_groups_p * src.cache_group_stride * 8), DLAGP_BUFFER_FLAGS);
+                const int pair_group_off = (int)(group >> 1) * ((int)src.cache_group_stride * 8);
+                const int half = (int)(group & 1) * 8;
+                if (j2 < npx) {
+                    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+                    v2d rows[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rows[i] = *reinterpret_cast<const v2d *>(&a_lds[(8 + 2 * i + h) * A_STRIDE + j2]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, rows[i]), pair_rsrc,
+                                                               lane_store + (half + 2 * i + h) * (DLAGP_CACHE_TILE_SLOTS * 8), pair_group_off,
+                                                               DLAGP_CACHE_STORE_AUX);
+                }
+            } else
             if (j2 < npx) {
                 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
                 v2d rows[8];
@@ -1136,13 +1164,16 @@ __device__ __forceinline__ void accumulate_mfma_body(
             lds_wave_sync();
             bool bad = false;
             double result = factor_solve_row16<FLS>(mine, s_loc, n_log_2pi, bad);
-            const long smp = sample0 + 4 * r + slot;
-            if (s_loc == 4 && smp < S) {  // row 20 = t sits in lane 4 of the row
+            // ordinary launch: sample sample0 + row; pair launch: point 8 group + (row & 7) of model row >> 3
+            const int row = 4 * r + slot;
+            const long smp = PAIR ? group * 8 + (row & 7) : sample0 + row;
+            const long count = PAIR ? src.pair_S : S;
+            if (s_loc == 4 && smp < count) {  // row 20 = t sits in lane 4 of the row
                 if (bad) {
                     result = __builtin_nan("");
                     atomicOr(status, 1);
                 }
-                out[gb * S + smp] = result;
+                (PAIR && row >= 8 ? out2 : out)[gb * count + smp] = result;
             }
             lds_wave_sync();  // the next round's staging overwrites what this one read
         });
@@ -1205,13 +1236,14 @@ __device__ __forceinline__ void accumulate_mfma_body(
 }
 
 // The kernel: one wave per work item, see accumulate_mfma_body.
-template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, int PATCH = 0, bool LLS = false, bool FUSED = false>
+template <int LINES, bool BROADEN, bool STAMPS, int MODE = 0, int PATCH = 0, bool LLS = false, bool FUSED = false, bool PAIR = false>
 __global__ __launch_bounds__(DLAGP_MFMA_THREADS, 2) void accumulate_mfma(
     const SightlineDev *__restrict__ sightlines, const PassDesc *__restrict__ passes,
     const WorkItem *__restrict__ items, int nb, long S, int kd,
-    SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags, double *__restrict__ out) {
-    accumulate_mfma_body<LINES, BROADEN, STAMPS, MODE, PATCH, LLS, FUSED>(sightlines, passes, items, nb, S, kd, src, part, status,
-                                                                         launch_flags, out);
+    SampleSource src, double *__restrict__ part, int *__restrict__ status, int launch_flags, double *__restrict__ out,
+    double *__restrict__ out2) {
+    accumulate_mfma_body<LINES, BROADEN, STAMPS, MODE, PATCH, LLS, FUSED, PAIR>(sightlines, passes, items, nb, S, kd, src, part,
+                                                                               status, launch_flags, out, out2);
 }
 
 // Diagnostic (dlagp_debug_voigt): the Voigt profile V(v; sigma, gamma_l) = Re w((v + i gamma_l)/(sqrt2 sigma)) /

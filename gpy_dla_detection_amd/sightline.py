@@ -404,6 +404,22 @@ class DeviceBatch:
             d_uniforms or None, d_evidences, d_sample_ll, d_base_inds or None, stream))
 
 
+def _two_model_sweep_device(self, S: int, max_dlas: int, d_sample_z: int, d_sub_nhi: int, sub_nhi_stride: int, d_sample_nhi: int,
+                            nhi_stride: int, min_z_separation: float, d_uniforms: int, d_sub_evidences: int, d_sub_sample_ll: int,
+                            d_evidences: int, d_sample_ll: int, d_base_inds: int, stream: int = 0) -> None:
+    """
+    The sub-DLA model's one-absorber sweep and the DLA model's occupation sweep at the SAME redshift samples, device
+    pointers, enqueued on `stream` (dlagp_batch_two_model_sweep_device): one launch for both one-absorber levels when the
+    batch's shape allows (`get_option("last_sweep_paired")`).
+    """
+    _lib.check(_lib.load().dlagp_batch_two_model_sweep_device(
+        self._handle, S, max_dlas, d_sample_z, d_sub_nhi, sub_nhi_stride, d_sample_nhi, nhi_stride, float(min_z_separation),
+        d_uniforms or None, d_sub_evidences, d_sub_sample_ll, d_evidences, d_sample_ll, d_base_inds or None, stream))
+
+
+DeviceBatch.two_model_sweep_device = _two_model_sweep_device
+
+
 def log_mvnpdf_low_rank(y, mu, M, d, device: int = 0) -> float:
     """stateless log N(y; mu, M M' + diag(d)) on the GPU (reference null_gp.py:307-360)"""
     y, mu, d = (_lib.as_f64(a) for a in (y, mu, d))

@@ -234,12 +234,33 @@ int dlagp_batch_sweep_device(dlagp_batch *batch, int64_t S, int max_dlas, const 
                              double *d_sample_ll, int32_t *d_base_inds, void *stream);
 
 /*
+ * Two models at the SAME redshift samples in one device-resident call: a one-absorber model (the sub-DLA model,
+ * SubDLAGP.log_model_evidences(1): sub_nhi, -> d_sub_evidences [nb], d_sub_sample_ll [nb][S]) and the occupation sweep of
+ * the DLA model (as dlagp_batch_sweep_device).  In the MATLAB original both models share `sample_z_dlas(i)` and differ
+ * only in the column density (multi_dlas/process_qsos_multiple_dlas_meanflux.m:335-373); the Python loaders build both
+ * redshift sets by one formula (dla_samples.py:94-104, subdla_samples.py:115-125).  When the batch's shape allows (a
+ * homogeneous batch on the 3-line kernel with broadening, rank <= 20) the sub-DLA sweep rides in level 1's launch: a wave's
+ * 16 MFMA rows are 8 QMC points x 2 column densities and the Voigt optical depth is evaluated once per point ("pair
+ * launch", option "pair_models", read-back "last_sweep_paired"); otherwise the two sweeps run one after the other.  Results
+ * agree with dlagp_batch_sweep_device called twice to rounding (a sample's sums are formed the same way, but blocks of 16
+ * samples are cut at other pixel positions).
+ */
+int dlagp_batch_two_model_sweep_device(dlagp_batch *batch, int64_t S, int max_dlas, const double *d_sample_z,
+                                       const double *d_sub_nhi, int64_t sub_nhi_stride, const double *d_sample_nhi,
+                                       int64_t nhi_stride, double min_z_separation, const double *d_uniforms,
+                                       double *d_sub_evidences, double *d_sub_sample_ll, double *d_evidences,
+                                       double *d_sample_ll, int32_t *d_base_inds, void *stream);
+
+/*
  * The evidence loop of BayesModelSelect.model_selection (reference bayesian_model_selection.py:84-95: one
  * log_model_evidence / log_model_evidences call per model of [null, sub-DLA, DLA]) for every sightline of the
  * batch in one synchronous call: the null evidences (dlagp_batch_null), the one-absorber sweep of the sub-DLA
  * model (dlagp_batch_sweep with max_dlas = 1 over sub_sample_z / sub_sample_nhi) and the occupation sweep of the
  * DLA model (dlagp_batch_sweep) are enqueued back to back and waited for once.  Same arguments and the same
- * results, bit for bit, as the three calls; sub_sample_ll, sample_ll, base_inds may be NULL.
+ * results as the three calls; sub_sample_ll, sample_ll, base_inds may be NULL.  (Bit for bit when the two models' launches
+ * stay separate; when sub_sample_z equals sample_z by content and the batch's shape allows, the sub-DLA sweep rides in level
+ * 1's launch -- see dlagp_batch_two_model_sweep_device -- and the results agree to rounding, ~1e-13 relative; base_inds can
+ * then differ only where a uniform falls within that distance of a cdf step.  Option "pair_models" = 0 keeps them separate.)
  *   null_evidences [nb]   sub_evidences [nb]   sub_sample_ll [nb][S]   evidences / sample_ll / base_inds as above
  */
 int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, const double *sub_sample_z,

@@ -539,6 +539,7 @@ def test_model_evidences_in_one_call_equal_the_three_calls(restore_options):
         nulls = batch.nulls()
         sub = batch.sweep(z_sub[rows], nhi_sub, 1, min_sep)
         dla = batch.sweep(zs[rows], nhi, max_dlas, min_sep, uniforms[rows])
+        # the three launches kept apart (option pair_models = 0, set for this whole test): bit for bit
         got_nulls, got_sub, got_dla = batch.model_evidences(z_sub[rows], nhi_sub, zs[rows], nhi, max_dlas, min_sep,
                                                             uniforms[rows])
         np.testing.assert_array_equal(got_nulls, nulls)
@@ -546,9 +547,22 @@ def test_model_evidences_in_one_call_equal_the_three_calls(restore_options):
             assert got[2].shape == want[2].shape and got[1].shape == want[1].shape
             for a, b in zip(got, want):
                 np.testing.assert_array_equal(a, b)  # NaN == NaN here
+        # the default: both models' one-absorber level in ONE launch when their redshift samples are equal (they are:
+        # the synthetic sub-DLA samples share the DLA samples' offsets, as the reference's loaders do).  Every sample's
+        # sums are formed as before, but the launch of 2 S rows is cut at other pixel positions: agreement to rounding.
+        set_option("pair_models", 1)
+        pair_nulls, pair_sub, pair_dla = batch.model_evidences(z_sub[rows], nhi_sub, zs[rows], nhi, max_dlas, min_sep,
+                                                               uniforms[rows])
+        set_option("pair_models", 0)
+        np.testing.assert_array_equal(pair_nulls, nulls)
+        for got, want in ((pair_sub, sub), (pair_dla, dla)):
+            np.testing.assert_allclose(got[0], want[0], rtol=1e-12, equal_nan=True)
+            np.testing.assert_allclose(got[1], want[1], rtol=1e-12, equal_nan=True)
+            np.testing.assert_array_equal(got[2], want[2])  # the resampled base indices
         return got_nulls, got_sub, got_dla
 
     assert get_option("shared_work_stream") == 0
+    set_option("pair_models", 0)  # this test is about the call structure; the pair launch is switched on where it is compared
     flavours = [dict(), dict(broadening=False), dict(num_lines=5), dict(lls_break=True)]
     for kinds in ([dict()] * 4, flavours):
         devs = [device_sightline(s, **f) for s, f in zip(sights, kinds)]
@@ -785,6 +799,7 @@ def restore_options():
     set_option("negative_noise_mfma", 0)
     set_option("finalize_wave", 1)
     set_option("fuse_finalize", 1)
+    set_option("pair_models", 1)
 
 
 @pytest.mark.parametrize("shape", [dict(index=4, n_unmasked=1250, n_masked=28, k=20),
@@ -2340,6 +2355,116 @@ def test_accumulate_waves_finish_their_own_blocks_bit_for_bit(restore_options):
     # ... and the next launch on a healthy sightline starts from a clear flag
     np.testing.assert_array_equal(devs[0].eval(zs[0], nhi), got["single"])
     neg.close()
+    batch.close()
+
+
+def test_sub_dla_and_dla_models_share_one_optical_depth_in_a_pair_launch(restore_options):
+    """
+    The sub-DLA model and level 1 of the DLA model are one absorber per sample at the SAME redshift samples and differ
+    only in the column density (MATLAB: one `sample_z_dlas(i)` for both, multi_dlas/process_qsos_multiple_dlas_meanflux.m:
+    335-373; Python: dla_samples.py:94-104 = subdla_samples.py:115-125).  When the samples are equal by content and the
+    batch's shape allows, ONE launch evaluates both -- a wave's 16 MFMA rows are 8 QMC points x 2 column densities, the
+    Voigt optical depth is formed once per point (kernels_mfma.h PAIR).  Every sample's sums are formed exactly as in a
+    launch of its own, so with equal cuts (one piece per block here) the pair launch equals the two separate sweeps BIT FOR
+    BIT: evidences, per-sample likelihoods, base indices, NaN pattern -- the device call and the host call, cached and
+    recomputed deeper levels, max_dlas 1 and 4, S not a multiple of 8, ragged sightlines; different redshift sets fall
+    back to two launches.  And both agree with the oracle.
+    """
+    import torch
+
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch, get_option, set_option
+
+    sights = [make_sightline(70, n_unmasked=685, n_masked=14), make_sightline(71, n_unmasked=300, n_masked=6),
+              make_sightline(72, n_unmasked=1250, n_masked=25), make_sightline(73, n_unmasked=58, n_masked=1)]
+    devs = [device_sightline(s) for s in sights]
+    batch = DeviceBatch(devs)
+    nb = len(sights)
+    set_option("pixel_splits", 1)  # one piece per block: every launch of this test is finished by its own waves
+    for S, max_dlas in ((1003, 4), (64, 1), (1000, 2)):
+        zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+        nhi = make_qmc_samples(sights[0], S)[2]
+        nhi_sub = make_qmc_samples(sights[0], S, sub_dla=True)[2]
+        uniforms = parallel.resampling_uniforms(nb, max_dlas, S, seed=11) if max_dlas > 1 else None
+        for cache in (1, 0):
+            set_option("profile_cache", cache)
+            set_option("pair_models", 1)
+            got = batch.model_evidences(zs, nhi_sub, zs, nhi, max_dlas, 0.002, uniforms)
+            assert get_option("last_sweep_paired") == 1
+            set_option("pair_models", 0)
+            want = batch.model_evidences(zs, nhi_sub, zs, nhi, max_dlas, 0.002, uniforms)
+            assert get_option("last_sweep_paired") == 0
+            np.testing.assert_array_equal(got[0], want[0])
+            for model in (1, 2):
+                for a, b in zip(got[model], want[model]):
+                    np.testing.assert_array_equal(a, b, err_msg="S=%d max_dlas=%d cache=%d model=%d" % (S, max_dlas, cache, model))
+        set_option("profile_cache", 1)
+        # three equal pieces per block: the pair launch leaves partial sums and finalize_rank20 sorts the rows to the two
+        # models -- the same cuts for 2 S rows as for S, so still bit for bit
+        set_option("pixel_splits", 3)
+        set_option("pair_models", 1)
+        cut3 = batch.model_evidences(zs, nhi_sub, zs, nhi, max_dlas, 0.002, uniforms)
+        assert get_option("last_sweep_paired") == 1 and get_option("last_launch_parts") in (1, 3)
+        set_option("pair_models", 0)
+        cut3_want = batch.model_evidences(zs, nhi_sub, zs, nhi, max_dlas, 0.002, uniforms)
+        for model in (1, 2):
+            for a, b in zip(cut3[model], cut3_want[model]):
+                np.testing.assert_array_equal(a, b, err_msg="three pieces, S=%d model=%d" % (S, model))
+        set_option("pixel_splits", 1)
+        set_option("pair_models", 1)
+        # the two-phase form resumes the paired sweep
+        batch.model_evidences_start(zs, nhi_sub, zs, nhi, max_dlas, 0.002)
+        two_phase = batch.model_evidences_finish(uniforms)
+        for model in (1, 2):
+            for a, b in zip(two_phase[model], got[model]):
+                np.testing.assert_array_equal(a, b)
+        # other redshifts for the sub-DLA model: two launches, the same answer as two sweeps
+        other = batch.model_evidences(zs[:, ::-1].copy(), nhi_sub, zs, nhi, max_dlas, 0.002, uniforms)
+        assert get_option("last_sweep_paired") == 0
+        np.testing.assert_array_equal(other[2][0], got[2][0])
+    # against the oracle: both models of the pair launch
+    from oracle import ref_like as R
+
+    S = 1003
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    nhi_sub = make_qmc_samples(sights[0], S, sub_dla=True)[2]
+    got = batch.model_evidences(zs, nhi_sub, zs, nhi, 1, 0.002, None)
+    assert get_option("last_sweep_paired") == 1
+    for b in (0, 3):
+        st = oracle_state(sights[b])
+        for i in (0, 7, 8, 500, S - 1):
+            for model, table in ((1, nhi_sub), (2, nhi)):
+                want_ll = R.sample_log_likelihood_k_dlas(st, [zs[b, i]], [table[i]]) - np.log(S)
+                assert abs(got[model][1][b, i, 0] - want_ll) <= RTOL_LL * abs(want_ll)
+    # the device-pointer call, automatic plans (4 x 8192 samples fill the chip with single-piece blocks)
+    set_option("pixel_splits", 0)
+    S, max_dlas = 8192, 2
+    dev = torch.device("cuda", 0)
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    z = torch.from_numpy(zs).to(dev)
+    t_nhi = torch.from_numpy(make_qmc_samples(sights[0], S)[2]).to(dev)
+    t_sub = torch.from_numpy(make_qmc_samples(sights[0], S, sub_dla=True)[2]).to(dev)
+    u = torch.from_numpy(parallel.resampling_uniforms(nb, max_dlas, S, seed=3)).to(dev)
+    f64 = dict(dtype=torch.float64, device=dev)
+
+    def device_run(pair):
+        set_option("pair_models", pair)
+        ev_sub, ll_sub = torch.zeros(nb, **f64), torch.zeros((nb, 1, S), **f64)
+        ev, ll = torch.zeros((nb, max_dlas), **f64), torch.zeros((nb, max_dlas, S), **f64)
+        base = torch.zeros((nb, max_dlas - 1, S), dtype=torch.int32, device=dev)
+        batch.two_model_sweep_device(S, max_dlas, z.data_ptr(), t_sub.data_ptr(), 0, t_nhi.data_ptr(), 0, 0.002, u.data_ptr(),
+                                     ev_sub.data_ptr(), ll_sub.data_ptr(), ev.data_ptr(), ll.data_ptr(), base.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in (ev_sub, ll_sub, ev, ll, base)], get_option("last_sweep_paired")
+
+    paired, was_paired = device_run(1)
+    separate, was_not = device_run(0)
+    assert was_paired == 1 and was_not == 0
+    for a, b in zip(paired[:4], separate[:4]):  # automatic plans may cut the separate launches elsewhere: rounding
+        np.testing.assert_allclose(a, b, rtol=1e-12, equal_nan=True)
+    assert np.mean(paired[4] == separate[4]) > 0.999
     batch.close()
 
 

@@ -19,6 +19,21 @@ for c in 3 4 5; do
 done
 python3 tools/measure_configs.py 2>/dev/null | tail -1 > $out/other_configs.json
 python3 tools/measure_catalogue.py 2048 10000 32 2>/dev/null | tail -1 > $out/catalogue_pipeline.json
+python3 tools/measure_catalogue.py 2048 10000 32 dr12q 2>/dev/null | tail -1 > $out/catalogue_pipeline_dr12q.json
+# efficiency against the sightline length (real DR12Q sightlines: n <= 1250, median ~685): one JSON per n_u, and the kernel
+# stats of the same command under rocprofv3
+echo '[' > $out/frac_vs_n.json
+first=1
+for n in 300 685 1250 3061; do
+  [ $first = 1 ] || echo ',' >> $out/frac_vs_n.json
+  first=0
+  python3 tools/measure_frac_vs_n.py --pixels $n --stamps 2>> $out/bench.err | tail -1 >> $out/frac_vs_n.json
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_n$n -- python3 tools/measure_frac_vs_n.py --pixels $n > $out/frac_n${n}_under_rocprof.json 2>> $out/bench.err
+  cp $out/prof_n$n/*/*_kernel_stats.csv $out/kernel_stats_n$n.csv
+  rm -rf $out/prof_n$n
+done
+echo ']' >> $out/frac_vs_n.json
+python3 tools/measure_frac_vs_n.py --pixels 755 --spread 0.65 2>> $out/bench.err | tail -1 > $out/frac_ragged_mix.json
 python3 tools/measure_route_a.py 256 2>/dev/null | tail -1 > $out/route_a.json
 rm -rf $out/prof $out/prof_c3 $out/prof_c4 $out/prof_c5
 ls -la $out

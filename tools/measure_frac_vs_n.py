@@ -114,6 +114,18 @@ def main():
     out["sub_dla"]["fused_finalize"] = sl.get_option("last_launch_fused")
     out["plan"] = {"work_items": sl.get_option("last_launch_items"), "pieces_per_block": sl.get_option("last_launch_parts"),
                    "slots_mean": float(np.mean([-(-s.n // 8) * 8 for s in sights]))}
+    # the sub-DLA sweep and DLA(1) in one call: one launch for both when the batch's shape allows (pair launch)
+    sub_ev, sub_ll = torch.zeros(nb, **f64), torch.empty((nb, 1, S), **f64)
+
+    def two_models(max_dlas):
+        batch.two_model_sweep_device(S, max_dlas, z.data_ptr(), nhi_sub.data_ptr(), 0, nhi_dla.data_ptr(), 0, MIN_Z_SEPARATION,
+                                     uniforms.data_ptr() if max_dlas > 1 else 0, sub_ev.data_ptr(), sub_ll.data_ptr(),
+                                     evid.data_ptr(), sample_ll.data_ptr(), base.data_ptr() if max_dlas > 1 else 0, stream)
+
+    wall_p, acc_p, launches_p = timed(lambda: two_models(1), args.steps)
+    out["sub_dla_plus_dla1"] = entry(acc_p, 2 * evals)
+    out["sub_dla_plus_dla1"].update(step_wall_ms=wall_p, launches=launches_p, paired=sl.get_option("last_sweep_paired"),
+                                    step_frac=2 * evals * flops / (wall_p * 1e-3) / 1e12 / PEAK)
     if args.stamps:
         sl.set_option("debug", 2)
         sl.debug_read(reset=True)
@@ -135,6 +147,12 @@ def main():
                          "other_kernels_share": 1.0 - acc4 / wall4, "frac": 4 * evals * flops / (acc4 * 1e-3) / 1e12 / PEAK,
                          "step_frac": 4 * evals * flops / (wall4 * 1e-3) / 1e12 / PEAK,
                          "cached": sl.get_option("last_sweep_cached"), "fused_finalize": sl.get_option("last_launch_fused")}
+        # what a catalogue run does per batch: null + sub-DLA + DLA(1..4) (the null launch is not part of this figure)
+        wall5, acc5, l5 = timed(lambda: two_models(4), args.steps)
+        out["model_selection_5_levels"] = {"step_wall_ms": wall5, "accumulate_ms": acc5, "launches": l5,
+                                           "paired": sl.get_option("last_sweep_paired"),
+                                           "frac": 5 * evals * flops / (acc5 * 1e-3) / 1e12 / PEAK,
+                                           "step_frac": 5 * evals * flops / (wall5 * 1e-3) / 1e12 / PEAK}
     print(json.dumps(out))
     batch.close()
     for d in devs:
