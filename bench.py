@@ -265,7 +265,7 @@ def cpu_baseline(sight, evals, chunks: int = 5, chunk_seconds: float = 2.0, sing
       (i)   1 process x 1 BLAS thread (this process, limited for the duration of the measurement only),
       (ii)  1 process x default BLAS threads, measured in a FRESH interpreter whose affinity is this job's share: the
             thread count reported is the one its BLAS actually ran with
-    About (chunks + 1) x chunk_seconds + 2 x single_seconds + start-up of wall time in total.
+    About (chunks + 2 ... 4) x chunk_seconds + 2 x single_seconds + start-up of wall time in total.
     """
     import multiprocessing as mp
 
@@ -289,18 +289,27 @@ def cpu_baseline(sight, evals, chunks: int = 5, chunk_seconds: float = 2.0, sing
         t0 = time.perf_counter()
         pool.map(_cpu_worker_eval, chunk_args(16, 0), chunksize=1)
         per_worker = max(16, int(16 * chunk_seconds / max(time.perf_counter() - t0, 1e-3)))
-        rates, busy, done, cursor, untimed_rate = [], [], 0, 0, None
-        for index in range(chunks + 1):
+        rates, busy, done, cursor, untimed_rates = [], [], 0, 0, []
+
+        def one_chunk():
+            nonlocal cursor
             t0 = time.perf_counter()
             results = pool.map(_cpu_worker_eval, chunk_args(per_worker, cursor), chunksize=1)
             wall = time.perf_counter() - t0
             cursor += per_worker * workers
-            count = sum(r[0] for r in results)
-            if index == 0:  # the ramp: measured, reported, not part of the value
-                untimed_rate = count / wall
-                continue
-            done += count
-            rates.append(count / wall)
+            return results, sum(r[0] for r in results) / wall
+
+        # the ramp: untimed chunks until two in a row agree within 5 % (at most four) -- on the pool's hosts the first two
+        # or three chunks of a run climb (page faults of the workers' first passes, the cores' clocks, other tenants' load
+        # moving off the pinned cores): 21.0 / 21.9 / 26.4 / 26.3 / 28.3 k in one collection of this round
+        for _ in range(4):
+            untimed_rates.append(one_chunk()[1])
+            if len(untimed_rates) >= 2 and abs(untimed_rates[-1] - untimed_rates[-2]) <= 0.05 * untimed_rates[-1]:
+                break
+        for _ in range(chunks):
+            results, rate = one_chunk()
+            done += sum(r[0] for r in results)
+            rates.append(rate)
             busy.extend(r[0] / r[1] for r in results)  # each worker's own rate while it ran
     variants = {}
     # (i): this process with its BLAS pools limited to one thread for the duration of the measurement ONLY
@@ -321,7 +330,17 @@ def cpu_baseline(sight, evals, chunks: int = 5, chunk_seconds: float = 2.0, sing
         spawn = mp.get_context("spawn")
         parent, child = spawn.Pipe(duplex=False)
         proc = spawn.Process(target=_default_threads_child, args=(child, sight, evals, single_seconds, cores))
-        proc.start()
+        # the child inherits THIS process's affinity at its start, and its BLAS sizes its pool when NumPy is imported --
+        # which a spawned interpreter does while it re-imports this module, before the target function runs: so the
+        # affinity is narrowed to the job's share here, around the start, and restored right after
+        before = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+        try:
+            if before is not None:
+                os.sched_setaffinity(0, set(cores))
+            proc.start()
+        finally:
+            if before is not None:
+                os.sched_setaffinity(0, before)
         child.close()
         answer = parent.recv() if parent.poll(120.0) else {"error": "no answer within 120 s"}
         proc.join(30.0)
@@ -345,7 +364,7 @@ def cpu_baseline(sight, evals, chunks: int = 5, chunk_seconds: float = 2.0, sing
                   "pinned processes x 1 BLAS thread after one untimed chunk of the same size; value = median chunk rate"
                   % (done, len(evals), chunks, per_worker, workers),
         "chunk_rates": rates,
-        "untimed_first_chunk_rate": untimed_rate,
+        "untimed_ramp_chunk_rates": untimed_rates,
         "spread": (rates_sorted[-1] - rates_sorted[0]) / float(np.median(rates)),
         "per_core": float(np.median(busy)),
         "cores_why": why,

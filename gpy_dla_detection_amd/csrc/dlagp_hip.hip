@@ -132,6 +132,7 @@ static Option g_opt_plan_rest_first = 0;   // dispatch the remainder pieces befo
 static Option g_opt_plan_slots = 2048;     // wave slots the planner fills: 256 CUs x 4 SIMDs x 2 waves (tuning)
 static Option g_opt_plan_xcd_affine = 1;   // batches: deal the work items so that an XCD sweeps one sightline at a time
 static Option g_opt_plan_taper = 1;        // batches: pieces per block for the sightlines of the last round of eight (1 = off)
+static Option g_opt_plan_affine_min_chunks = 256;  // ... the XCD-affine dealing only for sightlines at least this long (plan_host.h)
 // launches of up to this many blocks of 16 samples finalise with 16 lanes per sample (kernels_common.h); 0: never
 static Option g_opt_finalize_row16_blocks = DLAGP_FIN_ROW16_MAX_BLOCKS;
 // read-only diagnostics of the most recent launch / sweep (dlagp_get_option): which kernel served it
@@ -400,7 +401,7 @@ struct LaunchGroup {
     Workspace ws;
     int max_slots = 0;  // largest n_slots of a member (row stride of the profile cache)
     // key: (S, and the planner options in force: forced split count, item cost, dispatch order, slot count)
-    typedef std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t> PlanKey;
+    typedef std::tuple<int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t> PlanKey;
     std::map<PlanKey, std::unique_ptr<LaunchPlan>> plans;
     // A batch whose members differ in line count, broadening or Lyman-limit flag cannot share one instantiation of
     // the MFMA kernel.  Instead of sending all of them to the generic kernel (21x slower) it runs as several
@@ -516,12 +517,13 @@ static plan::Options planner_options(int column_groups = 1) {
     opt.slots = g_opt_plan_slots;
     opt.xcd_affine = g_opt_plan_xcd_affine;
     opt.taper = g_opt_plan_taper;
+    opt.affine_min_chunks = g_opt_plan_affine_min_chunks;
     return opt;
 }
 
 static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
     const LaunchGroup::PlanKey key(S, g_opt_pixel_splits, g_opt_plan_item_cost, g_opt_plan_rest_first, g_opt_plan_slots,
-                                   g_opt_plan_xcd_affine, g_opt_plan_taper);
+                                   g_opt_plan_xcd_affine, g_opt_plan_taper, g_opt_plan_affine_min_chunks);
     auto it = g.plans.find(key);
     if (it != g.plans.end()) {
         *out = it->second.get();
@@ -1516,13 +1518,13 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     sl.aux = ctx->aux.as<double>();
 
     if (ctx->mfma_ok) {
-        hipLaunchKernelGGL(fill_records, dim3((sl.n_slots + 255) / 256), dim3(256), 0, setup, sl.n_slots,
+        hipLaunchKernelGGL(fill_records, dim3((sl.n_slots + DLAGP_SETUP_THREADS - 1) / DLAGP_SETUP_THREADS), dim3(DLAGP_SETUP_THREADS), 0, setup, sl.n_slots,
                            ctx->slot_pixel.as<const int>(), ctx->slot_pos.as<const int>(), sl.y, sl.mu, sl.omega2, sl.v,
                            ctx->aux.as<double>());
-        hipLaunchKernelGGL(build_mfma_operand, dim3(1024), dim3(256), 0, setup, ctx->dense_M.as<double>(),
+        hipLaunchKernelGGL(build_mfma_operand, dim3(4096), dim3(DLAGP_SETUP_THREADS), 0, setup, ctx->dense_M.as<double>(),
                            ctx->slot_pixel.as<const int>(), sl.n_slots, ctx->Pm.as<double>(), k_eff, ctx->col_groups);
     }
-    hipLaunchKernelGGL(build_shared_operand, dim3(1024), dim3(256), 0, setup, ctx->dense_M.as<double>(), n, sl.n_pad,
+    hipLaunchKernelGGL(build_shared_operand, dim3(4096), dim3(DLAGP_SETUP_THREADS), 0, setup, ctx->dense_M.as<double>(), n, sl.n_pad,
                        k_eff, sl.ntw, sl.ntq, sl.npair, ctx->P.as<double>());
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
@@ -2360,6 +2362,7 @@ int dlagp_set_option(const char *name, int64_t value) try {
     else if (!strcmp(name, "plan_slots")) g_opt_plan_slots = value > 0 ? value : 2048;
     else if (!strcmp(name, "plan_xcd_affine")) g_opt_plan_xcd_affine = value;
     else if (!strcmp(name, "plan_taper")) g_opt_plan_taper = value < 1 ? 1 : (value > 8 ? 8 : value);
+    else if (!strcmp(name, "plan_affine_min_chunks")) g_opt_plan_affine_min_chunks = value < 0 ? 0 : value;
     else if (!strcmp(name, "finalize_row16_blocks")) g_opt_finalize_row16_blocks = value;
     else if (!strcmp(name, "spare_workspaces")) g_opt_spare_workspaces = value;
     else if (!strcmp(name, "shared_work_stream")) g_opt_shared_work_stream = value != 0;
@@ -2404,6 +2407,7 @@ int dlagp_get_option(const char *name, int64_t *value) try {
     else if (!strcmp(name, "plan_slots")) *value = g_opt_plan_slots;
     else if (!strcmp(name, "plan_xcd_affine")) *value = g_opt_plan_xcd_affine;
     else if (!strcmp(name, "plan_taper")) *value = g_opt_plan_taper;
+    else if (!strcmp(name, "plan_affine_min_chunks")) *value = g_opt_plan_affine_min_chunks;
     else if (!strcmp(name, "finalize_row16_blocks")) *value = g_opt_finalize_row16_blocks;
     else if (!strcmp(name, "spare_workspaces")) *value = g_opt_spare_workspaces;
     else if (!strcmp(name, "shared_work_stream")) *value = g_opt_shared_work_stream;

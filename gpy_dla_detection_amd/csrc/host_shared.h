@@ -41,8 +41,14 @@ constexpr int finalize_wave_lds_doubles(int k) { return k * (k + 1) / 2 + k; }  
 #endif
 #define DLAGP_EVIDENCE_THREADS 1024
 #define DLAGP_LEVEL_THREADS 1024
-#define DLAGP_INTERP_PIXELS 8
+// Set-up kernels run as ONE-WAVE workgroups (round 5).  They are launched beside other batches' sweeps, whose accumulate
+// waves hold every register of a SIMD and 19.5 KB of LDS each and are replaced the moment they end: a workgroup of four waves
+// finds four free slots on ONE CU only when a sweep's launch drains -- interp_model averaged 263 us of wall time in a
+// catalogue run where it computes for 5 (profiles/r05_experiments.txt item 9) -- while a single wave fits whichever slot
+// frees next.
+#define DLAGP_INTERP_PIXELS 2
 #define DLAGP_INTERP_THREADS (32 * DLAGP_INTERP_PIXELS)
+#define DLAGP_SETUP_THREADS 64
 
 // the learned GP model on its rest-frame grid, as interp_model takes it (by value)
 namespace dlagp {

@@ -506,12 +506,17 @@ __device__ __forceinline__ double factor_solve_row16(const double *col, int q, d
             A1[k] = v;
         }
         LogProduct pivots;
+        // DPP row_newbcast: lane L of every row of 16 lanes, as ONE 64-bit move (v_mov_b64_dpp, gfx90a and later; the 32-bit
+        // halves cost two).  The DPP instructions of this routine are inline assembly in program order (volatile): the
+        // compiler's hazard recogniser does not see inside them, and a DPP read of a VGPR needs two wait states behind the
+        // VALU write of it -- so every place where the source may just have been written carries its own s_nop 1: this
+        // broadcast (its source was written by the previous column's updates) and the first update of a column (its
+        // sources were scaled right before it).
         auto row_bcast = [](double v, auto lane_c) __attribute__((always_inline)) {
-            constexpr int ctrl = 0x150 + decltype(lane_c)::value;  // DPP row_newbcast: lane L of every row of 16 lanes
-            // every lane is written (full row and bank masks): the "old" operand is never kept, so hand in the source
-            const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), ctrl, 0xf, 0xf, false);
-            const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), ctrl, 0xf, 0xf, false);
-            return __hiloint2double(hi, lo);
+            double out;
+            asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                         : "=v"(out) : "v"(v), "n"(decltype(lane_c)::value));
+            return out;
         };
         // fully unrolled: every register index and DPP control below is a compile-time constant
         auto column = [&](auto j_c) __attribute__((always_inline)) {
@@ -524,13 +529,28 @@ __device__ __forceinline__ double factor_solve_row16(const double *col, int q, d
             const double inv = fast_rsqrt(s);
             if constexpr (j < 16) A0[j] *= inv;  // rows > j: L_ij (row j itself and the rows above it: scratch)
             A1[j] *= inv;
+            // Trailing update of column k: entry (row, k) -= L(row, j) L(k, j), where L(k, j) sits in lane k (mod 16) of the
+            // row of 16 lanes.  The broadcast rides in the multiply-add itself: on gfx90a and later the FP64 VOP2 forms take a
+            // DPP row_newbcast source (v_fmac_f64_dpp: D += bcast(src0) * src1), so a (j, k) pair costs two instructions
+            // instead of two 32-bit DPP moves + two FMAs -- a third of this routine's instructions, which a single wave
+            // issues every 8 cycles (profiles/r05_experiments.txt item 7).  Same products, same rounding: c - l a either way.
             auto update = [&](auto k_c) __attribute__((always_inline)) {
                 constexpr int k = decltype(k_c)::value;
-                double lkj;
-                if constexpr (k < 16) lkj = row_bcast(A0[j], std::integral_constant<int, k>{});
-                else lkj = row_bcast(A1[j], std::integral_constant<int, k - 16>{});
-                if constexpr (k < 16) A0[k] = fma(-A0[j], lkj, A0[k]);
-                A1[k] = fma(-A1[j], lkj, A1[k]);
+                constexpr int lane = k < 16 ? k : k - 16;
+                const double src = k < 16 ? A0[j] : A1[j];  // L(k, j) lives in lane `lane` of this register
+                if constexpr (k == j + 1) {  // the column's first DPP read of the freshly scaled sources: wait states first
+                    if constexpr (k < 16)
+                        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                                     : "+v"(A0[k]) : "v"(src), "v"(A0[j]), "n"(lane));
+                    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                                 : "+v"(A1[k]) : "v"(src), "v"(A1[j]), "n"(lane));
+                } else {
+                    if constexpr (k < 16)
+                        asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                                     : "+v"(A0[k]) : "v"(src), "v"(A0[j]), "n"(lane));
+                    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                                 : "+v"(A1[k]) : "v"(src), "v"(A1[j]), "n"(lane));
+                }
             };
             static_for<j + 1, K>(update);
             __builtin_amdgcn_sched_barrier(0);  // columns in program order (the scheduler otherwise interleaves several)

@@ -63,7 +63,8 @@ struct Options {
     int64_t item_cost = 20;    // fixed cost of a work item in the model, tenths of a chunk
     int64_t rest_first = 0;    // dispatch the remainder pieces before the full ones
     int64_t slots = 2048;      // wave slots to fill: 256 CUs x 4 SIMDs x 2 waves
-    int64_t xcd_affine = 1;    // batches: deal the items so that an XCD sweeps one sightline at a time
+    int64_t xcd_affine = 1;    // batches of LONG sightlines: deal the items so that an XCD sweeps one sightline at a time
+    int64_t affine_min_chunks = 256;  // ... "long": the mean sightline has at least this many chunks (2048 slots: a 4 MB operand)
     int64_t column_groups = 1; // ranks above 20: every (block, piece) is evaluated once per column group
     int64_t taper = 1;         // batches: pieces per block for the sightlines of the last round of eight (1 = off)
 };
@@ -278,13 +279,21 @@ inline int build(const std::vector<Sightline> &sightlines, int64_t S, const Opti
     // only), each with its own 4 MB L2, and a sightline's MFMA operand is 6 MB.  In (sightline, group) order every XCD
     // has waves of the ~3 sightlines that are in flight at a time; dealt so that workgroup i works on a sightline
     // b = i (mod 8), every XCD sweeps ONE sightline's operand with all of its waves.  Option "plan_xcd_affine".
-    const bool affine = opt.xcd_affine != 0 && !remainder && full == 1 && nb >= 8;
-    // Longest sightlines first (a catalogue batch is ragged: n follows z_qso): the eight of a round are then of similar
-    // length, and the launch ends on its shortest items instead of on whatever came last.  Equal lengths (the bench)
-    // keep their order.
+    // Round 5: only where the operands are LONG -- one alone at least an XCD's 4 MB of L2 (n_slots >= 2048; the bench's
+    // n = 3000: 6 MB).  Workgroups reach the XCDs round-robin and IN ORDER: workgroup i cannot start before workgroup
+    // i - 1 has, so in a round of eight sightlines of different lengths the XCD with the longest one holds the dispatcher,
+    // and with it the other seven XCDs, back -- a round costs its LONGEST member on every XCD.  On a ragged batch of
+    // DR12Q-sized sightlines (32 sightlines, n_u uniform in 264 ... 1246) the affine dealing ran at 0.50 of peak where the
+    // plain (sightline, block) order -- every XCD sees the same mix, the ~3 operands in flight (<= 2.5 MB each) share the
+    // L2s -- ran at 0.56; at equal lengths n = 685 / 1250 the two orders are within 1 % (profiles/r05_experiments.txt item 8).
+    const bool batch_of_blocks = !remainder && full == 1 && nb >= 8;
+    const bool affine = opt.xcd_affine != 0 && batch_of_blocks && mean_chunks >= (double)opt.affine_min_chunks;
+    // Longest sightlines first (a catalogue batch is ragged: n follows z_qso): what is in flight at any moment is of similar
+    // length -- the eight of an affine round, the ~3 sightlines of the plain order -- and the launch ends on its shortest
+    // items instead of on whatever came last.  Equal lengths (the bench) keep their order.
     std::vector<int> order(nb);
     for (int b = 0; b < nb; ++b) order[b] = b;
-    if (affine) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sightlines[x].chunks > sightlines[y].chunks; });
+    if (batch_of_blocks) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sightlines[x].chunks > sightlines[y].chunks; });
     // Taper: a launch of many equal rounds ends with every wave slot somewhere inside its last item -- on average half an
     // item of idle time per slot.  The sightlines of the LAST round of eight are cut into `taper` pieces each, so that
     // the launch ends on items a fraction as long.  Option "plan_taper" (0 / 1: off).
@@ -334,9 +343,9 @@ inline int build(const std::vector<Sightline> &sightlines, int64_t S, const Opti
                 for (int x = 0; x < width; ++x) emit(order[b0 + x], grp);
         }
     } else {
-        // the full pieces in (sightline, group, piece) order, then the remainders
-        for (int b = 0; b < nb; ++b)
-            for (long grp = 0; grp < ngroups; ++grp) emit(b, grp);
+        // the full pieces in (sightline, group, piece) order -- a batch's sightlines longest first -- then the remainders
+        for (int x = 0; x < nb; ++x)
+            for (long grp = 0; grp < ngroups; ++grp) emit(order[x], grp);
         const bool rest_first = opt.rest_first != 0;
         if (remainder) std::stable_partition(pieces.begin(), pieces.end(), [=](const Piece &x) { return x.rest == rest_first; });
     }

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Markdown tables of DESIGN.md section 7 from a collection directory (tools/collect_profiles.sh <tag>): usage design_table.py profiles r05"""
+import csv
+import json
+import os
+import sys
+
+root, tag = sys.argv[1], sys.argv[2]
+
+
+def load(name):
+    path = os.path.join(root, "%s_%s" % (tag, name)) if root.endswith("profiles") else os.path.join(root, name)
+    text = open(path).read().strip()
+    return json.loads(text.splitlines()[-1]) if not text.startswith("[") else json.loads(text)
+
+
+def kernel_avg(csv_name, needle):
+    path = os.path.join(root, "%s_%s" % (tag, csv_name)) if root.endswith("profiles") else os.path.join(root, csv_name)
+    for r in csv.DictReader(open(path)):
+        if needle in r["Name"]:
+            return float(r["AverageNs"]) / 1e3, int(r["Calls"])
+    return None, 0
+
+
+b = load("bench.json")
+r = b["roofline"]
+print("| quantity | round 5 | file |")
+print("|---|---|---|")
+print("| step, configs[1] | %.4f ms → **%.1f M evals/s** | `%s_bench.json` |" % (b["ms_per_step"], b["value"] / 1e6, tag))
+avg, calls = kernel_avg("kernel_stats.csv", "accumulate_mfma<3, true, false, 0, 1, false, false")
+print("| accumulate_mfma, configs[1] | %.4f ms by HIP events → %.1f TFLOP/s = **%.1f %%** of 78.6 (`frac_cold` %.1f %%); %.4f ms avg over %d launches under rocprofv3 | `%s_bench.json`, `%s_kernel_stats.csv` |"
+      % (r["kernel_ms"], r["achieved"], 100 * r["frac"], 100 * r["frac_cold"], (avg or 0) / 1e3, calls, tag, tag))
+fin, _ = kernel_avg("kernel_stats.csv", "finalize_rank20")
+ev, _ = kernel_avg("kernel_stats.csv", "level_evidence")
+print("| finalize_rank20 / level_evidence | %.1f / %.1f µs | `%s_kernel_stats.csv` |" % (fin or 0, ev or 0, tag))
+for c, what in ((3, "64 sightlines × {sub-DLA, DLA(1)}: one pair launch"), (4, "one rank's 128 of 1024: null + sub-DLA + DLA(1)"),
+                (5, "one rank's 32 of 256: DLA(1..4), cached levels")):
+    x = load("bench_config%d.json" % c)
+    o = b["other_configs"][str(c)]
+    print("| config %d (%s) | %.1f ms, **%.1f M evals/s**%s, accumulate %.1f %% — inside the default run: %.1f ms | `%s_bench_config%d.json` |"
+          % (c, what, x["ms_per_step"], x["value"] / 1e6, (", **%.0f spectra/s**" % x["spectra_per_s"]) if x.get("spectra_per_s") else "",
+             100 * x["roofline"]["frac"], o["ms_per_step"], tag, c))
+s = b["strong_n1"]
+print("| by-sample split at N = 1 | %.4f ms, %.1f M evals/s | `%s_bench.json` |" % (s["ms_per_step"], s["evals_per_s"] / 1e6, tag))
+for name, label in (("catalogue_pipeline.json", "z_qso uniform in [2.2, 3.4]"), ("catalogue_pipeline_dr12q.json", "DR12Q-like z_qso")):
+    x = load(name)
+    print("| catalogue driver, 2048 spectra, %s (n median %.0f, mean %.0f) | **%.0f spectra/s**, %.1f M evals/s, whole run %.1f %% of FP64 peak | `%s_%s` |"
+          % (label, x["kept_pixels"]["median"], x["kept_pixels"]["mean"], x["spectra_per_s"], x["evals_per_s"] / 1e6,
+             100 * x["whole_run_frac_of_fp64_peak"], tag, name))
+x = load("route_a.json")
+print("| route A (reference driver loop, imports swapped), 256 spectra | **%.2f ms per spectrum** (%.0f spectra/s) | `%s_route_a.json` |"
+      % (x["ms_per_spectrum"], x["spectra_per_s"], tag))
+cb = b["cpu_baseline"]
+print("| CPU baseline (oracle, %d pinned processes × 1 BLAS thread) | **%.1f k evals/s** (chunks %s; ramp %s); 1 process %.1f k; default threads %.1f k on %s threads | `%s_bench.json` |"
+      % (cb["cores"], cb["value"] / 1e3, " / ".join("%.1f" % (v / 1e3) for v in cb["chunk_rates"]),
+         " / ".join("%.1f" % (v / 1e3) for v in cb.get("untimed_ramp_chunk_rates", [cb.get("untimed_first_chunk_rate", 0)])),
+         cb["variants"]["i_one_process_one_blas_thread"]["value"] / 1e3,
+         cb["variants"]["ii_one_process_default_blas_threads"].get("value", 0) / 1e3,
+         cb["variants"]["ii_one_process_default_blas_threads"].get("blas_threads_used"), tag))
+print()
+print("**Efficiency against the sightline length** (batch of 32 × 10 000 samples, one stream; `frac` = accumulate kernels, `step` = wall "
+      "time incl. finalisation and level_finish; `%s_frac_vs_n.json`, `%s_kernel_stats_n*.csv`):\n" % (tag, tag))
+print("| n_u (n kept) | sub-DLA sweep | sub-DLA + DLA(1), one pair launch | level 1 + store | cached level | model selection, 5 levels: step | prologue / epilogue cycles per wave |")
+print("|---|---|---|---|---|---|---|")
+for d in load("frac_vs_n.json"):
+    st = d.get("stamps_cycles_per_wave", {})
+    print("| %d (%.0f) | %.3f ms, frac %.3f, step %.3f | %.3f ms, frac %.3f, step %.3f | %.3f ms, %.3f | %.3f ms, %.3f | %.2f ms, **%.3f** | %.0f k / %.0f k of %.0f k |"
+          % (d["pixels_unmasked"], d["n_kept_mean"], d["sub_dla"]["ms_per_launch"], d["sub_dla"]["frac"], d["sub_dla"]["step_frac"],
+             d["sub_dla_plus_dla1"]["ms_per_launch"], d["sub_dla_plus_dla1"]["frac"], d["sub_dla_plus_dla1"]["step_frac"],
+             d["level1_with_store"]["ms_per_launch"], d["level1_with_store"]["frac"], d["cached_level"]["ms_per_launch"],
+             d["cached_level"]["frac"], d["model_selection_5_levels"]["step_wall_ms"], d["model_selection_5_levels"]["step_frac"],
+             st.get("prologue", 0) / 1e3, st.get("epilogue", 0) / 1e3, (st.get("passes_and_epilogue", 0) + st.get("prologue", 0)) / 1e3))
+try:
+    d = load("frac_ragged_mix.json")
+    print("| ragged: n_u uniform in %d…%d (mean n %.0f) | %.3f ms, frac %.3f, step %.3f | %.3f ms, frac %.3f, step %.3f | %.3f ms, %.3f | %.3f ms, %.3f | %.2f ms, **%.3f** | |"
+          % (round(d["pixels_unmasked"] * (1 - d["spread"])), round(d["pixels_unmasked"] * (1 + d["spread"])), d["n_kept_mean"],
+             d["sub_dla"]["ms_per_launch"], d["sub_dla"]["frac"], d["sub_dla"]["step_frac"], d["sub_dla_plus_dla1"]["ms_per_launch"],
+             d["sub_dla_plus_dla1"]["frac"], d["sub_dla_plus_dla1"]["step_frac"], d["level1_with_store"]["ms_per_launch"],
+             d["level1_with_store"]["frac"], d["cached_level"]["ms_per_launch"], d["cached_level"]["frac"],
+             d["model_selection_5_levels"]["step_wall_ms"], d["model_selection_5_levels"]["step_frac"]))
+except (OSError, KeyError):
+    pass
