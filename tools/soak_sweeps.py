@@ -20,6 +20,7 @@ from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline  # 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 worst, checked, shared_waves, waves = 0.0, 0, 0, 0
+worst_pair, pairs = 0.0, 0
 for trial in range(trials):
     nb = int(rng.choice([1, 1, 2, 3, 6]))
     S = int(rng.choice([1, 7, 16, 17, 100, 625, 1000, 2048, 4000]))
@@ -60,6 +61,7 @@ for trial in range(trials):
         worst = max(worst, float(rel))
         assert rel < 1e-10, (trial, rel)
     checked += int(ok.sum())
+    sl.set_option("pair_models", 0)  # the three launches kept apart: bit for bit
     nulls, sub, dla = batch.model_evidences(z_sub, nhi_sub, zs, nhi, max_dlas, sep, uniforms)
     assert np.array_equal(nulls, batch.nulls())
     want_sub = batch.sweep(z_sub, nhi_sub, 1, sep)
@@ -67,6 +69,38 @@ for trial in range(trials):
         assert np.array_equal(x, y, equal_nan=True), ("model_evidences: sub-DLA model", trial)
     for x, y in zip(dla, a):
         assert np.array_equal(x, y, equal_nan=x.dtype.kind == "f"), ("model_evidences: DLA model", trial)
+    # round 5: the pair launch (sub-DLA model + level 1 of the DLA model, one optical depth per QMC point) and the wave's own
+    # finalisation.  Automatic plans may cut the launch of 2 S rows elsewhere than the launches of S rows: agreement to
+    # rounding, identical base indices and NaN pattern; with forced equal cuts (h pieces per block) everything is bit for bit,
+    # pair launch or not, finished by the waves themselves (h = 1) or by finalize_rank20, fused or not.
+    sl.set_option("pair_models", 1)
+    p_nulls, p_sub, p_dla = batch.model_evidences(z_sub, nhi_sub, zs, nhi, max_dlas, sep, uniforms)
+    pairs += sl.get_option("last_sweep_paired")
+    assert np.array_equal(p_nulls, nulls)
+    for got, want in ((p_sub, sub), (p_dla, dla)):
+        assert np.array_equal(got[2], want[2]), ("pair launch: base indices", trial)
+        for x, y in zip(got[:2], want[:2]):
+            assert np.array_equal(np.isnan(x), np.isnan(y)), ("pair launch: NaN pattern", trial)
+            fin = np.isfinite(y)
+            if fin.any():
+                rel = np.max(np.abs(x[fin] - y[fin]) / np.maximum(1.0, np.abs(y[fin])))
+                worst_pair = max(worst_pair, float(rel))
+                assert rel < 1e-10, ("pair launch", trial, rel)
+    h = int(rng.choice([1, 1, 2, 3]))
+    sl.set_option("pixel_splits", h)
+    forms = []
+    for pair, fuse in ((1, 1), (1, 0), (0, 1), (0, 0)):
+        sl.set_option("pair_models", pair)
+        sl.set_option("fuse_finalize", fuse)
+        forms.append(batch.model_evidences(z_sub, nhi_sub, zs, nhi, max_dlas, sep, uniforms))
+    sl.set_option("pixel_splits", 0)
+    sl.set_option("pair_models", 1)
+    sl.set_option("fuse_finalize", 1)
+    for other in forms[1:]:
+        assert np.array_equal(other[0], forms[0][0])
+        for model in (1, 2):
+            for x, y in zip(other[model], forms[0][model]):
+                assert np.array_equal(x, y, equal_nan=x.dtype.kind == "f"), ("forced cuts: pair / fused forms differ", trial, h)
     if S >= 16:
         blocks = a[2][:, :, : S // 16 * 16].reshape(nb, max_dlas - 1, -1, 16)
         agree = (blocks == blocks[..., :1]).all(axis=-1)
@@ -78,4 +112,4 @@ for trial in range(trials):
     if trial % 20 == 19:
         print("trial", trial + 1, "values", checked, "worst", worst, flush=True)
 print("seed", sys.argv[1] if len(sys.argv) > 1 else 0, "trials", trials, "values", checked, "worst relative difference", worst,
-      "waves with a shared row", shared_waves, "of", waves)
+      "waves with a shared row", shared_waves, "of", waves, "| pair launches", pairs, "worst pair-vs-separate difference", worst_pair)
