@@ -466,19 +466,34 @@ __device__ __forceinline__ void accumulate_mfma_body(
             patch_sample[rank] = lane / 3 | (lane % 3) << 8;
         }
         lds_wave_sync();
-        for (int base = 0; base < npatch * NCAND; base += 64) {
-            const int item = base + lane;
-            if (item < npatch * NCAND) {
-                const int rank = item / NCAND, j = item % NCAND;
+        // All the wavelengths of the candidate entries are fetched before the first is used: one trip to L2 for the wave
+        // instead of one per round of 64 candidates (<= 48 pairs x 7 = 6 rounds, each with its table look-ups behind it).
+        constexpr int ROUNDS = (NPAIR_MAX * NCAND + 63) / 64;
+        const int ncand = npatch * NCAND;
+        double lam_c[ROUNDS];
+        int e_c[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int item = r * 64 + lane;
+            const int rank = item < ncand ? item / NCAND : 0;
+            e_c[r] = patch_first[rank] + item % NCAND;
+            const int e_load = e_c[r] < 0 ? 0 : (e_c[r] < num_entries ? e_c[r] : num_entries - 1);
+            lam_c[r] = r * 64 < ncand ? lam_ptr[e_load] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (r * 64 >= ncand) break;
+            const int item = r * 64 + lane;
+            if (item < ncand) {
+                const int rank = item / NCAND;
                 const int packed = patch_sample[rank];
                 const int ss = packed & 255, l = packed >> 8;
-                const int e = patch_first[rank] + j;
-                const int e_load = e < 0 ? 0 : (e < num_entries ? e : num_entries - 1);
-                const double lam_e = lam_ptr[e_load];
+                const int e = e_c[r];
+                const double lam_e = lam_c[r];
                 const double *mrow = prep_lds + ss * prep_stride;
                 const double x = fma(lam_e, mrow[l], x_offset);  // the loop's expression, bit for bit
                 double factor = -1.0;  // marks "not a core entry" (profile values are >= 0)
-                if (e == e_load && !(x * x >= DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT)) {
+                if (e >= 0 && e < num_entries && !(x * x >= DLAGP_FAD_XSPLIT * DLAGP_FAD_XSPLIT)) {
                     const double core = DLAGP_LINES.k_core[l] * core_taylor(x, DLAGP_LINES.y[l]);
                     double tau = core == core ? core : 0.0;  // a NaN term is dropped (np.nansum, voigt.py:309)
 #pragma unroll
