@@ -353,7 +353,10 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     results; default 1), "fuse_finalize" (1 = when the launch plan gives every block of 16 samples ONE
  *                     piece -- batches: more blocks than wave slots -- the accumulate wave also factors its block and
  *                     writes log p itself, and no partial sums cross HBM; 0 = always the separate finalisation kernel;
- *                     identical results, bit for bit; default 1)
+ *                     identical results, bit for bit; default 1), "pair_models" (1 = dlagp_batch_model_evidences* and
+ *                     dlagp_batch_two_model_sweep_device evaluate the sub-DLA model and level 1 of the DLA model in ONE
+ *                     launch when both sample the same redshifts -- one Voigt optical depth per QMC point; 0 = two
+ *                     launches; identical results at equal cuts, to rounding otherwise; default 1)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.
  */

@@ -111,6 +111,16 @@ def test_default_line_carries_the_other_configurations():
     assert two["other_configs"]["4"]["sightlines_per_gpu"] == 128
 
 
+def test_bench_at_dr12q_sightline_lengths():
+    """`--pixels N` (hidden): the batch configurations on synthetic sightlines of N unmasked pixels -- real DR12Q sightlines
+    keep n <= 1250, median ~685 (reference set_parameters.py:33-34,58) -- with the line's own figures consistent with it"""
+    line = run_bench(0, "--gpus", "1", "--config", "3", "--pixels", "685", "--sightlines", "8", "--steps", "2", "--warmup", "1",
+                     "--ramp-ms", "5")
+    assert "n=671 pixels (n_u=685)" in line["config"]["workload"] and line["config"]["sightlines_per_gpu"] == 8
+    assert line["roofline"]["flop_per_eval"] == 671 * 20 * 21 + 2 * 671 * 20
+    assert line["value"] > 1e6 and 0.2 < line["roofline"]["frac"] < 1.0 and "other_configs" not in line
+
+
 def test_many_ranks_rehearsed_on_the_one_card():
     """
     The driver's multi-GPU run, rehearsed as far as a one-GPU box allows: `python bench.py --gpus 4 --rehearse-on-one-gpu
