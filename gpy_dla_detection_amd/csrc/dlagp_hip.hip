@@ -360,7 +360,7 @@ static std::mutex g_spare_mutex;
 // spare every other batch freed and reallocated gigabytes (hipFree synchronises the device: 7 ms per batch).
 static std::map<int, std::vector<Workspace>> g_spare_workspace;
 static Option g_opt_spare_workspaces = 5;
-static Option g_opt_shared_work_stream = 0;
+static Option g_opt_shared_work_stream = 1;
 static Option g_opt_shared_rows = 1;  // cached levels: a wave whose samples stack the same cached row reads it once
 // test hook: contexts with a negative noise variance stay on the MFMA kernel (default: they take the generic kernel, whose
 // per-pixel log(d) is NaN for any negative d as in the reference) -- the tests of that kernel's non-PD flag need them
@@ -861,11 +861,14 @@ static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &s
 // THREAD, not on the null stream: two host threads that sweep different batches then overlap -- one's transfers and
 // host-side work beside the other's kernels -- instead of queueing behind each other (the catalogue driver's two sweep
 // threads).  Every such call still returns with its own work complete.
-// Option "shared_work_stream" = 1 puts the KERNELS of all threads on one stream per device instead (transfers stay on
-// the thread's stream, ordered against the kernels by events, and a call waits for its own completion event only): the
-// calls of different threads then run strictly one after the other.  Measured on the catalogue driver it makes no
-// difference (the device serialises two full-size launches anyway; profiles/r03_experiments.txt item 15), so the
-// default stays 0.
+// Option "shared_work_stream" = 1 (the default since round 5) puts the KERNELS of all threads on one stream per device
+// (transfers stay on the thread's stream, ordered against the kernels by events, and a call waits for its own completion
+// event only): the kernels of different threads' calls then run strictly one after the other, each launch with the chip
+// to itself, while uploads, downloads and host work overlap them.  In round 3 it made no difference on the catalogue
+// driver (profiles/r03_experiments.txt item 15: the finalisation kernels between the accumulate launches left the
+// streams little to contend for); with fused launches following each other, two threads' accumulate kernels on two
+// streams interleave slot by slot and both lose their fill pattern: one stream is +21 % on a DR12Q-like catalogue, +7 % on
+// the uniform mix (profiles/r05_experiments.txt item 12).  0: every calling thread launches on its own stream.
 // Streams and staging memory of a host thread are BORROWED from process-wide free lists and handed back when the thread
 // ends (thread_local holders' destructors, which make no HIP call: at process exit the runtime may already be gone).
 // The catalogue driver starts five fresh worker threads per call; with per-thread streams and arenas that were never
@@ -936,13 +939,46 @@ static hipStream_t compute_stream(int device) {
     return s;
 }
 
-// the calling thread's pair of events that order its transfer stream against the kernel stream within one call
+// the calling thread's pair of events that order its transfer stream against the kernel stream within one call.  Like the
+// streams they go back to a process-wide pool when the thread ends, so that a driver which starts a thread per chunk of
+// a catalogue does not grow the number of events with the number of chunks.
 struct CallEvents {
     hipEvent_t uploaded = nullptr, computed = nullptr;
 };
+struct EventPool {
+    std::mutex mutex;
+    std::map<int, std::vector<CallEvents>> free;
+};
+static EventPool &event_pool() {
+    static EventPool *pool = new EventPool();  // never destroyed, for the same reason as the stream pool
+    return *pool;
+}
+struct ThreadEvents {
+    std::map<int, CallEvents> events;
+    ~ThreadEvents() {
+        EventPool &pool = event_pool();
+        std::lock_guard<std::mutex> lock(pool.mutex);
+        for (auto &kv : events)
+            if (kv.second.uploaded && kv.second.computed) pool.free[kv.first].push_back(kv.second);
+    }
+};
 static int call_events(int device, CallEvents **out) {
-    static thread_local std::map<int, CallEvents> events;
-    CallEvents &ev = events[device];
+    static thread_local ThreadEvents mine;
+    auto it = mine.events.find(device);
+    if (it == mine.events.end()) {
+        CallEvents ev;
+        {
+            EventPool &pool = event_pool();
+            std::lock_guard<std::mutex> lock(pool.mutex);
+            auto &idle = pool.free[device];
+            if (!idle.empty()) {
+                ev = idle.back();
+                idle.pop_back();
+            }
+        }
+        it = mine.events.emplace(device, ev).first;
+    }
+    CallEvents &ev = it->second;
     if (!ev.uploaded) HIP_TRY(hipEventCreateWithFlags(&ev.uploaded, hipEventDisableTiming));
     if (!ev.computed) HIP_TRY(hipEventCreateWithFlags(&ev.computed, hipEventDisableTiming));
     *out = &ev;

@@ -52,9 +52,16 @@ struct dim3 {
 
 namespace fake {
 
+struct Stream;
+struct Wait {  // hipStreamWaitEvent: the waiting stream's operations from ticket `at` on run after (stream, ticket)
+    uint64_t at;
+    Stream *stream;
+    uint64_t ticket;
+};
 struct Stream {
     int device = 0;
     std::atomic<uint64_t> issued{0}, completed{0};
+    std::vector<Wait> waits;  // guarded by State::mutex
 };
 struct Event {
     Stream *stream = nullptr;
@@ -98,10 +105,28 @@ inline Stream *resolve(Stream *s) {
     return null_stream;
 }
 inline uint64_t enqueue(Stream *s) { return resolve(s)->issued.fetch_add(1) + 1; }
-inline void complete(Stream *s, uint64_t upto) {
+// Everything on `s` up to ticket `upto` has run -- and with it whatever those operations had waited for on other streams
+// (hipStreamWaitEvent): a call of the library that drains its transfer stream has thereby seen its kernels on the shared
+// kernel stream complete.  Call with State::mutex held.
+inline void complete_locked(Stream *s, uint64_t upto, int depth = 0) {
     uint64_t seen = s->completed.load();
     while (seen < upto && !s->completed.compare_exchange_weak(seen, upto)) {
     }
+    if (depth > 8) return;
+    for (size_t i = 0; i < s->waits.size();) {
+        const Wait w = s->waits[i];
+        if (w.at <= upto) {
+            s->waits[i] = s->waits.back();
+            s->waits.pop_back();
+            complete_locked(w.stream, w.ticket, depth + 1);
+        } else {
+            ++i;
+        }
+    }
+}
+inline void complete(Stream *s, uint64_t upto) {
+    std::lock_guard<std::mutex> lock(state().mutex);
+    complete_locked(s, upto);
 }
 
 // the allocation that holds `p`, or end()
@@ -201,7 +226,7 @@ inline hipError_t hipFree(void *p) {
     fake::State &st = fake::state();
     {  // the real hipFree synchronises the device
         std::lock_guard<std::mutex> lock(st.mutex);
-        for (fake::Stream *s : st.streams) fake::complete(s, s->issued.load());
+        for (fake::Stream *s : st.streams) fake::complete_locked(s, s->issued.load());
         auto it = st.allocations.find((char *)p);
         if (it == st.allocations.end()) {
             fake::report("hipFree of a pointer that is not a live allocation (double free?)", p);
@@ -280,7 +305,7 @@ inline hipError_t hipStreamSynchronize(hipStream_t stream) {
 inline hipError_t hipDeviceSynchronize() {
     fake::State &st = fake::state();
     std::lock_guard<std::mutex> lock(st.mutex);
-    for (fake::Stream *s : st.streams) fake::complete(s, s->issued.load());
+    for (fake::Stream *s : st.streams) fake::complete_locked(s, s->issued.load());
     return hipSuccess;
 }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *out, unsigned) {
@@ -307,8 +332,13 @@ inline hipError_t hipEventSynchronize(hipEvent_t e) {
     if (e->stream) fake::complete(e->stream, e->ticket);
     return hipSuccess;
 }
-inline hipError_t hipStreamWaitEvent(hipStream_t stream, hipEvent_t, unsigned) {
-    fake::enqueue(fake::resolve(stream));
+inline hipError_t hipStreamWaitEvent(hipStream_t stream, hipEvent_t event, unsigned) {
+    fake::Stream *s = fake::resolve(stream);
+    const uint64_t at = fake::enqueue(s);
+    if (event && event->stream && event->stream != s) {
+        std::lock_guard<std::mutex> lock(fake::state().mutex);
+        s->waits.push_back({at, event->stream, event->ticket});
+    }
     return hipSuccess;
 }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) {

@@ -280,12 +280,14 @@ inline int build(const std::vector<Sightline> &sightlines, int64_t S, const Opti
     // has waves of the ~3 sightlines that are in flight at a time; dealt so that workgroup i works on a sightline
     // b = i (mod 8), every XCD sweeps ONE sightline's operand with all of its waves.  Option "plan_xcd_affine".
     // Round 5: only where the operands are LONG -- one alone at least an XCD's 4 MB of L2 (n_slots >= 2048; the bench's
-    // n = 3000: 6 MB).  Workgroups reach the XCDs round-robin and IN ORDER: workgroup i cannot start before workgroup
-    // i - 1 has, so in a round of eight sightlines of different lengths the XCD with the longest one holds the dispatcher,
-    // and with it the other seven XCDs, back -- a round costs its LONGEST member on every XCD.  On a ragged batch of
-    // DR12Q-sized sightlines (32 sightlines, n_u uniform in 264 ... 1246) the affine dealing ran at 0.50 of peak where the
-    // plain (sightline, block) order -- every XCD sees the same mix, the ~3 operands in flight (<= 2.5 MB each) share the
-    // L2s -- ran at 0.56; at equal lengths n = 685 / 1250 the two orders are within 1 % (profiles/r05_experiments.txt item 8).
+    // n = 3000: 6 MB).  On DR12Q-sized sightlines (operand <= 2.5 MB) the plain (sightline, block) order -- every XCD sees
+    // the same ~3 sightlines in flight -- is within 1 % of the affine order at equal lengths (n = 685 / 1250) and 12 %
+    // FASTER on a ragged batch (32 sightlines, n_u uniform in 264 ... 1246: 0.50 -> 0.58 of peak;
+    // profiles/r05_experiments.txt item 8): with the sightlines sorted by length, XCD 0 got the longest member of EVERY
+    // round of eight and XCD 7 the shortest -- 15 % more work on one XCD than on average, and a launch that ends when that
+    // XCD does.  (A per-item trace, tools/trace_ragged.py, shows every XCD's wave slots 99.8 % occupied while items keep
+    // coming: nobody waits for anybody in the middle of the launch -- the loss is the tail.)  The affine rounds therefore
+    // also alternate their direction (below), so that a long operand's batch stays balanced when its lengths differ.
     const bool batch_of_blocks = !remainder && full == 1 && nb >= 8;
     const bool affine = opt.xcd_affine != 0 && batch_of_blocks && mean_chunks >= (double)opt.affine_min_chunks;
     // Longest sightlines first (a catalogue batch is ragged: n follows z_qso): what is in flight at any moment is of similar
@@ -336,11 +338,13 @@ inline int build(const std::vector<Sightline> &sightlines, int64_t S, const Opti
         }
     };
     if (affine) {
-        // rounds of 8 sightlines, inside a round group-major
+        // rounds of 8 sightlines, inside a round group-major; odd rounds in reverse (the sightlines are sorted by length:
+        // the XCD that gets a round's longest member gets the next round's shortest)
         for (int b0 = 0; b0 < nb; b0 += 8) {
             const int width = std::min(8, nb - b0);
+            const bool reversed = (b0 / 8) % 2 == 1;
             for (long grp = 0; grp < ngroups; ++grp)
-                for (int x = 0; x < width; ++x) emit(order[b0 + x], grp);
+                for (int x = 0; x < width; ++x) emit(order[b0 + (reversed ? width - 1 - x : x)], grp);
         }
     } else {
         // the full pieces in (sightline, group, piece) order -- a batch's sightlines longest first -- then the remainders

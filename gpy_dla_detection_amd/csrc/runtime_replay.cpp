@@ -118,12 +118,33 @@ static int selftest() {
     const bool flagged_in_flight = !fake::check_idle(p, "selftest") && fake::error_count() == before + 1;
     (void)hipStreamSynchronize(stream);
     const bool idle_after_sync = fake::check_idle(p, "selftest");
+    // the shared kernel stream: a call's kernels run on `stream`, its copies on `copies` behind an event, and the call
+    // waits for `copies` only.  That wait covers the kernels before the event -- and not the one launched after it.
+    hipStream_t copies = nullptr;
+    hipEvent_t computed = nullptr;
+    (void)hipStreamCreateWithFlags(&copies, hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&computed, hipEventDisableTiming);
+    double *q = nullptr;
+    (void)hipMalloc((void **)&q, 1024);
+    hipLaunchKernelGGL(nothing, dim3(1), dim3(64), 0, stream, p, 3);
+    (void)hipEventRecord(computed, stream);
+    hipLaunchKernelGGL(nothing, dim3(1), dim3(64), 0, stream, q, 3);
+    (void)hipStreamWaitEvent(copies, computed, 0);
+    (void)hipStreamSynchronize(copies);
+    before = fake::error_count();
+    const bool wait_covers_event = fake::check_idle(p, "selftest") && fake::error_count() == before;
+    const bool wait_stops_at_event = !fake::check_idle(q, "selftest") && fake::error_count() == before + 1;
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(q);
+    (void)hipEventDestroy(computed);
     (void)hipFree(p);
     before = fake::error_count();
     const bool flagged_double_free = hipFree(p) != hipSuccess && fake::error_count() == before + 1;
-    std::printf("{\"selftest\": true, \"in_flight_recycle_flagged\": %s, \"idle_after_sync\": %s, \"double_free_flagged\": %s}\n",
-                flagged_in_flight ? "true" : "false", idle_after_sync ? "true" : "false", flagged_double_free ? "true" : "false");
-    return flagged_in_flight && idle_after_sync && flagged_double_free ? 0 : 1;
+    std::printf("{\"selftest\": true, \"in_flight_recycle_flagged\": %s, \"idle_after_sync\": %s, \"double_free_flagged\": %s, "
+                "\"stream_wait_covers_event\": %s, \"stream_wait_stops_at_event\": %s}\n",
+                flagged_in_flight ? "true" : "false", idle_after_sync ? "true" : "false", flagged_double_free ? "true" : "false",
+                wait_covers_event ? "true" : "false", wait_stops_at_event ? "true" : "false");
+    return flagged_in_flight && idle_after_sync && flagged_double_free && wait_covers_event && wait_stops_at_event ? 0 : 1;
 }
 
 int main(int argc, char **argv) {
@@ -131,6 +152,9 @@ int main(int argc, char **argv) {
     const int per_producer = argc > 1 ? atoi(argv[1]) : 24;
     const unsigned seed = argc > 2 ? (unsigned)atoi(argv[2]) : 1u;
     const int K = 20, S = 96, MAX_DLAS = 3, NB = 4;
+    // odd seeds: every thread's kernels on the one kernel stream of the device (the default); even seeds: on the
+    // thread's own stream
+    if (dlagp_set_option("shared_work_stream", seed % 2) != DLAGP_OK) return 2;
 
     // the learned model: a grid that covers every spectrum's rest wavelengths
     const int n_grid = 400;

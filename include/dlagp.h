@@ -343,12 +343,13 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     "spare_workspaces" (sweep workspaces of destroyed batches kept per device for the next
  *                     batches, default 5), "plan_xcd_affine" (1 = batches of >= 8 sightlines deal their work items so
  *                     that the workgroups of one XCD sweep one sightline's operand at a time -- only where the mean sightline has at least
- *                     "plan_affine_min_chunks" chunks of 8 slots (default 256: an operand of 4 MB, one XCD's L2): on shorter,
- *                     ragged sightlines -- catalogues -- the XCD with the longest sightline of a round holds the in-order
- *                     dispatcher back, and the plain (sightline, block) order, longest first, is the faster one; default 1),
+ *                     "plan_affine_min_chunks" chunks of 8 slots (default 256: an operand of 4 MB, one XCD's L2): on shorter
+ *                     sightlines the plain (sightline, block) order, longest first, is as fast at equal lengths and faster on
+ *                     ragged batches -- catalogues -- where the affine rounds leave the XCDs with unequal work; default 1),
  *                     "shared_work_stream" (1 = the kernels of the host-pointer entry points of ALL host threads go to
- *                     one stream per device, each call waiting for its own completion event; default 0: every
- *                     calling thread has its own stream), "shared_rows" (1 = on the cached levels of a sweep a wave whose
+ *                     one stream per device, each call waiting for its own completion event: launches of different threads
+ *                     run one after the other, transfers and host work overlap them; default 1 since round 5; 0: every
+ *                     calling thread launches on its own stream), "shared_rows" (1 = on the cached levels of a sweep a wave whose
  *                     16 samples stack the same cached profile reads it once per pass; 0 = always 16 reads; identical
  *                     results; default 1), "fuse_finalize" (1 = when the launch plan gives every block of 16 samples ONE
  *                     piece -- batches: more blocks than wave slots -- the accumulate wave also factors its block and

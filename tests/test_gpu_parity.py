@@ -561,7 +561,7 @@ def test_model_evidences_in_one_call_equal_the_three_calls(restore_options):
             np.testing.assert_array_equal(got[2], want[2])  # the resampled base indices
         return got_nulls, got_sub, got_dla
 
-    assert get_option("shared_work_stream") == 0
+    assert get_option("shared_work_stream") == 1  # the default since round 5: one kernel stream per device
     set_option("pair_models", 0)  # this test is about the call structure; the pair launch is switched on where it is compared
     flavours = [dict(), dict(broadening=False), dict(num_lines=5), dict(lls_break=True)]
     for kinds in ([dict()] * 4, flavours):
@@ -637,7 +637,7 @@ def test_model_evidences_in_one_call_equal_the_three_calls(restore_options):
         for t in threads:
             t.join()
         assert not errors, errors
-    set_option("shared_work_stream", 0)
+    set_option("shared_work_stream", 1)
     for h in halves:
         h.close()
 
@@ -794,7 +794,7 @@ def restore_options():
     set_option("pixel_splits", 0)
     set_option("profile_cache", 1)
     set_option("core_patch", 1)
-    set_option("shared_work_stream", 0)
+    set_option("shared_work_stream", 1)
     set_option("shared_rows", 1)
     set_option("negative_noise_mfma", 0)
     set_option("finalize_wave", 1)

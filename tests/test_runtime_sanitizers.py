@@ -52,11 +52,13 @@ def test_the_checker_has_teeth(replay_binaries, kind):
     res, text = run(replay_binaries[kind], "--selftest")
     assert res.returncode == 0, text[-2000:]
     verdict = json.loads(res.stdout.strip().splitlines()[-1])
-    assert verdict == {"selftest": True, "in_flight_recycle_flagged": True, "idle_after_sync": True, "double_free_flagged": True}
+    assert verdict == {"selftest": True, "in_flight_recycle_flagged": True, "idle_after_sync": True, "double_free_flagged": True,
+                       "stream_wait_covers_event": True, "stream_wait_stops_at_event": True}
 
 
 @pytest.mark.parametrize("kind,seed", [("tsan", 1), ("tsan", 2), ("asan", 1), ("asan", 2)])
 def test_catalogue_call_pattern_over_the_fake_device(replay_binaries, kind, seed):
+    """odd seeds run with the one shared kernel stream per device (the default), even seeds with per-thread streams"""
     res, text = run(replay_binaries[kind], "250", str(seed))
     assert res.returncode == 0, text[-4000:]
     summary = json.loads(res.stdout.strip().splitlines()[-1])
