@@ -2462,6 +2462,13 @@ int dlagp_get_option(const char *name, int64_t *value) try {
     else if (!strcmp(name, "last_sweep_cached")) *value = g_last_sweep_cached;
     else if (!strcmp(name, "last_launch_patch")) *value = g_last_launch_patch;
     else if (!strcmp(name, "last_launch_groups")) *value = g_last_launch_groups;
+    else if (!strcmp(name, "work_stream_idle")) {
+        // diagnostics (tools/measure_catalogue.py, DLAGP_POLL_IDLE): 1 when the current device's shared kernel stream has
+        // nothing queued or running -- polled from a side thread it says how often the host leaves the device without work
+        int device = 0;
+        HIP_TRY(hipGetDevice(&device));
+        *value = g_opt_shared_work_stream && hipStreamQuery(compute_stream(device)) == hipSuccess;
+    }
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 } DLAGP_CATCH_INT("dlagp_get_option")

@@ -41,7 +41,7 @@
 #define DLAGP_FAKE_PRINT_STACK() ((void)0)
 #endif
 
-enum hipError_t { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorInvalidDevice = 101 };
+enum hipError_t { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorInvalidDevice = 101, hipErrorNotReady = 600 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
@@ -301,6 +301,10 @@ inline hipError_t hipStreamSynchronize(hipStream_t stream) {
     fake::Stream *s = fake::resolve(stream);
     fake::complete(s, s->issued.load());
     return hipSuccess;
+}
+inline hipError_t hipStreamQuery(hipStream_t stream) {
+    fake::Stream *s = fake::resolve(stream);
+    return s->completed.load() >= s->issued.load() ? hipSuccess : hipErrorNotReady;
 }
 inline hipError_t hipDeviceSynchronize() {
     fake::State &st = fake::state();

@@ -29,6 +29,7 @@ from scipy.special import logsumexp
 from . import parallel
 from .dla_gp import map_traceback
 from .null_gp import prepare_data
+from .samples import DLASamples, SubDLASamples
 from .set_parameters import Parameters
 
 LearnedModel = namedtuple(
@@ -79,15 +80,22 @@ def occupation_log_priors(prior, z_qso: float, max_dlas: int, dla_samples, subdl
 
 
 def _empty_results(num: int, S: int, max_dlas: int) -> Dict[str, np.ndarray]:
+    """
+    The result arrays of `num` quasars.  The per-quasar values start as NaN (the reference's np.full / np.nan fills,
+    run_bayes_select.py:116-139).  The three per-SAMPLE arrays -- 80 KB x (2 max_dlas) per quasar, 1 GB for 2048 quasars --
+    are handed out untouched: every row is written whole when its batch finishes (`finish`), a failed batch ends the
+    run, and filling them first kept the device waiting for 7 % of a 2048-spectrum run while one thread touched a
+    gigabyte of fresh pages.
+    """
     nan = lambda *shape: np.full(shape, np.nan)  # noqa: E731
     return dict(
         min_z_dlas=nan(num), max_z_dlas=nan(num),
         log_priors_no_dla=nan(num), log_priors_dla=nan(num, max_dlas), log_priors_lls=nan(num),
         log_likelihoods_no_dla=nan(num), log_likelihoods_dla=nan(num, max_dlas), log_likelihoods_lls=nan(num),
         log_posteriors_no_dla=nan(num), log_posteriors_dla=nan(num, max_dlas), log_posteriors_lls=nan(num),
-        sample_log_likelihoods_dla=nan(num, S, max_dlas),
-        base_sample_inds=np.zeros((num, S, max_dlas - 1), dtype=np.int32),
-        sample_log_likelihoods_lls=nan(num, S),
+        sample_log_likelihoods_dla=np.empty((num, S, max_dlas)),
+        base_sample_inds=np.empty((num, S, max_dlas - 1), dtype=np.int32),
+        sample_log_likelihoods_lls=np.empty((num, S)),
         MAP_z_dlas=nan(num, max_dlas, max_dlas), MAP_log_nhis=nan(num, max_dlas, max_dlas),
         model_posteriors=nan(num, 2 + max_dlas), p_dlas=nan(num), p_no_dlas=nan(num),
     )
@@ -217,22 +225,46 @@ def process_qso(
     nhi_dla = np.asarray(dla_samples.nhi_samples, dtype=np.float64)
     nhi_sub = np.asarray(subdla_samples.nhi_samples, dtype=np.float64)
 
+    # The sample redshifts of a spectrum are `z_min + (z_max - z_min) * offsets` for both sample holders
+    # (samples.DLASamples._map_offsets; reference dla_samples.py:94-104, subdla_samples.py:115-125).  With the stock
+    # holders the two bounds are found ONCE per spectrum and the tables of a whole batch come out of one broadcast
+    # expression -- element by element the same multiply and add -- and when the two holders carry the same offsets the
+    # sub-DLA table IS the DLA table (the library then shares one optical depth between the two models).  One thread
+    # prepares for three that sweep: per spectrum this was 6 searches for the bounds and 2 x S-element expressions.
+    stock_holders = (type(dla_samples).sample_z_dlas is DLASamples.sample_z_dlas
+                     and type(subdla_samples).sample_z_lls is SubDLASamples.sample_z_lls
+                     and type(dla_samples)._map_offsets is DLASamples._map_offsets
+                     and type(subdla_samples)._map_offsets is DLASamples._map_offsets
+                     and dla_samples.params is params and subdla_samples.params is params)
+    same_offsets = stock_holders and np.array_equal(dla_samples.offset_samples, subdla_samples.offset_samples)
+
     def prepare(start: int, stop: int):
         """host index logic + device contexts of local rows [start, stop): everything a sweep needs"""
-        sightlines, z_dla, z_lls = [], [], []
-        for i in range(start, stop):
-            q = int(mine[i])
-            wavelengths, flux, noise_variance, pixel_mask = spectra[q]
-            z_qso = z_qso_list[q]
-            rest_wavelengths = params.emitted_wavelengths(wavelengths, z_qso)
-            st = prepare_data(params, rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, normalize=True)
-            sightlines.append(engine.sightline(st, z_qso, broadening))
-            z_dla.append(dla_samples.sample_z_dlas(st["this_wavelengths"], z_qso))
-            z_lls.append(subdla_samples.sample_z_lls(st["this_wavelengths"], z_qso))
-            local["min_z_dlas"][i] = params.min_z_dla(wavelengths, z_qso)
-            local["max_z_dlas"][i] = params.max_z_dla(wavelengths, z_qso)
+        sightlines, z_dla, z_lls, bounds_z = [], [], [], []
         try:
-            return sightlines, engine.batch(sightlines), np.stack(z_dla), np.stack(z_lls)
+            for i in range(start, stop):
+                q = int(mine[i])
+                wavelengths, flux, noise_variance, pixel_mask = spectra[q]
+                z_qso = z_qso_list[q]
+                rest_wavelengths = params.emitted_wavelengths(wavelengths, z_qso)
+                st = prepare_data(params, rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, normalize=True)
+                sightlines.append(engine.sightline(st, z_qso, broadening))
+                if stock_holders:
+                    kept = st["this_wavelengths"]
+                    bounds_z.append((params.min_z_dla(kept, z_qso), params.max_z_dla(kept, z_qso)))
+                else:
+                    z_dla.append(dla_samples.sample_z_dlas(st["this_wavelengths"], z_qso))
+                    z_lls.append(subdla_samples.sample_z_lls(st["this_wavelengths"], z_qso))
+                local["min_z_dlas"][i] = params.min_z_dla(wavelengths, z_qso)
+                local["max_z_dlas"][i] = params.max_z_dla(wavelengths, z_qso)
+            if stock_holders:
+                z_min = np.array([b[0] for b in bounds_z], dtype=np.float64)[:, None]
+                width = np.array([b[1] - b[0] for b in bounds_z], dtype=np.float64)[:, None]
+                z_dla = z_min + width * dla_samples.offset_samples[None, :]
+                z_lls = z_dla if same_offsets else z_min + width * subdla_samples.offset_samples[None, :]
+            else:
+                z_dla, z_lls = np.stack(z_dla), np.stack(z_lls)
+            return sightlines, engine.batch(sightlines), z_dla, z_lls
         except BaseException:
             for s in sightlines:  # a batch that could not be built must not leave its contexts behind
                 if hasattr(s, "close"):

@@ -442,6 +442,76 @@ def assert_catalogue_matches_golden(results, g, rtol):
     assert int(results["num_dla_samples"]) == S and int(results["k"]) == 20
 
 
+class RecordingEngine:
+    """records the redshift tables `process_qso` hands to the sweeps; returns empty evidences"""
+
+    def __init__(self):
+        self.tables = []
+
+    def sightline(self, state, z_qso, broadening):
+        return state["this_wavelengths"]
+
+    def batch(self, sightlines):
+        return list(sightlines)
+
+    def model_evidences(self, batch, z_lls, nhi_sub, z_dla, nhi_dla, max_dlas, min_z_separation, seed):
+        self.tables.append((z_lls, z_dla))
+        nb, S = z_dla.shape
+        ll = np.zeros((nb, S, max_dlas))
+        return (np.zeros(nb), (np.zeros((nb, 1)), np.zeros((nb, S, 1)), None),
+                (np.zeros((nb, max_dlas)), ll, np.zeros((nb, max_dlas - 1, S), dtype=np.int32)))
+
+    def release(self, batch, sightlines):
+        pass
+
+
+def test_batched_sample_redshifts_are_the_holders_own():
+    """
+    `process_qso` forms the redshift tables of a whole batch in one broadcast expression when the sample holders are the
+    stock ones: element for element what `sample_z_dlas` / `sample_z_lls` return per spectrum (reference
+    dla_samples.py:94-104, subdla_samples.py:115-125), and ONE table for both models when their offsets coincide.
+    """
+    from gpy_dla_detection_amd.run_bayes_select import process_qso
+    from gpy_dla_detection_amd.samples import DLASamples, SubDLASamples
+
+    S = 257
+    learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(S)
+
+    class MyDLASamples(DLASamples):  # any subclass takes the per-spectrum route through the holder's methods
+        def sample_z_dlas(self, wavelengths, z_qso):
+            return super().sample_z_dlas(wavelengths, z_qso)
+
+    u = halton(S, 3)
+    own_route = RecordingEngine()
+    process_qso(spectra, z_qsos, params, FixedPrior(), MyDLASamples(params, None, halton(S, 2), 20.0 + 3.0 * u), sub_samples,
+                learned, max_dlas=2, batch_size=2, engine=own_route, prefetch=False)
+    batched = RecordingEngine()
+    process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=2, batch_size=2,
+                engine=batched, prefetch=False)
+    other_offsets = SubDLASamples(params, None, halton(S, 5), 19.5 + 0.5 * u, Z_dla=1.0, Z_lls=0.25)
+    distinct = RecordingEngine()
+    process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, other_offsets, learned, max_dlas=2, batch_size=2,
+                engine=distinct, prefetch=False)
+    assert len(batched.tables) == len(own_route.tables) == 2
+    for (lls_a, dla_a), (lls_b, dla_b), (lls_c, dla_c) in zip(own_route.tables, batched.tables, distinct.tables):
+        assert lls_a is not dla_a
+        assert lls_b is dla_b  # same offsets: one table, the library pairs the two models on it
+        np.testing.assert_array_equal(dla_b, dla_a)
+        np.testing.assert_array_equal(lls_b, lls_a)
+        assert lls_c is not dla_c and not np.array_equal(lls_c, dla_c)
+        np.testing.assert_array_equal(dla_c, dla_a)
+    row = other_offsets.sample_z_lls(params.observed_wavelengths(
+        prepare_state(params, spectra[0], z_qsos[0])["x"], z_qsos[0]), z_qsos[0])
+    np.testing.assert_array_equal(distinct.tables[0][0][0], row)
+
+
+def prepare_state(params, spectrum, z_qso):
+    from gpy_dla_detection_amd.null_gp import prepare_data
+
+    wavelengths, flux, noise_variance, pixel_mask = spectrum
+    return prepare_data(params, params.emitted_wavelengths(wavelengths, z_qso), flux, noise_variance, pixel_mask, z_qso)
+
+
 def test_process_qso_matches_reference_driver_golden(tmp_path):
     from gpy_dla_detection_amd.run_bayes_select import process_qso, write_results
     from tests.golden_inputs import checksum as crc

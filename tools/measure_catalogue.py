@@ -4,7 +4,11 @@ End-to-end catalogue throughput on one GPU: raw spectra -> run_bayes_select.proc
 the reference's output arrays.  Synthetic SDSS-like spectra (4600 pixels at 1e-4 dex from 3631 A),
 S = 10 000 QMC samples, max_dlas = 4.  Prints one JSON object with spectra/s and a phase split.
 
-    python3 tools/measure_catalogue.py [spectra] [S] [batch size] [mix]
+    python3 tools/measure_catalogue.py [spectra] [S] [batch size] [mix] [sweeps-only]
+
+With a fifth argument `sweeps-only` the batches (at most 12) are prepared first and only their model selections are timed,
+one after the other on one thread: what the device does with the pipeline's work when nothing else shares it -- the
+bound the pipeline's spectra/s is to be read against.
 
 The kept pixels n of a spectrum follow z_qso through the modelled window 911.75-1215.75 A (reference
 set_parameters.py:33-34, null_gp.py:139-152): the window is entered at z_qso ~ 2.0 and fully covered, n = 1250, from
@@ -61,6 +65,38 @@ def make_inputs(num, k=20, seed=7, mix="uniform"):
     return learned, spectra, z_qsos
 
 
+def sweeps_only(spectra, z_qsos, params, dla, sub, learned, batch_size, S):
+    from gpy_dla_detection_amd.null_gp import prepare_data
+    from gpy_dla_detection_amd.run_bayes_select import DeviceEngine
+
+    engine = DeviceEngine(learned, params)
+    nhi_dla = np.asarray(dla.nhi_samples, dtype=np.float64)
+    nhi_sub = np.asarray(sub.nhi_samples, dtype=np.float64)
+    min_sep = params.kms_to_z(3000.0)
+    prepared = []
+    for start in range(0, min(len(spectra), 12 * batch_size), batch_size):
+        sightlines, z_dla, z_lls = [], [], []
+        for q in range(start, min(start + batch_size, len(spectra))):
+            wavelengths, flux, noise_variance, pixel_mask = spectra[q]
+            rest = params.emitted_wavelengths(wavelengths, z_qsos[q])
+            st = prepare_data(params, rest, flux, noise_variance, pixel_mask, z_qsos[q], normalize=True)
+            sightlines.append(engine.sightline(st, z_qsos[q], True))
+            z_dla.append(dla.sample_z_dlas(st["this_wavelengths"], z_qsos[q]))
+            z_lls.append(sub.sample_z_lls(st["this_wavelengths"], z_qsos[q]))
+        prepared.append((sightlines, engine.batch(sightlines), np.stack(z_dla), np.stack(z_lls)))
+    times = []
+    for rep in range(3):  # the first round allocates the workspaces
+        t0 = time.perf_counter()
+        for sightlines, batch, z_dla, z_lls in prepared:
+            engine.model_evidences(batch, z_lls, nhi_sub, z_dla, nhi_dla, 4, min_sep, 0)
+        times.append(time.perf_counter() - t0)
+    count = sum(len(p[0]) for p in prepared)
+    for sightlines, batch, _, _ in prepared:
+        engine.release(batch, sightlines)
+    engine.close()
+    return {"batches": len(prepared), "spectra": count, "seconds_per_round": times, "spectra_per_s": count / min(times[1:])}
+
+
 def main():
     num = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
@@ -76,6 +112,13 @@ def main():
     from gpy_dla_detection_amd.run_bayes_select import kept_pixel_counts
 
     kept = kept_pixel_counts(params, spectra, z_qsos)
+    if len(sys.argv) > 5 and sys.argv[5] == "sweeps-only":
+        out = sweeps_only(spectra, z_qsos, params, dla, sub, learned, batch_size, S)
+        used = kept[: out["spectra"]]
+        out.update({"mix": mix, "S": S, "batch_size": batch_size, "kept_pixels_mean": float(used.mean()),
+                    "frac_of_fp64_peak": float(used.sum()) * (20 * 21 + 40) * 5 * S / (out["spectra"] / out["spectra_per_s"]) / 78.6e12})
+        print(json.dumps(out))
+        return
     for item in os.environ.get("DLAGP_OPTIONS", "").split(","):  # e.g. DLAGP_OPTIONS=shared_work_stream=0
         if item:
             from gpy_dla_detection_amd.sightline import set_option
@@ -92,9 +135,48 @@ def main():
 
     allocs_before = (get_option("big_allocs"), get_option("big_frees"))
     free_before = torch.cuda.mem_get_info()[0]
+    polls = [0, 0]
+    idle_at, calls = [], []
+    if os.environ.get("DLAGP_POLL_IDLE"):  # a side thread asks every 0.5 ms whether the kernel stream has run dry
+        import threading
+
+        stop_polling = threading.Event()
+
+        def poll():
+            torch.cuda.set_device(0)
+            while not stop_polling.is_set():
+                polls[0] += 1
+                if get_option("work_stream_idle"):
+                    polls[1] += 1
+                    idle_at.append(time.perf_counter())
+                time.sleep(0.0005)
+
+        if os.environ.get("DLAGP_POLL_IDLE") == "who":
+            # ... and what every worker thread was inside at those instants (the engine's calls, timed)
+            from gpy_dla_detection_amd import run_bayes_select as rbs
+
+            def timed(name, fn):
+                def wrapper(*args, **kwargs):
+                    t0 = time.perf_counter()
+                    try:
+                        return fn(*args, **kwargs)
+                    finally:
+                        calls.append((name, threading.get_ident(), t0, time.perf_counter()))
+                return wrapper
+
+            for name in ("sightline", "batch", "model_evidences", "release"):
+                setattr(rbs.DeviceEngine, name, timed(name, getattr(rbs.DeviceEngine, name)))
+            rbs.prepare_data = timed("prepare_data", rbs.prepare_data)
+            rbs.occupation_log_priors = timed("log_priors", rbs.occupation_log_priors)
+
+        poller = threading.Thread(target=poll, daemon=True)
+        poller.start()
     t0 = time.perf_counter()
     res = process_qso(spectra, z_qsos, params, FixedPrior(), dla, sub, learned, batch_size=batch_size)
     t = time.perf_counter() - t0
+    if polls[0]:
+        stop_polling.set()
+        poller.join()
     free_after = torch.cuda.mem_get_info()[0]
     out = {
         "spectra": num, "S": S, "max_dlas": 4, "batch_size": batch_size, "seconds": t, "mix": mix,
@@ -108,6 +190,49 @@ def main():
         "hbm_growth_during_run_gb": round((free_before - free_after) / 2 ** 30, 3),
         "workspace_allocs_frees_during_run": [get_option("big_allocs") - allocs_before[0], get_option("big_frees") - allocs_before[1]],
     }
+    if polls[0]:
+        out["kernel_stream_idle"] = {"polls": polls[0], "found_idle": polls[1], "share": polls[1] / polls[0]}
+    if calls:
+        from collections import Counter
+
+        names = {"sightline": "p", "prepare_data": "p", "batch": "B", "model_evidences": "S", "release": "r", "log_priors": "f"}
+        states = Counter()
+        for t in idle_at:
+            inside = sorted(names[n] for n, _, a, b in calls if a <= t <= b)
+            states["".join(inside) or "-"] += 1
+        # p: a context being made, B: a batch object being made, S: a thread inside the library's model selection call,
+        # f / r: finishing; e.g. "SS" = two sweep threads inside the call, nobody preparing
+        out["threads_inside_at_idle_instants"] = dict(states.most_common(12))
+        sweeps = sorted((a, b) for n, _, a, b in calls if n == "model_evidences")
+        out["model_evidences_ms"] = {"mean": 1e3 * float(np.mean([b - a for a, b in sweeps])), "calls": len(sweeps)}
+    if os.environ.get("DLAGP_PROFILE_THREADS"):
+        # where the HOST's time goes, worker threads included: one cProfile per thread on the thread's own CPU clock
+        # (waiting for the interpreter lock or inside a blocking call does not count), merged
+        import cProfile
+        import pstats
+        import threading
+
+        profilers = []
+
+        def first_event(*_):
+            sys.setprofile(None)
+            pr = cProfile.Profile(time.thread_time)
+            profilers.append(pr)
+            pr.enable()
+
+        threading.setprofile(first_event)
+        t0 = time.perf_counter()
+        process_qso(spectra, z_qsos, params, FixedPrior(), dla, sub, learned, batch_size=batch_size)
+        out["profiled_run_seconds"] = time.perf_counter() - t0
+        threading.setprofile(None)
+        stats = None
+        for pr in profilers:
+            pr.create_stats()
+            if stats is None:
+                stats = pstats.Stats(pr)
+            else:
+                stats.add(pr)
+        stats.sort_stats("tottime").print_stats(45)
     if os.environ.get("DLAGP_PROFILE"):
         import cProfile
         import pstats
