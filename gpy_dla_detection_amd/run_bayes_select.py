@@ -328,6 +328,12 @@ def process_qso(
     # `prefetch=False` -- and seed=None, whose draws come from the global RNG in catalogue order -- runs everything in
     # this thread, in order.
     bounds = [(start, min(start + batch_size, len(mine))) for start in range(0, len(mine), batch_size)]
+    if prefetch and seed is not None and len(mine) > 3 * batch_size >= 12:
+        # the device waits while the first batch is prepared: the pipeline starts on a quarter and a half batch (a
+        # spectrum's results do not depend on the batch it rides in)
+        ramp = (batch_size // 4, batch_size // 4 + batch_size // 2)
+        bounds = [(0, ramp[0]), ramp] + [(start, min(start + batch_size, len(mine)))
+                                         for start in range(ramp[1], len(mine), batch_size)]
 
     def sweep_and_finish(start, stop, sightlines, batch, z_dla, z_lls):
         """whatever happens in the sweeps or the bookkeeping, the batch's contexts and workspace go back"""

@@ -371,7 +371,8 @@ int dlagp_set_option(const char *name, int64_t value);
  * broadening or Lyman-limit flags), "last_launch_fused" (1 = the accumulate waves of the last launch finished their own
  * blocks, see "fuse_finalize"), "big_allocs" / "big_frees" (sweep-workspace buffers above the pool's 64 MB
  * limit allocated / freed since the library was loaded -- a free synchronises the device; a pipelined run in its steady
- * state shows neither). */
+ * state shows neither), "work_stream_idle" (1 = the current device's shared kernel stream has nothing queued or running
+ * at this instant: polled from a side thread it says how often the host leaves the device without work). */
 int dlagp_get_option(const char *name, int64_t *value);
 /* The work decomposition the MFMA path would choose for `groups` blocks of 16 samples of sightlines with `chunks`
  * chunks of 8 pixel slots each (pure host arithmetic, no device needed): every block is cut into `full` pieces of

@@ -505,6 +505,34 @@ def test_batched_sample_redshifts_are_the_holders_own():
     np.testing.assert_array_equal(distinct.tables[0][0][0], row)
 
 
+def test_pipeline_starts_on_short_batches():
+    """
+    the pipelined driver begins with a quarter and a half batch (the device waits for the first batch's preparation);
+    every spectrum's row lands where the in-order run puts it
+    """
+    from gpy_dla_detection_amd.run_bayes_select import process_qso
+
+    S = 64
+    learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(S)
+    spectra, z_qsos = list(spectra) * 10, [z + 0.001 * i for i, z in enumerate(list(z_qsos) * 10)]
+
+    class Engine(RecordingEngine):
+        def model_evidences(self, batch, z_lls, nhi_sub, z_dla, nhi_dla, max_dlas, min_z_separation, seed):
+            out = super().model_evidences(batch, z_lls, nhi_sub, z_dla, nhi_dla, max_dlas, min_z_separation, seed)
+            return (z_dla[:, 0].copy(),) + out[1:]  # a value that names the spectrum
+
+    piped, in_order = Engine(), Engine()
+    a = process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=2, batch_size=8,
+                    engine=piped)
+    b = process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=2, batch_size=8,
+                    engine=in_order, prefetch=False)
+    assert sorted(t[1].shape[0] for t in piped.tables) == [2, 4, 8, 8, 8]
+    assert [t[1].shape[0] for t in in_order.tables] == [8, 8, 8, 6]
+    for name in ("log_likelihoods_no_dla", "min_z_dlas", "max_z_dlas", "sample_log_likelihoods_dla", "base_sample_inds"):
+        np.testing.assert_array_equal(a[name], b[name], err_msg=name)
+    assert len(set(a["log_likelihoods_no_dla"])) == 30
+
+
 def prepare_state(params, spectrum, z_qso):
     from gpy_dla_detection_amd.null_gp import prepare_data
 
