@@ -44,9 +44,20 @@ s = b["strong_n1"]
 print("| by-sample split at N = 1 | %.4f ms, %.1f M evals/s | `%s_bench.json` |" % (s["ms_per_step"], s["evals_per_s"] / 1e6, tag))
 for name, label in (("catalogue_pipeline.json", "z_qso uniform in [2.2, 3.4]"), ("catalogue_pipeline_dr12q.json", "DR12Q-like z_qso")):
     x = load(name)
-    print("| catalogue driver, 2048 spectra, %s (n median %.0f, mean %.0f) | **%.0f spectra/s**, %.1f M evals/s, whole run %.1f %% of FP64 peak | `%s_%s` |"
+    idle = x.get("kernel_stream_idle")
+    print("| catalogue driver, 2048 spectra, %s (n median %.0f, mean %.0f) | **%.0f spectra/s**, %.1f M evals/s, whole run %.1f %% of FP64 peak%s | `%s_%s` |"
           % (label, x["kept_pixels"]["median"], x["kept_pixels"]["mean"], x["spectra_per_s"], x["evals_per_s"] / 1e6,
-             100 * x["whole_run_frac_of_fp64_peak"], tag, name))
+             100 * x["whole_run_frac_of_fp64_peak"],
+             ", kernel stream found empty at %.1f %% of %d polls" % (100 * idle["share"], idle["polls"]) if idle else "", tag, name))
+try:
+    x = load("catalogue_pipeline_dr12q_8192.json")
+    print("| catalogue driver, 8192 spectra, DR12Q-like z_qso | **%.0f spectra/s**, whole run %.1f %% of FP64 peak | `%s_catalogue_pipeline_dr12q_8192.json` |"
+          % (x["spectra_per_s"], 100 * x["whole_run_frac_of_fp64_peak"], tag))
+    x = load("bench_pixels_685.json")
+    print("| one sightline of DR12Q's median length (`bench.py --pixels 685`: n = %d) | step %.4f ms → **%.1f M evals/s**; accumulate %.4f ms = %.1f %% of peak | `%s_bench_pixels_685.json` |"
+          % (round(x["roofline"]["flop_per_eval"] / 460), x["ms_per_step"], x["value"] / 1e6, x["roofline"]["kernel_ms"], 100 * x["roofline"]["frac"], tag))
+except (OSError, KeyError):
+    pass
 x = load("route_a.json")
 print("| route A (reference driver loop, imports swapped), 256 spectra | **%.2f ms per spectrum** (%.0f spectra/s) | `%s_route_a.json` |"
       % (x["ms_per_spectrum"], x["spectra_per_s"], tag))
