@@ -84,17 +84,25 @@ def sweeps_only(spectra, z_qsos, params, dla, sub, learned, batch_size, S):
             z_dla.append(dla.sample_z_dlas(st["this_wavelengths"], z_qsos[q]))
             z_lls.append(sub.sample_z_lls(st["this_wavelengths"], z_qsos[q]))
         prepared.append((sightlines, engine.batch(sightlines), np.stack(z_dla), np.stack(z_lls)))
+    from gpy_dla_detection_amd.sightline import set_option, timing_read
+
     times = []
     for rep in range(3):  # the first round allocates the workspaces
+        if rep == 2:
+            set_option("timing", 1)  # event pairs around the accumulate launches of the last round
+            timing_read(True)
         t0 = time.perf_counter()
         for sightlines, batch, z_dla, z_lls in prepared:
             engine.model_evidences(batch, z_lls, nhi_sub, z_dla, nhi_dla, 4, min_sep, 0)
         times.append(time.perf_counter() - t0)
+    accumulate_ms, launches = timing_read(True)
+    set_option("timing", 0)
     count = sum(len(p[0]) for p in prepared)
     for sightlines, batch, _, _ in prepared:
         engine.release(batch, sightlines)
     engine.close()
-    return {"batches": len(prepared), "spectra": count, "seconds_per_round": times, "spectra_per_s": count / min(times[1:])}
+    return {"batches": len(prepared), "spectra": count, "seconds_per_round": times, "spectra_per_s": count / min(times[1:]),
+            "accumulate_ms_last_round": accumulate_ms, "accumulate_launches_last_round": launches}
 
 
 def main():
@@ -115,6 +123,7 @@ def main():
     if len(sys.argv) > 5 and sys.argv[5] == "sweeps-only":
         out = sweeps_only(spectra, z_qsos, params, dla, sub, learned, batch_size, S)
         used = kept[: out["spectra"]]
+        out["accumulate_frac_of_fp64_peak"] = float(used.sum()) * (20 * 21 + 40) * 5 * S / (out["accumulate_ms_last_round"] * 1e-3) / 78.6e12
         out.update({"mix": mix, "S": S, "batch_size": batch_size, "kept_pixels_mean": float(used.mean()),
                     "frac_of_fp64_peak": float(used.sum()) * (20 * 21 + 40) * 5 * S / (out["spectra"] / out["spectra_per_s"]) / 78.6e12})
         print(json.dumps(out))
@@ -171,9 +180,15 @@ def main():
 
         poller = threading.Thread(target=poll, daemon=True)
         poller.start()
+    if os.environ.get("DLAGP_TIME_ACCUMULATE"):  # event pairs around every accumulate launch of the timed run
+        from gpy_dla_detection_amd.sightline import set_option, timing_read
+
+        set_option("timing", 1)
+        timing_read(True)
     t0 = time.perf_counter()
     res = process_qso(spectra, z_qsos, params, FixedPrior(), dla, sub, learned, batch_size=batch_size)
     t = time.perf_counter() - t0
+    accumulate = timing_read(True) if os.environ.get("DLAGP_TIME_ACCUMULATE") else None
     if polls[0]:
         stop_polling.set()
         poller.join()
@@ -190,6 +205,12 @@ def main():
         "hbm_growth_during_run_gb": round((free_before - free_after) / 2 ** 30, 3),
         "workspace_allocs_frees_during_run": [get_option("big_allocs") - allocs_before[0], get_option("big_frees") - allocs_before[1]],
     }
+    if accumulate:
+        # the accumulate kernels' own time inside the pipeline: against `seconds` it says how much of the run they fill,
+        # against the same sweeps run alone (sweeps-only) how much the work beside them slows them down
+        out["accumulate_ms"], out["accumulate_launches"] = accumulate
+        out["accumulate_frac_of_fp64_peak"] = float(kept.sum()) * (20 * 21 + 40) * 5 * S / (accumulate[0] * 1e-3) / 78.6e12
+        out["accumulate_share_of_run"] = accumulate[0] * 1e-3 / t
     if polls[0]:
         out["kernel_stream_idle"] = {"polls": polls[0], "found_idle": polls[1], "share": polls[1] / polls[0]}
     if calls:
