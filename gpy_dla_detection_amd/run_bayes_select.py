@@ -236,6 +236,11 @@ def process_qso(
                      and type(dla_samples)._map_offsets is DLASamples._map_offsets
                      and type(subdla_samples)._map_offsets is DLASamples._map_offsets
                      and dla_samples.params is params and subdla_samples.params is params)
+    if (type(params).min_z_dla is Parameters.min_z_dla and type(params).max_z_dla is Parameters.max_z_dla
+            and type(params)._in_model_range is Parameters._in_model_range):
+        z_range = params.z_dla_range  # both bounds from one in-range test
+    else:
+        z_range = lambda w, z: (params.min_z_dla(w, z), params.max_z_dla(w, z))  # noqa: E731
     same_offsets = stock_holders and np.array_equal(dla_samples.offset_samples, subdla_samples.offset_samples)
 
     def prepare(start: int, stop: int):
@@ -250,13 +255,11 @@ def process_qso(
                 st = prepare_data(params, rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, normalize=True)
                 sightlines.append(engine.sightline(st, z_qso, broadening))
                 if stock_holders:
-                    kept = st["this_wavelengths"]
-                    bounds_z.append((params.min_z_dla(kept, z_qso), params.max_z_dla(kept, z_qso)))
+                    bounds_z.append(z_range(st["this_wavelengths"], z_qso))
                 else:
                     z_dla.append(dla_samples.sample_z_dlas(st["this_wavelengths"], z_qso))
                     z_lls.append(subdla_samples.sample_z_lls(st["this_wavelengths"], z_qso))
-                local["min_z_dlas"][i] = params.min_z_dla(wavelengths, z_qso)
-                local["max_z_dlas"][i] = params.max_z_dla(wavelengths, z_qso)
+                local["min_z_dlas"][i], local["max_z_dlas"][i] = z_range(wavelengths, z_qso)
             if stock_holders:
                 z_min = np.array([b[0] for b in bounds_z], dtype=np.float64)[:, None]
                 width = np.array([b[1] - b[0] for b in bounds_z], dtype=np.float64)[:, None]
@@ -285,25 +288,37 @@ def process_qso(
         if np.isneginf(masked.max(axis=1)).any():
             raise ValueError("All-NaN slice encountered")  # what np.nanargmax says about a level without a finite sample
         log_nhi = dla_samples.log_nhi_samples
-        for b, i in enumerate(range(start, stop)):
-            q = int(mine[i])
-            log_priors = occupation_log_priors(prior, z_qso_list[q], max_dlas, dla_samples, subdla_samples)
-            log_likelihoods = np.concatenate([[nulls[b]], ev_sub[b], ev_dla[b]])
-            log_posteriors = log_likelihoods + log_priors
-            for name, values in (("log_priors", log_priors), ("log_likelihoods", log_likelihoods),
-                                 ("log_posteriors", log_posteriors)):
-                local[name + "_no_dla"][i] = values[0]
-                local[name + "_lls"][i] = values[1]
-                local[name + "_dla"][i] = values[-max_dlas:]
-            for level in range(max_dlas):  # dla_gp.map_traceback with the level's best sample already known
-                top = best[b, level]
-                members = [top] + [base[b, j, top] for j in range(level)]
-                local["MAP_z_dlas"][i, level, : level + 1] = z_dla[b][members]
-                local["MAP_log_nhis"][i, level, : level + 1] = log_nhi[members]
-            posteriors = np.exp(log_posteriors - _logsumexp(log_posteriors))
-            local["model_posteriors"][i] = posteriors
-            local["p_dlas"][i] = np.sum(posteriors[-max_dlas:])
-            local["p_no_dlas"][i] = 1 - local["p_dlas"][i]
+        # The bookkeeping of the batch's spectra as a handful of array expressions instead of ~40 small NumPy calls per
+        # spectrum (this thread holds the interpreter lock the preparing and sweeping threads also need): element for
+        # element the per-spectrum expressions of the reference's loop body (tests/test_host_logic.py holds them to it).
+        nb = stop - start
+        log_priors = np.stack([occupation_log_priors(prior, z_qso_list[int(mine[i])], max_dlas, dla_samples, subdla_samples)
+                               for i in range(start, stop)])  # the prior object is the caller's: one call per spectrum
+        log_likelihoods = np.concatenate([np.asarray(nulls, dtype=np.float64).reshape(nb, 1), ev_sub, ev_dla], axis=1)
+        log_posteriors = log_likelihoods + log_priors
+        for name, values in (("log_priors", log_priors), ("log_likelihoods", log_likelihoods),
+                             ("log_posteriors", log_posteriors)):
+            local[name + "_no_dla"][rows] = values[:, 0]
+            local[name + "_lls"][rows] = values[:, 1]
+            local[name + "_dla"][rows] = values[:, -max_dlas:]
+        every = np.arange(nb)
+        for level in range(max_dlas):  # dla_gp.map_traceback with the level's best sample already known
+            members = np.empty((nb, level + 1), dtype=np.intp)
+            members[:, 0] = best[:, level]
+            for j in range(level):
+                members[:, j + 1] = base[every, j, best[:, level]]
+            local["MAP_z_dlas"][rows, level, : level + 1] = z_dla[every[:, None], members]
+            local["MAP_log_nhis"][rows, level, : level + 1] = log_nhi[members]
+        finite = np.isfinite(log_posteriors).all(axis=1)
+        top = log_posteriors.max(axis=1)
+        with np.errstate(invalid="ignore", over="ignore"):
+            norm = top + np.log(np.exp(log_posteriors - top[:, None]).sum(axis=1))
+        for b in np.flatnonzero(~finite):  # NaN of a stopped sweep, infinities: scipy's general routine (see _logsumexp)
+            norm[b] = _logsumexp(log_posteriors[b])
+        posteriors = np.exp(log_posteriors - norm[:, None])
+        local["model_posteriors"][rows] = posteriors
+        local["p_dlas"][rows] = posteriors[:, -max_dlas:].sum(axis=1)
+        local["p_no_dlas"][rows] = 1 - local["p_dlas"][rows]
 
     def sweeps(sightlines, batch, z_dla, z_lls):
         """the three models of one batch: null evidences, sub-DLA sweep, DLA sweep"""

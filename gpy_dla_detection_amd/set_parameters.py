@@ -113,5 +113,18 @@ class Parameters:
             ]
         )
 
+    def z_dla_range(self, wavelengths: np.ndarray, z_qso: float):
+        """(`min_z_dla`, `max_z_dla`) with the in-range test made once: the same expressions, the same values"""
+        ind = self._in_model_range(wavelengths, z_qso)
+        inside = wavelengths[ind]
+        z_min = np.max(
+            [
+                np.min(inside) / self.lya_wavelength - 1,
+                self.observed_wavelengths(self.lyman_limit, z_qso) / self.lya_wavelength - 1 + self.min_z_cut,
+            ]
+        )
+        z_max = np.min([(np.max(inside) / self.lya_wavelength - 1) - self.max_z_cut, z_qso - self.max_z_cut])
+        return z_min, z_max
+
     def __repr__(self) -> str:
         return str(self.__dict__)

@@ -638,6 +638,9 @@ def test_model_evidences_in_one_call_equal_the_three_calls(restore_options):
             t.join()
         assert not errors, errors
     set_option("shared_work_stream", 1)
+    # every host-pointer call returns with its own work complete: the kernel stream has nothing queued now
+    # (the read-back tools/measure_catalogue.py polls to see how often a catalogue run leaves the device without work)
+    assert get_option("work_stream_idle") == 1
     for h in halves:
         h.close()
 

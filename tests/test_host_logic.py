@@ -505,6 +505,103 @@ def test_batched_sample_redshifts_are_the_holders_own():
     np.testing.assert_array_equal(distinct.tables[0][0][0], row)
 
 
+def test_prepare_data_shortcuts_are_numpys_arithmetic():
+    """
+    `prepare_data` forms the normalisation median and the padding of the wavelength grid without NumPy's generic front
+    ends (one thread prepares every spectrum of a catalogue): bit for bit np.nanmedian / np.logspace, NaNs, ties, even and
+    odd counts, empty windows; `Parameters.z_dla_range` is (min_z_dla, max_z_dla).
+    """
+    import warnings
+
+    from gpy_dla_detection_amd.null_gp import _logspace, _nanmedian_1d
+
+    rng = np.random.default_rng(11)
+    for trial in range(4000):
+        n = int(rng.integers(0, 40))
+        a = rng.standard_normal(n) * 10.0 ** int(rng.integers(-3, 3))
+        if n and trial % 3 == 0:
+            a[rng.random(n) < 0.3] = np.nan
+        if n and trial % 5 == 0:
+            a[rng.integers(0, n)] = a[rng.integers(0, n)]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want, got = np.nanmedian(a), _nanmedian_1d(a)
+        assert np.array_equal(np.float64(want), np.float64(got), equal_nan=True), (a, want, got)
+    for trial in range(4000):
+        lo, spacing, num = rng.uniform(3, 4), 10 ** rng.uniform(-5, -3), int(rng.integers(1, 6))
+        for a, b in ((lo - num * spacing, lo - spacing), (lo + spacing, lo + num * spacing), (lo, lo)):
+            np.testing.assert_array_equal(_logspace(a, b, num), np.logspace(a, b, num))
+    params = Parameters(num_dla_samples=16)
+    obs = 10.0 ** (3.56 + 1e-4 * np.arange(4600))
+    for z_qso in (2.2, 2.6, 3.3, 4.5):
+        for w in (obs, obs[::3], obs[rng.random(obs.size) > 0.05]):
+            assert params.z_dla_range(w, z_qso) == (params.min_z_dla(w, z_qso), params.max_z_dla(w, z_qso))
+
+
+def test_batch_bookkeeping_is_the_per_spectrum_loop():
+    """
+    `process_qso` turns a batch's evidences into priors / posteriors / MAP values with array expressions over the batch;
+    the reference does it spectrum by spectrum (run_bayes_select.py:189-230, bayesian_model_selection.py:68-105,
+    dla_gp.py:428-472).  Same values to the last bit, also where a sweep stopped on a NaN evidence.
+    """
+    from gpy_dla_detection_amd.run_bayes_select import _logsumexp, occupation_log_priors, process_qso
+
+    S, max_dlas = 96, 3
+    learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(S)
+    spectra, z_qsos = list(spectra) * 4, [z + 0.01 * i for i, z in enumerate(list(z_qsos) * 4)]
+    rng = np.random.default_rng(3)
+
+    class ZPrior:
+        def less_ind(self, z_qso):
+            return 700.0 + 40.0 * z_qso, 9000.0 + z_qso
+
+    class Engine(RecordingEngine):
+        def __init__(self):
+            super().__init__()
+            self.outputs = []
+
+        def model_evidences(self, batch, z_lls, nhi_sub, z_dla, nhi_dla, max_dlas, min_z_separation, seed):
+            nb, S = z_dla.shape
+            nulls = -500.0 + 30.0 * rng.standard_normal(nb)
+            ev_sub = -480.0 + 30.0 * rng.standard_normal((nb, 1))
+            ev_dla = -470.0 + 30.0 * rng.standard_normal((nb, max_dlas))
+            ll = -470.0 + 30.0 * rng.standard_normal((nb, S, max_dlas))
+            ll[rng.random(ll.shape) < 0.05] = np.nan
+            if nb > 1:
+                ev_dla[1, 2:] = np.nan  # a sweep that stopped after its second level
+            base = rng.integers(0, S, size=(nb, max_dlas - 1, S)).astype(np.int32)
+            self.tables.append((z_lls, z_dla))
+            self.outputs.append((nulls, ev_sub, ev_dla, ll, base))
+            return nulls, (ev_sub, ll[:, :, :1].copy(), None), (ev_dla, ll, base)
+
+    engine = Engine()
+    res = process_qso(spectra, z_qsos, params, ZPrior(), dla_samples, sub_samples, learned, max_dlas=max_dlas, batch_size=5,
+                      engine=engine, prefetch=False)
+    i = 0
+    for (z_lls, z_dla), (nulls, ev_sub, ev_dla, ll, base) in zip(engine.tables, engine.outputs):
+        for b in range(z_dla.shape[0]):
+            log_priors = occupation_log_priors(ZPrior(), z_qsos[i], max_dlas, dla_samples, sub_samples)
+            log_likelihoods = np.concatenate([[nulls[b]], ev_sub[b], ev_dla[b]])
+            log_posteriors = log_likelihoods + log_priors
+            np.testing.assert_array_equal(res["log_priors_dla"][i], log_priors[-max_dlas:])
+            np.testing.assert_array_equal(res["log_posteriors_dla"][i], log_posteriors[-max_dlas:])
+            assert res["log_posteriors_no_dla"][i] == log_posteriors[0] and res["log_likelihoods_lls"][i] == log_likelihoods[1]
+            with np.errstate(invalid="ignore"):
+                posteriors = np.exp(log_posteriors - _logsumexp(log_posteriors))
+            np.testing.assert_array_equal(res["model_posteriors"][i], posteriors)
+            p_dla = np.sum(posteriors[-max_dlas:])
+            assert np.array_equal(res["p_dlas"][i], p_dla, equal_nan=True)
+            assert np.array_equal(res["p_no_dlas"][i], 1 - p_dla, equal_nan=True)
+            for level in range(max_dlas):
+                top = np.nanargmax(ll[b, :, level])
+                members = [top] + [base[b, j, top] for j in range(level)]
+                np.testing.assert_array_equal(res["MAP_z_dlas"][i, level, : level + 1], z_dla[b][members])
+                np.testing.assert_array_equal(res["MAP_log_nhis"][i, level, : level + 1], dla_samples.log_nhi_samples[members])
+                assert np.isnan(res["MAP_z_dlas"][i, level, level + 1:]).all()
+            i += 1
+    assert i == len(spectra)
+
+
 def test_pipeline_starts_on_short_batches():
     """
     the pipelined driver begins with a quarter and a half batch (the device waits for the first batch's preparation);
