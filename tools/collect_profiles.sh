@@ -19,8 +19,8 @@ for c in 3 4 5; do
 done
 python3 tools/measure_configs.py 2>/dev/null | tail -1 > $out/other_configs.json
 # the catalogue driver end to end, with the share of instants at which its kernel stream was found empty
-DLAGP_POLL_IDLE=1 python3 tools/measure_catalogue.py 2048 10000 32 2>/dev/null | tail -1 > $out/catalogue_pipeline.json
-DLAGP_POLL_IDLE=1 python3 tools/measure_catalogue.py 2048 10000 32 dr12q 2>/dev/null | tail -1 > $out/catalogue_pipeline_dr12q.json
+DLAGP_RUNS=3 DLAGP_POLL_IDLE=1 DLAGP_TIME_ACCUMULATE=1 python3 tools/measure_catalogue.py 2048 10000 32 2>/dev/null | tail -1 > $out/catalogue_pipeline.json
+DLAGP_RUNS=3 DLAGP_POLL_IDLE=1 DLAGP_TIME_ACCUMULATE=1 python3 tools/measure_catalogue.py 2048 10000 32 dr12q 2>/dev/null | tail -1 > $out/catalogue_pipeline_dr12q.json
 python3 tools/measure_catalogue.py 8192 10000 32 dr12q 2>/dev/null | tail -1 > $out/catalogue_pipeline_dr12q_8192.json
 # one sightline of DR12Q's median length through bench.py's own step
 python3 bench.py --pixels 685 --no-cpu-baseline --no-other-configs 2>> $out/bench.err | tail -1 > $out/bench_pixels_685.json

@@ -45,9 +45,13 @@ print("| by-sample split at N = 1 | %.4f ms, %.1f M evals/s | `%s_bench.json` |"
 for name, label in (("catalogue_pipeline.json", "z_qso uniform in [2.2, 3.4]"), ("catalogue_pipeline_dr12q.json", "DR12Q-like z_qso")):
     x = load(name)
     idle = x.get("kernel_stream_idle")
-    print("| catalogue driver, 2048 spectra, %s (n median %.0f, mean %.0f) | **%.0f spectra/s**, %.1f M evals/s, whole run %.1f %% of FP64 peak%s | `%s_%s` |"
-          % (label, x["kept_pixels"]["median"], x["kept_pixels"]["mean"], x["spectra_per_s"], x["evals_per_s"] / 1e6,
-             100 * x["whole_run_frac_of_fp64_peak"],
+    runs = x.get("spectra_per_s_runs")
+    rate = x.get("spectra_per_s_median", x["spectra_per_s"])
+    print("| catalogue driver, 2048 spectra, %s (n median %.0f, mean %.0f) | **%.0f spectra/s**%s, %.1f M evals/s, whole run %.1f %% of FP64 peak%s%s | `%s_%s` |"
+          % (label, x["kept_pixels"]["median"], x["kept_pixels"]["mean"], rate,
+             " (median of %s)" % " / ".join("%.0f" % r for r in runs) if runs else "",
+             rate * (1 + 5 * x["S"]) / 1e6, 100 * x["whole_run_frac_of_fp64_peak"] * rate / x["spectra_per_s"],
+             "; last run: accumulate kernels %.1f %% of the wall time at %.1f %% of peak" % (100 * x["accumulate_share_of_run"], 100 * x["accumulate_frac_of_fp64_peak"]) if "accumulate_share_of_run" in x else "",
              ", kernel stream found empty at %.1f %% of %d polls" % (100 * idle["share"], idle["polls"]) if idle else "", tag, name))
 try:
     x = load("catalogue_pipeline_dr12q_8192.json")

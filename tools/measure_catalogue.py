@@ -142,6 +142,12 @@ def main():
     process_qso(spectra[:warm], z_qsos[:warm], params, FixedPrior(), dla, sub, learned, batch_size=batch_size)
     from gpy_dla_detection_amd.sightline import get_option
 
+    # DLAGP_RUNS=n: n - 1 plain timed runs in front of the (instrumented) last one; single runs scatter by +-4 %
+    earlier_runs = []
+    for _ in range(int(os.environ.get("DLAGP_RUNS", "1")) - 1):
+        t0 = time.perf_counter()
+        process_qso(spectra, z_qsos, params, FixedPrior(), dla, sub, learned, batch_size=batch_size)
+        earlier_runs.append(num / (time.perf_counter() - t0))
     allocs_before = (get_option("big_allocs"), get_option("big_frees"))
     free_before = torch.cuda.mem_get_info()[0]
     polls = [0, 0]
@@ -205,6 +211,9 @@ def main():
         "hbm_growth_during_run_gb": round((free_before - free_after) / 2 ** 30, 3),
         "workspace_allocs_frees_during_run": [get_option("big_allocs") - allocs_before[0], get_option("big_frees") - allocs_before[1]],
     }
+    if earlier_runs:
+        out["spectra_per_s_runs"] = earlier_runs + [num / t]
+        out["spectra_per_s_median"] = float(np.median(out["spectra_per_s_runs"]))
     if accumulate:
         # the accumulate kernels' own time inside the pipeline: against `seconds` it says how much of the run they fill,
         # against the same sweeps run alone (sweeps-only) how much the work beside them slows them down
