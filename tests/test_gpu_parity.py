@@ -1482,6 +1482,61 @@ def test_process_qso_on_device_matches_reference_driver_golden():
     assert_catalogue_matches_golden(results, g, rtol=RTOL_LL)
 
 
+def test_pipelined_driver_equals_the_in_order_driver_on_the_device():
+    """
+    42 spectra in batches of 8: the pipelined driver (five threads, short first batches, one table of sample redshifts
+    shared by both models, the batch's bookkeeping as array expressions) against the same catalogue swept in order on
+    the calling thread, and -- for a few spectra -- against the drop-in classes called one spectrum at a time the way the
+    reference's driver does (run_bayes_select.py:141-230).  Different batch compositions, different launch shapes: the
+    log-likelihoods agree to rounding, everything discrete exactly.
+    """
+    from gpy_dla_detection_amd.bayesian_model_selection import BayesModelSelect
+    from gpy_dla_detection_amd.dla_gp import DLAGP
+    from gpy_dla_detection_amd.null_gp import NullGP
+    from gpy_dla_detection_amd.run_bayes_select import process_qso
+    from gpy_dla_detection_amd.subdla_gp import SubDLAGP
+    from tests.test_host_logic import FixedPrior, catalogue_inputs
+
+    S, max_dlas = 512, 3
+    learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(S)
+    rng = np.random.default_rng(17)
+    many, many_z = [], []
+    for i in range(42):  # the three golden spectra with fresh noise and slightly different redshifts
+        w, f, v, m = spectra[i % 3]
+        many.append((w, f + 0.02 * rng.standard_normal(f.shape), v, m))
+        many_z.append(z_qsos[i % 3] + 0.002 * (i // 3))
+    piped = process_qso(many, many_z, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=max_dlas, batch_size=8)
+    in_order = process_qso(many, many_z, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=max_dlas,
+                           batch_size=8, prefetch=False)
+    exact = ("base_sample_inds", "min_z_dlas", "max_z_dlas", "log_priors_no_dla", "log_priors_lls", "log_priors_dla", "z_qsos")
+    for name in piped:
+        if name in exact:
+            np.testing.assert_array_equal(piped[name], in_order[name], err_msg=name)
+        elif piped[name].dtype.kind == "f" and piped[name].ndim:
+            assert np.array_equal(np.isnan(piped[name]), np.isnan(in_order[name])), name
+            np.testing.assert_allclose(piped[name], in_order[name], rtol=1e-9, atol=1e-280, equal_nan=True, err_msg=name)
+    assert np.array_equal(np.argmax(piped["model_posteriors"], axis=1), np.argmax(in_order["model_posteriors"], axis=1))
+
+    bayes = BayesModelSelect([0, 1, max_dlas], 2)
+    model = tuple(learned)[:7]
+    for q in (0, 13, 41):
+        np.random.seed(0)
+        w, f, v, m = many[q]
+        rest = params.emitted_wavelengths(w, many_z[q])
+        gps = [NullGP(params, FixedPrior(), *model),
+               SubDLAGP(params, FixedPrior(), sub_samples, *model, min_z_separation=3000.0, broadening=True),
+               DLAGP(params, FixedPrior(), dla_samples, *model, min_z_separation=3000.0, broadening=True)]
+        for gp in gps:
+            gp.set_data(rest, f, v, m, many_z[q], build_model=True)
+        bayes.model_selection(gps, many_z[q])
+        np.testing.assert_allclose(piped["log_posteriors_dla"][q], bayes.log_posteriors[-max_dlas:], rtol=1e-9)
+        np.testing.assert_allclose(piped["log_posteriors_no_dla"][q], bayes.log_posteriors[0], rtol=1e-9)
+        np.testing.assert_allclose(piped["log_posteriors_lls"][q], bayes.log_posteriors[1], rtol=1e-9)
+        np.testing.assert_array_equal(piped["base_sample_inds"][q], gps[2].base_sample_inds.T)
+        np.testing.assert_allclose(piped["sample_log_likelihoods_dla"][q], gps[2].sample_log_likelihoods, rtol=1e-9, equal_nan=True)
+        np.testing.assert_allclose(piped["model_posteriors"][q], bayes.model_posteriors, rtol=1e-6, atol=1e-280)
+
+
 # ------------------------------------------------------------------------------------------------
 # INTEGRATION route A: the reference driver's loop body (run_bayes_select.py:141-230) with the imports swapped
 # ------------------------------------------------------------------------------------------------
