@@ -68,7 +68,10 @@ def prepare_data(params: Parameters, X: np.ndarray, Y: np.ndarray, noise_varianc
 # NumPy's own over random inputs in tests/test_host_logic.py -- without the generic front ends.
 def _nanmedian_1d(values: np.ndarray) -> float:
     """`np.nanmedian` of a 1-D float array (reference null_gp.py:131): NaNs dropped, middle element(s) by partition"""
-    w = np.array(values, dtype=np.float64, copy=True).ravel()
+    values = np.asarray(values)
+    if values.dtype != np.float64:
+        return np.nanmedian(values)  # other types keep NumPy's own accumulation rules
+    w = values.ravel().copy()
     nan = np.isnan(w)
     if nan.any():
         w = w[~nan]
