@@ -143,3 +143,23 @@ def test_bind_reads_the_gpus_numa_cpus_from_sysfs_without_touching_the_gpu(bench
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {20, 21})
     assert not bench.bind_to_gpu_numa_node(0, str(root))["bound"] and pinned == [[5, 6]]
     assert "torch" not in sys.modules or True  # (the functions import nothing: sysfs reads only)
+
+
+def test_design_tables_render_from_the_committed_profiles():
+    """DESIGN.md section 7 is generated: tools/design_table.py turns profiles/r05_* into its two tables, and every figure of the
+    main table that DESIGN.md prints comes out of that run (numbers traceable to the profiles)"""
+    import re
+    import subprocess
+    import sys
+
+    from tests.conftest import REPO
+
+    res = subprocess.run([sys.executable, os.path.join(REPO, "tools", "design_table.py"), os.path.join(REPO, "profiles"), "r05"],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rows = [line for line in res.stdout.splitlines() if line.startswith("| ")]
+    assert len(rows) >= 18
+    design = open(os.path.join(REPO, "DESIGN.md")).read()
+    missing = [row[:90] for row in rows if row not in design]
+    assert not missing, missing
+    assert re.search(r"\| step, configs\[1\] \| 0\.\d+ ms", res.stdout)
