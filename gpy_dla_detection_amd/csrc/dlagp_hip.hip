@@ -759,6 +759,13 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
         tg.armed = true;
     }
     const hipEvent_t ev_start = timing ? tg.ev.start : nullptr, ev_stop = timing ? tg.ev.stop : nullptr;
+    // With several host threads launching onto ONE stream (shared_work_stream) the runtime enqueues the start marker and the
+    // kernel as two commands: another thread's kernel that slips in between is counted into this launch's interval
+    // (three threads: the sum of the intervals came out 14 % above the wall time's share, profiles/r05_experiments.txt
+    // item 23).  While timing is on, launches therefore enqueue one at a time.
+    static std::mutex timing_order;
+    std::unique_lock<std::mutex> one_at_a_time(timing_order, std::defer_lock);
+    if (timing) one_at_a_time.lock();
 
     int *status = status_shared ? status_shared : ws.status.as<int>();
     g_last_launch_path = use_mfma ? 2 : 1;

@@ -81,9 +81,45 @@ def main():
                 "launches_per_step": launches / len(order), "accumulate_frac": flop / (ms * 1e-3) / 1e12 / PEAK,
                 "step_frac": flop / wall / 1e12 / PEAK}
 
+    def run_threads(nthreads):
+        """the rotation's steps issued by `nthreads` host threads onto the ONE stream, each thread its own batches"""
+        import threading
+
+        for s in sets:
+            step(s)
+        torch.cuda.synchronize()
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < 0.2:
+            step(sets[0])
+            torch.cuda.synchronize()
+        sl.set_option("timing", 1)
+        sl.timing_read(reset=True)
+
+        def worker(t):
+            torch.cuda.set_device(0)
+            for _ in range(rounds):
+                for s in sets[t::nthreads]:
+                    step(s)
+
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        sl.set_option("timing", 0)
+        ms, launches = sl.timing_read(reset=True)
+        flop = rounds * sum(s["flop"] for s in sets)
+        return {"threads": nthreads, "accumulate_frac": flop / (ms * 1e-3) / 1e12 / PEAK, "step_frac": flop / wall / 1e12 / PEAK,
+                "launches": launches}
+
     out = {"batches": K, "rounds": rounds, "mix": mix,
            "each_batch_again_and_again": [run([s] * rounds) for s in sets],
            "batches_in_rotation": run(sets * rounds)}
+    if K >= 3:
+        out["rotation_issued_by_three_threads"] = run_threads(3)
     out["mean_frac_again_and_again"] = float(np.mean([r["accumulate_frac"] for r in out["each_batch_again_and_again"]]))
     print(json.dumps(out))
     for s in sets:
