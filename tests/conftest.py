@@ -15,6 +15,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+PARITY_REPORT = []  # lines the full-population comparisons leave for the end of the run (they are what a reviewer reads)
+
+
+def report_parity(label: str, worst: float, count: int, note: str = "") -> None:
+    PARITY_REPORT.append("parity %-58s worst relative difference to the oracle %.3e over %d evaluations%s"
+                         % (label, worst, count, (" " + note) if note else ""))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if PARITY_REPORT:
+        terminalreporter.write_sep("-", "HIP path against the oracle, whole populations")
+        for line in PARITY_REPORT:
+            terminalreporter.write_line(line)
+
+
 def free_port() -> int:
     """a TCP port nobody listens on right now (two test runs on one host must not share a rendezvous port)"""
     import socket

@@ -12,8 +12,9 @@ import pytest
 
 from gpy_dla_detection_amd.samples import halton
 from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline
-from tests.conftest import load_golden, oracle_state
+from tests.conftest import load_golden, oracle_state, report_parity
 from tests.golden_inputs import MVNPDF_SHAPES, checksum, mvnpdf_inputs
+from tests.oracle_fanout import oracle_log_likelihoods
 
 pytestmark = pytest.mark.gpu
 
@@ -776,13 +777,13 @@ def test_full_size_properties():
     np.testing.assert_allclose(two, swapped, rtol=1e-12)
     ghost = dev.eval(np.stack([z[sub], z[sub][::-1]], 1), np.stack([nhi[sub], np.zeros(512)], 1))
     np.testing.assert_allclose(ghost, ll[sub], rtol=1e-12)
-    # (4) spot-check against the oracle on a strided subset
-    from oracle import ref_like as R
-
-    st = oracle_state(sight)
-    pick = np.arange(0, S, 500)
-    want = np.array([R.sample_log_likelihood_k_dlas(st, [z[i]], [nhi[i]]) for i in pick])
-    np.testing.assert_allclose(ll[pick], want, rtol=RTOL_LL)
+    # (4) the WHOLE population against the oracle: every one of the 10 000 samples (reference dla_gp.py:132-159 ->
+    # :311-329), fanned over the host's cores; the same best sample
+    want = oracle_log_likelihoods([(sight, z, nhi)])[0]
+    worst = float(np.max(np.abs(ll - want) / np.abs(want)))
+    report_parity("configs[1]: 1 sightline x 10 000 samples, n = 3000", worst, S)
+    assert worst <= RTOL_LL, worst
+    assert int(np.argmax(ll)) == int(np.argmax(want))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1037,11 +1038,9 @@ def full_size_sightlines(count):
     return [_FULL[i] for i in range(count)]
 
 
-def oracle_spot(sight, zs, ns):
-    from oracle import ref_like as R
-
-    st = oracle_state(sight)
-    return np.array([R.sample_log_likelihood_k_dlas(st, np.atleast_1d(z), np.atleast_1d(n)) for z, n in zip(zs, ns)])
+def spread(b: int, count: int, S: int) -> np.ndarray:
+    """`count` distinct sample indices spread over [0, S), different for every sightline b"""
+    return (b * 37 + np.arange(count) * (S // count)) % S
 
 
 def test_config3_batch_of_64_sightlines_full_size():
@@ -1053,15 +1052,24 @@ def test_config3_batch_of_64_sightlines_full_size():
     batch = DeviceBatch(devs)
     S = 10000
     z = np.stack([make_qmc_samples(s, S)[0] for s in sights])
-    pick = np.arange(7, S, 1111)
+    per = 128  # oracle-checked samples per sightline and model, plus the device's best sample of the sightline
     for sub in (False, True):
         nhi = np.broadcast_to(make_qmc_samples(sights[0], S, sub_dla=sub)[2], z.shape)
         ll = batch.eval(z, nhi)
         assert ll.shape == (64, S) and np.all(np.isfinite(ll))
         # the batch launch (one piece per block) agrees with a single-sightline launch (pieces + remainder)
         np.testing.assert_allclose(ll[5], devs[5].eval(z[5], nhi[5]), rtol=1e-13)
-        for b in (0, 11, 40, 63):  # spot checks against the oracle
-            np.testing.assert_allclose(ll[b, pick], oracle_spot(sights[b], z[b, pick], nhi[b, pick]), rtol=RTOL_LL)
+        # EVERY sightline against the oracle (reference dla_gp.py:311-329 / subdla_gp.py:224-242)
+        picks = [np.unique(np.append(spread(b, per, S), int(np.argmax(ll[b])))) for b in range(64)]
+        wants = oracle_log_likelihoods([(sights[b], z[b, picks[b]], nhi[b, picks[b]]) for b in range(64)])
+        worst = 0.0
+        for b in range(64):
+            got = ll[b, picks[b]]
+            worst = max(worst, float(np.max(np.abs(got - wants[b]) / np.abs(wants[b]))))
+            assert int(np.argmax(got)) == int(np.argmax(wants[b])), b  # the same best sample among those compared
+        report_parity("configs[2]: 64 sightlines, %s model" % ("sub-DLA" if sub else "DLA(1)"), worst,
+                      sum(len(p) for p in picks))
+        assert worst <= RTOL_LL, worst
     # sightlines with an injected absorber prefer the DLA model at the injected redshift
     nhi = np.broadcast_to(make_qmc_samples(sights[0], S)[2], z.shape)
     ll = batch.eval(z, nhi)
@@ -1084,18 +1092,29 @@ def test_config4_one_gpu_share_128_sightlines_through_shard_runner():
     table = runner.run()
     assert table.shape == (128, 3) and np.all(np.isfinite(table))
     z = runner.z
-    pick = np.arange(3, S, 997)
     log_S = np.log(S)
-    for b in (2, 64, 127):
-        st = oracle_state(sights[b])
-        assert abs(table[b, 0] - R.null_log_model_evidence(st)) <= RTOL_LL * abs(table[b, 0])
-        # the evidence is a log-mean-exp over all S samples: recompute it from oracle-checked likelihoods
-        for col, nhi in ((1, runner.nhi_sub), (2, runner.nhi_dla)):
-            dev_ll = runner.batch.batch.sightlines[b].eval(z[b], nhi)
-            np.testing.assert_allclose(dev_ll[pick], oracle_spot(sights[b], z[b, pick], nhi[pick]), rtol=RTOL_LL)
-            top = dev_ll.max()
-            want = top + np.log(np.mean(np.exp(dev_ll - top))) - log_S  # the Occam term of dla_gp.py:157-159
-            assert abs(table[b, col] - want) <= 1e-11 * abs(want)
+    # the null evidence of every sightline (reference null_gp.py:294-305)
+    nulls = np.array([R.null_log_model_evidence(oracle_state(s)) for s in sights])
+    worst_null = float(np.max(np.abs(table[:, 0] - nulls) / np.abs(nulls)))
+    report_parity("configs[3]: null evidence of 128 sightlines", worst_null, 128)
+    assert worst_null <= RTOL_LL
+    per = 32
+    for col, nhi, name in ((1, runner.nhi_sub, "sub-DLA"), (2, runner.nhi_dla, "DLA(1)")):
+        # the evidence is a log-mean-exp over all S samples (dla_gp.py:180-190): recomputed from the device's
+        # likelihoods, which the oracle checks on every sightline
+        dev_ll = runner.batch.batch.eval(z, np.broadcast_to(nhi, z.shape))
+        top = dev_ll.max(axis=1)
+        want = top + np.log(np.mean(np.exp(dev_ll - top[:, None]), axis=1)) - log_S  # Occam term of dla_gp.py:157-159
+        assert np.all(np.abs(table[:, col] - want) <= 1e-11 * np.abs(want))
+        picks = [np.unique(np.append(spread(b, per, S), int(np.argmax(dev_ll[b])))) for b in range(128)]
+        wants = oracle_log_likelihoods([(sights[b], z[b, picks[b]], nhi[picks[b]]) for b in range(128)])
+        worst = 0.0
+        for b in range(128):
+            got = dev_ll[b, picks[b]]
+            worst = max(worst, float(np.max(np.abs(got - wants[b]) / np.abs(wants[b]))))
+            assert int(np.argmax(got)) == int(np.argmax(wants[b])), b
+        report_parity("configs[3]: 128 sightlines, %s model" % name, worst, sum(len(p) for p in picks))
+        assert worst <= RTOL_LL, worst
     # argmax over [null, DLA(1)] = injected truth (synthetic.py: index % 3 absorbers injected)
     for b in range(128):
         assert (table[b, 2] > table[b, 0]) == (b % 3 != 0), b
@@ -1117,17 +1136,31 @@ def test_config5_one_gpu_share_32_sightlines_four_levels():
     assert get_option("last_sweep_cached") == 1 and get_option("last_launch_path") == 2
     assert ev.shape == (32, 4) and ll.shape == (32, S, 4) and base.shape == (32, 3, S)
     assert np.all(np.isfinite(ev))
-    # (1) oracle spot checks on every level: the parameter sets of a few samples, rebuilt through the base indices
-    pick = np.arange(11, S, 1999)
-    for b in (0, 13, 31):
+    # (1) the oracle on every level, 1000 samples per level and sightline (plus the level's best sample): the parameter
+    # sets of level l stack the QMC point on the absorbers the DEVICE drew for it (base indices, dla_gp.py:135-150)
+    members = (0, 7, 13, 22, 31)
+    jobs, where = [], []
+    for b in members:
         for level in range(max_dlas):
+            col = np.where(np.isnan(ll[b, :, level]), -np.inf, ll[b, :, level])
+            pick = np.unique(np.append(spread(b + level, 1000, S), int(np.argmax(col))))
             idx = np.concatenate([pick[None, :], base[b, :level][:, pick]], axis=0)  # (level + 1, len(pick))
-            want = oracle_spot(sights[b], z[b][idx].T, nhi[idx].T) - np.log(S)
-            got = ll[b, pick, level]
-            ok = ~np.isnan(got)  # NaN = two absorbers closer than min_z_separation (dla_gp.py:164-177)
-            zs = np.sort(z[b][idx], axis=0)
-            assert np.array_equal(~ok, np.any(np.diff(zs, axis=0) < min_sep, axis=0))
-            np.testing.assert_allclose(got[ok], want[ok], rtol=RTOL_LL)
+            jobs.append((sights[b], z[b][idx].T, nhi[idx].T))
+            where.append((b, level, pick, idx))
+    wants = oracle_log_likelihoods(jobs)
+    worst = np.zeros(max_dlas)
+    for (b, level, pick, idx), want in zip(where, wants):
+        want = want - np.log(S)
+        got = ll[b, pick, level]
+        ok = ~np.isnan(got)  # NaN = two absorbers closer than min_z_separation (dla_gp.py:164-177)
+        zs = np.sort(z[b][idx], axis=0)
+        assert np.array_equal(~ok, np.any(np.diff(zs, axis=0) < min_sep, axis=0))
+        worst[level] = max(worst[level], float(np.max(np.abs(got[ok] - want[ok]) / np.abs(want[ok]))))
+        assert int(np.argmax(np.where(ok, got, -np.inf))) == int(np.argmax(np.where(ok, want, -np.inf))), (b, level)
+    for level in range(max_dlas):
+        report_parity("configs[4]: %d sightlines, level %d (%d absorbers per sample)" % (len(members), level + 1, level + 1),
+                      worst[level], sum(len(w[2]) for w in where if w[1] == level))
+    assert worst.max() <= RTOL_LL, worst
     # (2) device levels == host levels (NumPy half of every level, reference RNG) on two sightlines
     two = DeviceBatch([devs[4], devs[22]])
     want_ev, want_ll, want_base = parallel.sweep_batch(two.eval, z[[4, 22]], nhi, max_dlas, min_sep, seed=0)

@@ -166,3 +166,23 @@ def test_oracle_reproduces_reference_on_gapped_masks():
         got2 = np.array([R.sample_log_likelihood_k_dlas(st, z, n) for z, n in zip(g["z2_%d" % c], g["n2_%d" % c])])
         np.testing.assert_allclose(got2, g["out2_%d" % c], rtol=1e-12)
         assert abs(R.null_log_model_evidence(st) - g["null_%d" % c]) <= 1e-12 * abs(g["null_%d" % c])
+
+
+def test_oracle_fan_out_equals_the_oracle_in_process():
+    """tests/oracle_fanout.py (the GPU tests' whole-population checker): same values as the oracle called here"""
+    from gpy_dla_detection_amd.synthetic import make_qmc_samples, make_sightline
+    from tests.oracle_fanout import oracle_log_likelihoods
+
+    jobs = []
+    for index, kd in ((2, 1), (5, 3)):
+        sight = make_sightline(index, n_unmasked=300, n_masked=9, k=20)
+        z, _, nhi = make_qmc_samples(sight, 23)
+        zs = np.stack([np.roll(z, j) for j in range(kd)], axis=1)
+        ns = np.stack([np.roll(nhi, j) for j in range(kd)], axis=1)
+        jobs.append((sight, zs if kd > 1 else z, ns if kd > 1 else nhi))
+    got = oracle_log_likelihoods(jobs, workers=3)
+    for (sight, zs, ns), values in zip(jobs, got):
+        st = oracle_state(sight)
+        zs, ns = np.asarray(zs).reshape(23, -1), np.asarray(ns).reshape(23, -1)
+        want = np.array([R.sample_log_likelihood_k_dlas(st, zs[i], ns[i]) for i in range(23)])
+        np.testing.assert_allclose(values, want, rtol=1e-13)  # (the workers run one BLAS thread each)
