@@ -15,6 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DLAGP_LIB lets a tuning session load an alternative build of the same ABI (A/B runs on one device)
 LIB_PATH = os.environ.get("DLAGP_LIB") or os.path.join(_HERE, "csrc", "libdlagp_hip.so")
 
+ABI_VERSION = 3            # dlagp_abi_version() this binding is written for
+LEVEL_EXCHANGE = 2064      # DLAGP_LEVEL_EXCHANGE of include/dlagp.h: scratch doubles per sightline of dlagp_level_finish_device
+
 # error codes of include/dlagp.h
 DLAGP_OK, DLAGP_EINVAL, DLAGP_EDEVICE, DLAGP_ELINALG, DLAGP_ENOMEM = 0, -1, -2, -3, -4
 
@@ -59,6 +62,7 @@ SIGNATURES = {
     "dlagp_batch_model_evidences_start": (c_int, [c_void_p, c_int64, c_int, _dp, _dp, c_int64, _dp, _dp, c_int64, c_double]),
     "dlagp_batch_model_evidences_finish": (c_int, [c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, POINTER(ctypes.c_int32)]),
     "dlagp_batch_model_evidences_cancel": (c_int, [c_void_p]),
+    "dlagp_batch_resample_ties": (c_int, [c_void_p, POINTER(ctypes.c_int32), c_int64]),
     "dlagp_batch_level_eval_device": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
                                               c_void_p, c_int, c_void_p, c_void_p]),
     "dlagp_sweep_state_init_device": (c_int, [c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -155,6 +159,9 @@ def load():
             fn = getattr(lib, name)
             fn.restype = restype
             fn.argtypes = argtypes
+        if lib.dlagp_abi_version() != ABI_VERSION:
+            raise RuntimeError("{} has ABI version {}, this binding is written for {}: rebuild it "
+                               "(`make -C gpy_dla_detection_amd/csrc`)".format(LIB_PATH, lib.dlagp_abi_version(), ABI_VERSION))
         _lib = lib
     return _lib
 

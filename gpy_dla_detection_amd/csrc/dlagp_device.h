@@ -107,6 +107,37 @@ struct SampleSource {
     long pair_S;         // QMC points per sightline of a pair launch; 0 = an ordinary launch
 };
 
+// What the kernels that end an occupation level need (reference dla_gp.py:155-218; kernels_common.h "level finish").
+// One struct, passed by value, for the one-workgroup kernel and for the three kernels of the spread form.
+//   weights  [nb][S]  exp(value - max) of the level, 0 for a NaN sample
+//   exch     [nb][DLAGP_LEVEL_EXCH]  what the two phases hand each other: the 1024 virtual lanes' maxima and weight sums,
+//            the 16 waves' counts of finite samples
+//   ties     [nb][max_dlas - 1]  searches of the resampling that ended within DLAGP_TIE_MARGIN of a cdf step (NULL: not
+//            counted): the host settles those levels with NumPy's own arithmetic (include/dlagp.h, dlagp_batch_resample_ties)
+#define DLAGP_LEVEL_LANES 1024      // virtual lanes: lane t owns samples [t chunk, (t + 1) chunk), chunk = ceil(S / 1024)
+#define DLAGP_LEVEL_EXCH (2 * DLAGP_LEVEL_LANES + 16)  // the lanes' maxima and sums, the 16 waves' counts of finite samples
+#define DLAGP_TIE_MARGIN 1e-11      // on the cdf's scale [0, 1]: far above any rounding difference between this library's cdf
+                                    // and NumPy's sequential cumsum (<= ~S eps = 1e-12 at S = 10 000), far below the spacing of
+                                    // 53-bit uniforms' chance encounters (2 S margin = 2e-7 of the searches are settled on the host)
+struct LevelArgs {
+    const double *ll;        // [nb][S] raw log-likelihoods of the level
+    long S;
+    int level, max_dlas;
+    SampleSource src;        // redshifts of a sample's absorbers (separation mask)
+    double min_z_separation;
+    double log_s;            // log(S), from the host
+    const double *uniforms;  // [nb][max_dlas - 1][S]
+    double *sample_ll;       // [nb][max_dlas][S]
+    double *evidences;       // [nb][max_dlas]
+    int *base;               // [nb][max_dlas - 1][S]
+    double *weights;
+    double *exch;
+    int *alive;              // [nb]
+    const int *status;       // the launch's non-PD flag ...
+    int *sticky_status;      // ... accumulated over the sweep's levels
+    int *ties;
+};
+
 #if defined(__HIPCC__)
 __device__ __forceinline__ long sample_point(const SampleSource &src, long b, long s, int j, long S, int kd) {
     if (src.pair_S) {  // pair launch: the point behind virtual sample s (rows beyond the last point repeat it; never stored)

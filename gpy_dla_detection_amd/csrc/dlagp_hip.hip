@@ -325,6 +325,8 @@ struct Workspace {
     // device-resident occupation sweep: raw level log-likelihoods, cdf scratch, per-sightline alive flag,
     // and staging of its host-pointer variant
     DeviceBuffer level_ll, cdf, alive, uniforms, evidences, sample_ll, base;
+    DeviceBuffer level_x;  // what the phases of the level finish hand each other, [nb][DLAGP_LEVEL_EXCH] (kernels_common.h)
+    DeviceBuffer ties;     // [nb][max_dlas - 1] searches of the resampling that ended within DLAGP_TIE_MARGIN of a cdf step
     DeviceBuffer cache;  // profile cache of the multi-level sweep, [nb][S][max n_slots]
     DeviceBuffer sub_z, sub_nhi, sub_evidences, sub_ll;  // the one-absorber model of dlagp_batch_model_evidences
     DeviceBuffer sub_level_ll, sub_alive;  // pair launches: the one-absorber model's raw level and its per-sightline flags
@@ -334,6 +336,8 @@ struct Workspace {
         cache.release();
         level_ll.release();
         cdf.release();
+        level_x.release();
+        ties.release();
         alive.release();
         uniforms.release();
         evidences.release();
@@ -488,6 +492,12 @@ struct dlagp_ctx {
 
 struct dlagp_batch {
     LaunchGroup group;
+    // near-tie counts of the most recent sweep (dlagp_batch_resample_ties): with the results of a host-pointer sweep they are
+    // already here; after a *_device sweep they still sit in the workspace, behind the sweep's kernels on `ties_stream`
+    std::vector<int32_t> ties;
+    int ties_levels = -1;  // max_dlas - 1 of that sweep; -1: no sweep yet
+    bool ties_on_device = false;
+    hipStream_t ties_stream = nullptr;
     // dlagp_batch_model_evidences_start has run and _finish has not
     struct Pending {
         bool active = false;
@@ -1104,23 +1114,40 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
     return DLAGP_OK;
 }
 
-// level_finish with its cdf in LDS whenever 8 S bytes fit beside the kernel's static 8.3 KB (S <= 18 000)
-static int launch_level_finish(int nb, hipStream_t stream, const double *ll, long S, int level, int max_dlas,
-                               const SampleSource &src, double min_z_separation, const double *uniforms, double *sample_ll,
-                               double *evidences, int *base, double *cdf, int *alive, const int *status, int *sticky) {
+// The kernels that end an occupation level (kernels_common.h "level finish").  Spread form -- two launches that put one
+// sightline's level on ~30 compute units -- whenever the cumulative weights fit a workgroup's LDS (8 S bytes beside 150
+// static ones: S <= 18 000); the one-workgroup kernel otherwise, and when option "level_spread" is 0.  Same arithmetic, same
+// bits either way.
+static Option g_opt_level_spread = 1;
+static Option g_opt_level_search_groups = 16;  // workgroups per sightline that share the searches of the spread form
+static Option g_last_level_spread = 0;
+static int launch_level_finish(int nb, hipStream_t stream, LevelArgs a) {
+    const long S = a.S;
     const size_t lds_bytes = (size_t)S * sizeof(double);
-    if (lds_bytes <= 144 * 1024) {
-        // beyond the default limit (64 KB with the kernel's static 8.3 KB) the attribute is needed -- per device, so it is
-        // set at every such launch rather than remembered (a process may drive several devices)
-        if (lds_bytes > 55 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(level_finish<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        hipLaunchKernelGGL(level_finish<true>, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS), (uint32_t)lds_bytes, stream,
-                           ll, S, level, max_dlas, src, min_z_separation, uniforms, sample_ll, evidences, base, cdf, alive,
-                           status, sticky);
+    const int lds_limit = 144000;  // beside the kernels' 16.7 KB of static LDS: S <= 18 000
+    const bool in_lds = lds_bytes <= (size_t)lds_limit;
+    const bool resamples = a.level + 1 < a.max_dlas;
+    const bool spread = g_opt_level_spread != 0 && in_lds;
+    g_last_level_spread = spread ? 1 : 0;
+    // beyond the default limit (64 KB in all) the attribute is needed -- per device, so it is set at every such launch
+    // rather than remembered (a process may drive several devices)
+    const bool big_lds = resamples && lds_bytes > 46 * 1024;
+    if (spread) {
+        hipLaunchKernelGGL(level_weights, dim3(DLAGP_LEVEL_LANES / 64, (unsigned)nb), dim3(64), 0, stream, a);
+        if (big_lds)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(level_resample),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit));
+        const int groups = resamples ? (int)std::max<int64_t>(1, std::min<int64_t>(g_opt_level_search_groups, 64)) : 1;
+        hipLaunchKernelGGL(level_resample, dim3((unsigned)groups, (unsigned)nb), dim3(DLAGP_LEVEL_SEARCH_THREADS),
+                           resamples ? (uint32_t)lds_bytes : 0u, stream, a);
+    } else if (in_lds) {
+        if (big_lds)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(level_finish_fused<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit));
+        hipLaunchKernelGGL(level_finish_fused<true>, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS),
+                           resamples ? (uint32_t)lds_bytes : 0u, stream, a);
     } else {
-        hipLaunchKernelGGL(level_finish<false>, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS), 0, stream, ll, S, level,
-                           max_dlas, src, min_z_separation, uniforms, sample_ll, evidences, base, cdf, alive, status, sticky);
+        hipLaunchKernelGGL(level_finish_fused<false>, dim3((unsigned)nb), dim3(DLAGP_LEVEL_THREADS), 0, stream, a);
     }
     HIP_TRY(hipGetLastError());
     return DLAGP_OK;
@@ -1153,6 +1180,8 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     if ((rc = grow(g, ws.level_ll, rows * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.cdf, rows * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.alive, (size_t)(nb + 1) * sizeof(int)))) return rc;  // [nb] = sticky non-PD flag
+    if ((rc = grow(g, ws.level_x, (size_t)nb * DLAGP_LEVEL_EXCH * sizeof(double)))) return rc;
+    if ((rc = grow(g, ws.ties, (size_t)nb * std::max(max_dlas - 1, 1) * sizeof(int)))) return rc;
     if (pair && (rc = grow(g, ws.sub_level_ll, rows * sizeof(double)))) return rc;
     if (pair && (rc = grow(g, ws.sub_alive, (size_t)(nb + 1) * sizeof(int)))) return rc;
     const long n_ll = (long)rows * max_dlas, n_base = (long)rows * (max_dlas - 1);
@@ -1223,6 +1252,7 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     g_last_sweep_cached = all_cached ? 1 : 0;
     if (cache_decision && phase != SWEEP_FINISH) *cache_decision = all_cached ? 1 : 0;
     g_last_sweep_paired = pair ? 1 : 0;
+    const double log_s = std::log((double)S);
     for (int level = 0; level < max_dlas; ++level) {
         bool first = true;
         const bool launch = !(phase == SWEEP_FINISH && level == 0);  // FINISH: level 1 was launched by START
@@ -1246,16 +1276,16 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
         }
         if (pair && level == 0 && launch) {
             const SampleSource sub0{d_sample_z, pair->d_nhi, nullptr, 1, (long)pair->nhi_stride, 0, nullptr, nullptr, 0, 0, 0, 0, 0};
-            if ((rc = launch_level_finish(nb, stream, ws.sub_level_ll.as<const double>(), (long)S, 0, 1, sub0, min_z_separation,
-                                          nullptr, pair->d_sample_ll, pair->d_evidences, nullptr, ws.cdf.as<double>(),
-                                          ws.sub_alive.as<int>(), ws.status.as<const int>(), ws.alive.as<int>() + nb)))
-                return rc;
+            LevelArgs sub_level{ws.sub_level_ll.as<const double>(), (long)S, 0, 1, sub0, min_z_separation, log_s, nullptr,
+                                pair->d_sample_ll, pair->d_evidences, nullptr, ws.cdf.as<double>(), ws.level_x.as<double>(),
+                                ws.sub_alive.as<int>(), ws.status.as<const int>(), ws.alive.as<int>() + nb, nullptr};
+            if ((rc = launch_level_finish(nb, stream, sub_level))) return rc;
         }
         if (phase == SWEEP_START) return DLAGP_OK;  // level 1's own evidence and resampling wait for the uniforms
-        if ((rc = launch_level_finish(nb, stream, ws.level_ll.as<const double>(), (long)S, level, max_dlas, src0,
-                                      min_z_separation, d_uniforms, d_sample_ll, d_evidences, d_base, ws.cdf.as<double>(),
-                                      ws.alive.as<int>(), ws.status.as<const int>(), ws.alive.as<int>() + nb)))
-            return rc;
+        LevelArgs this_level{ws.level_ll.as<const double>(), (long)S, level, max_dlas, src0, min_z_separation, log_s, d_uniforms,
+                             d_sample_ll, d_evidences, d_base, ws.cdf.as<double>(), ws.level_x.as<double>(), ws.alive.as<int>(),
+                             ws.status.as<const int>(), ws.alive.as<int>() + nb, ws.ties.as<int>()};
+        if ((rc = launch_level_finish(nb, stream, this_level))) return rc;
     }
     return DLAGP_OK;
 }
@@ -1616,7 +1646,7 @@ static int upload_padded(DeviceBuffer &buf, const double *src, int n, int n_pad,
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int dlagp_abi_version(void) { return 2; }  // 2: DLAGP_ENOMEM, exception barrier on every entry point
+int dlagp_abi_version(void) { return 3; }  // 2: DLAGP_ENOMEM, exception barrier; 3: near-tie counts of the resampling
 
 int dlagp_device_count(void) try {
     int count = 0;
@@ -2011,6 +2041,21 @@ int dlagp_batch_null(dlagp_batch *batch, double *out) try {
     return sweep_from_host(batch->group, 1, 0, nullptr, nullptr, out);
 } DLAGP_CATCH_INT("dlagp_batch_null")
 
+// the sweep about to be enqueued leaves its near-tie counts in the workspace (dlagp_batch_resample_ties fetches them)
+static void ties_left_on_device(dlagp_batch *batch, int max_dlas, hipStream_t stream) {
+    batch->ties_levels = max_dlas - 1;
+    batch->ties_on_device = true;
+    batch->ties_stream = stream;
+}
+// ... or brings them back with its results
+static void ties_come_back(dlagp_batch *batch, Transfers &tr, int max_dlas) {
+    const size_t count = batch->group.ctxs.size() * (size_t)(max_dlas - 1);
+    batch->ties.assign(count, 0);
+    batch->ties_levels = max_dlas - 1;
+    batch->ties_on_device = false;
+    if (count) tr.download(batch->ties.data(), batch->group.ws.ties.ptr, count * sizeof(int32_t));
+}
+
 static int check_sweep_args(const dlagp_batch *batch, int64_t S, int max_dlas, const void *sample_z,
                             const void *sample_nhi, int64_t nhi_stride, const void *uniforms, const void *evidences) {
     int alive = batch_alive(batch);
@@ -2035,6 +2080,7 @@ int dlagp_batch_sweep_device(dlagp_batch *batch, int64_t S, int max_dlas, const 
         return fail(DLAGP_EINVAL, "the device variant needs d_sample_ll and d_base_inds (they are its working state)");
     cancel_pending(batch);
     HIP_TRY(hipSetDevice(batch->group.device));
+    ties_left_on_device(batch, max_dlas, static_cast<hipStream_t>(stream));
     return sweep_levels(batch->group, S, max_dlas, d_sample_z, d_sample_nhi, nhi_stride, min_z_separation, d_uniforms,
                         d_evidences, d_sample_ll, d_base_inds, static_cast<hipStream_t>(stream));
 } DLAGP_CATCH_INT("dlagp_batch_sweep_device")
@@ -2054,6 +2100,7 @@ int dlagp_batch_two_model_sweep_device(dlagp_batch *batch, int64_t S, int max_dl
     HIP_TRY(hipSetDevice(g.device));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if ((rc = enter_stream(g, stream))) return rc;
+    ties_left_on_device(batch, max_dlas, stream);
     if (pair_eligible(g, S)) {
         const PairSpec sub{d_sub_nhi, sub_nhi_stride, d_sub_evidences, d_sub_sample_ll};
         return sweep_levels(g, S, max_dlas, d_sample_z, d_sample_nhi, nhi_stride, min_z_separation, d_uniforms, d_evidences,
@@ -2096,7 +2143,9 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
     tr.download(base_inds, ws.base.ptr, n_base * sizeof(int32_t));
     int status = 0;
     if ((rc = grow(g, ws.alive, (nb + 1) * sizeof(int)))) return rc;  // [nb]: the sweep's sticky non-PD flag (sweep_levels)
+    if ((rc = grow(g, ws.ties, nb * std::max(max_dlas - 1, 1) * sizeof(int)))) return rc;
     tr.download(&status, ws.alive.as<int>() + nb, sizeof(int));
+    ties_come_back(batch, tr, max_dlas);
     if ((rc = tr.reserve()) || (rc = tr.run_uploads())) return rc;
     rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), nhi_stride, min_z_separation,
                       ws.uniforms.as<double>(), ws.evidences.as<double>(), ws.sample_ll.as<double>(),
@@ -2141,6 +2190,7 @@ int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dla
     if ((rc = grow(g, ws.sub_ll, rows * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.out, nb * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.alive, (nb + 1) * sizeof(int)))) return rc;  // [nb]: the sweeps' sticky non-PD flag
+    if ((rc = grow(g, ws.ties, nb * std::max(max_dlas - 1, 1) * sizeof(int)))) return rc;
     if ((rc = grow(g, ws.status, sizeof(int)))) return rc;            // the null launch's
     if ((rc = grow(g, ws.sub_level_ll, rows * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.sub_alive, (nb + 1) * sizeof(int)))) return rc;
@@ -2157,7 +2207,7 @@ int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dla
     // the staging buffer is sized for BOTH phases now: growing it in _finish would free memory the copies of this
     // phase may still be reading
     const size_t second_phase = (n_base + 2 * nb + rows + nb * max_dlas + rows * max_dlas) * sizeof(double) +
-                                n_base * sizeof(int32_t) + 2 * sizeof(int) + 16 * 256;
+                                n_base * sizeof(int32_t) + 2 * sizeof(int) + nb * max_dlas * sizeof(int32_t) + 16 * 256;
     if ((rc = tr.reserve(second_phase)) || (rc = tr.run_uploads())) return rc;
     batch->pending.pair = pair;
     batch->pending.sub_nhi_stride = sub_nhi_stride;
@@ -2213,6 +2263,7 @@ int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniform
     int status[2] = {0, 0};
     tr.download(&status[0], ws.alive.as<int>() + nb, sizeof(int));
     tr.download(&status[1], ws.status.ptr, sizeof(int));
+    ties_come_back(batch, tr, max_dlas);
     const size_t capacity = ws.stage.bytes;
     if ((rc = tr.reserve())) return rc;
     if (ws.stage.bytes != capacity) return fail(DLAGP_EDEVICE, "internal: the staging buffer grew between the two phases");
@@ -2261,6 +2312,25 @@ int dlagp_batch_model_evidences(dlagp_batch *batch, int64_t S, int max_dlas, con
                                               sample_ll, base_inds);
 } DLAGP_CATCH_INT("dlagp_batch_model_evidences")
 
+int dlagp_batch_resample_ties(dlagp_batch *batch, int32_t *ties, int64_t capacity) try {
+    int rc = batch_alive(batch);
+    if (rc) return rc;
+    if (batch->ties_levels < 0) return fail(DLAGP_EINVAL, "no occupation sweep has run on this batch");
+    const size_t count = batch->group.ctxs.size() * (size_t)batch->ties_levels;
+    if (count && (!ties || capacity < (int64_t)count))
+        return fail(DLAGP_EINVAL, "ties needs room for %lld counts, has %lld", (long long)count, (long long)capacity);
+    if (!count) return DLAGP_OK;
+    if (batch->ties_on_device) {  // a *_device sweep: its kernels first
+        HIP_TRY(hipSetDevice(batch->group.device));
+        HIP_TRY(hipStreamSynchronize(batch->ties_stream));
+        batch->ties.assign(count, 0);
+        HIP_TRY(hipMemcpy(batch->ties.data(), batch->group.ws.ties.ptr, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+        batch->ties_on_device = false;
+    }
+    std::memcpy(ties, batch->ties.data(), count * sizeof(int32_t));
+    return DLAGP_OK;
+} DLAGP_CATCH_INT("dlagp_batch_resample_ties")
+
 // ---- one sightline's samples split over several GPUs (SURVEY 8e "secondary", reference dla_gp.py:132-159 is
 // independent per sample, :209-218 needs all S): every rank evaluates its slice of a level, the slices are
 // all-gathered by the caller (RCCL), and every rank finishes the level on the full vector with the same uniforms
@@ -2297,7 +2367,7 @@ int dlagp_sweep_state_init_device(int nb, int64_t S, int max_dlas, double *d_sam
                        d_sample_ll, n_ll, nan);
     hipLaunchKernelGGL(fill_f64, dim3(1), dim3(256), 0, stream, d_evidences, (long)nb * max_dlas, nan);
     hipLaunchKernelGGL(fill_i32, dim3(1), dim3(256), 0, stream, d_flags, (long)nb, 1);
-    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, stream, d_flags + nb, 2L, 0);
+    hipLaunchKernelGGL(fill_i32, dim3(1), dim3(64), 0, stream, d_flags + nb, 2L + (long)nb * (max_dlas - 1), 0);
     if (n_base > 0)
         hipLaunchKernelGGL(fill_i32, dim3((unsigned)std::min<long>((n_base + 255) / 256, 2048)), dim3(256), 0, stream,
                            d_base_inds, n_base, 0);
@@ -2317,9 +2387,11 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
     HIP_TRY(hipSetDevice(device));
     // the kernel reads the redshifts of a sample's absorbers through the index table; column densities are not used
     const SampleSource src{d_sample_z, d_sample_z, d_base_inds, 1, 0, max_dlas - 1, nullptr, nullptr, 0, 0, 0, 0, 0};
-    return launch_level_finish(nb, static_cast<hipStream_t>(stream), d_ll, (long)S, level, max_dlas, src,
-                               min_z_separation, d_uniforms, d_sample_ll, d_evidences, d_base_inds, d_cdf_scratch, d_flags,
-                               d_flags + nb + 1, d_flags + nb);
+    static_assert(DLAGP_LEVEL_EXCHANGE == DLAGP_LEVEL_EXCH, "include/dlagp.h and dlagp_device.h disagree on the scratch size");
+    const LevelArgs args{d_ll, (long)S, level, max_dlas, src, min_z_separation, std::log((double)S), d_uniforms, d_sample_ll,
+                         d_evidences, d_base_inds, d_cdf_scratch, d_cdf_scratch + (size_t)nb * S, d_flags, d_flags + nb + 1,
+                         d_flags + nb, max_dlas > 1 ? d_flags + nb + 2 : nullptr};
+    return launch_level_finish(nb, static_cast<hipStream_t>(stream), args);
 } DLAGP_CATCH_INT("dlagp_level_finish_device")
 
 int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, const uint8_t *d_too_close,
@@ -2414,6 +2486,8 @@ int dlagp_set_option(const char *name, int64_t value) try {
     else if (!strcmp(name, "finalize_wave")) g_opt_finalize_wave = value != 0;
     else if (!strcmp(name, "fuse_finalize")) g_opt_fuse_finalize = value != 0;
     else if (!strcmp(name, "pair_models")) g_opt_pair_models = value != 0;
+    else if (!strcmp(name, "level_spread")) g_opt_level_spread = value != 0;
+    else if (!strcmp(name, "level_search_groups")) g_opt_level_search_groups = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;
 } DLAGP_CATCH_INT("dlagp_set_option")
@@ -2461,6 +2535,9 @@ int dlagp_get_option(const char *name, int64_t *value) try {
     else if (!strcmp(name, "last_launch_fused")) *value = g_last_launch_fused;
     else if (!strcmp(name, "pair_models")) *value = g_opt_pair_models;
     else if (!strcmp(name, "last_sweep_paired")) *value = g_last_sweep_paired;
+    else if (!strcmp(name, "level_spread")) *value = g_opt_level_spread;
+    else if (!strcmp(name, "level_search_groups")) *value = g_opt_level_search_groups;
+    else if (!strcmp(name, "last_level_spread")) *value = g_last_level_spread;
     else if (!strcmp(name, "big_allocs")) *value = g_stat_big_allocs;
     else if (!strcmp(name, "big_frees")) *value = g_stat_big_frees;
     else if (!strcmp(name, "last_launch_path")) *value = g_last_launch_path;

@@ -9,9 +9,17 @@ inline LineConstants DLAGP_LINES;
 inline unsigned long long DLAGP_STAMPS[8];
 template <bool ROW16, bool NATIVE>
 void finalize_rank20(const double *, int, long, long, const SightlineDev *, double *, int *, const unsigned char *) {}
-template <bool CDF_IN_LDS>
-void level_finish(const double *, long, int, int, SampleSource, double, const double *, double *, double *, int *, double *, int *,
-                  const int *, int *) {}
+template <bool CUM_IN_LDS>
+void level_finish_fused(LevelArgs) {}
+inline void level_weights(LevelArgs) {}
+inline void level_resample(LevelArgs) {}
+// what a level-finish launch touches (fake::launch marks pointer arguments; this struct travels by value)
+inline void mark_arg(const LevelArgs &a, fake::Stream *s, uint64_t t) {
+    for (const void *p : {(const void *)a.ll, (const void *)a.uniforms, (const void *)a.sample_ll, (const void *)a.evidences,
+                          (const void *)a.base, (const void *)a.weights, (const void *)a.exch, (const void *)a.alive,
+                          (const void *)a.status, (const void *)a.ties})
+        fake::mark(p, s, t);
+}
 inline void accumulate_generic() {}
 inline void absorption_generic() {}
 }  // namespace dlagp

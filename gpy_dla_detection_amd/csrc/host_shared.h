@@ -41,6 +41,7 @@ constexpr int finalize_wave_lds_doubles(int k) { return k * (k + 1) / 2 + k; }  
 #endif
 #define DLAGP_EVIDENCE_THREADS 1024
 #define DLAGP_LEVEL_THREADS 1024
+#define DLAGP_LEVEL_SEARCH_THREADS 256  // spread form of the level finish (kernels_common.h): threads per workgroup of level_resample
 // Set-up kernels run as ONE-WAVE workgroups (round 5).  They are launched beside other batches' sweeps, whose accumulate
 // waves hold every register of a SIMD and 19.5 KB of LDS each and are replaced the moment they end: a workgroup of four waves
 // finds four free slots on ONE CU only when a sweep's launch drains -- interp_model averaged 263 us of wall time in a

@@ -924,84 +924,81 @@ __global__ __launch_bounds__(DLAGP_EVIDENCE_THREADS) void level_evidence(double 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Device-resident occupation sweep: everything the reference does between two levels
-// (dla_gp.py:155-218), one workgroup per sightline, no host round trip.
+// Level finish: everything the reference does between two occupation levels (dla_gp.py:155-218), no host round trip.
 //   1. ll[i] - log S -> sample_ll[b][level][i]; NaN where two absorbers of the sample are closer than
 //      min_z_separation (sorted-difference test on the sample's redshifts, :164-177)
 //   2. evidence = nanmax + log(nanmean(exp(ll - nanmax))) - level log S (:180-190); a NaN evidence ends
 //      the sightline's sweep (:200-206): later levels keep their NaN / zero fill
-//   3. unless this is the last level: resample base indices in proportion to exp(ll - nanmax) (NaN -> 0)
-//      exactly as np.random.choice(S, S, p = W / W.sum()) does -- cdf = cumsum(p) / cumsum(p)[-1],
-//      index = searchsorted(cdf, u, side="right") -- with the uniforms u drawn on the host from the
-//      legacy global RNG, so that the indices are the reference's (:213-218).  The cumulative sum
-//      is a parallel scan: its rounding differs from NumPy's sequential one at the 1e-16 level, far
-//      below the 1e-13 differences of the log-likelihoods themselves.
+//   3. unless this is the last level: resample base indices in proportion to W = exp(ll - nanmax) (NaN -> 0)
+//      as np.random.choice(S, S, p = W / W.sum()) does -- index = searchsorted(cdf, u, side="right") with the
+//      uniforms u drawn on the host from the legacy global RNG, so that the indices are the reference's (:213-218).
+//
+// Arithmetic, the same in both forms below.  1024 virtual lanes; lane t owns the chunk of samples [t c, (t + 1) c),
+// c = ceil(S / 1024).  A lane forms its chunk's values, their maximum m_t, the weights w_i = exp(v_i - m_t) RELATIVE TO ITS
+// OWN maximum and their sum s_t in order -- nothing of this waits for another lane.  Then, with M = max m_t and
+// f_t = exp(m_t - M): the 64 lanes of a wave scan f_t s_t (Hillis-Steele by shuffles), the 16 waves' totals are added in
+// wave order, and the cumulative weight of sample i is its wave's offset + the scan of the lanes before its own + the
+// running sum of f_t w_i inside its chunk.  Sample i is drawn for a uniform u when it is the first with
+// cum[i] > u cum[S - 1]; evidence = M + log(cum[S - 1] / #finite) - level log S.
+// NumPy takes exp(v - M) in one step, normalises and accumulates sequentially: the two cdfs differ by rounding, a few
+// 1e-16 (bounded by ~S eps), and an index could differ where a uniform falls that close to a cdf step.  So every search that
+// ends within DLAGP_TIE_MARGIN (1e-11, four to five orders above any rounding difference) of the step on either side of its
+// answer is COUNTED per (sightline, level) in `ties`, and the host settles a level with a non-zero count with NumPy's own
+// arithmetic (sightline.py `settle_near_ties`): the base indices a caller sees are np.random.choice's by construction,
+// not with high probability.
+//
+// Two forms of the same arithmetic (same device functions, same virtual lanes -- identical bits):
+//   level_finish_fused    one 1024-thread workgroup per sightline, the two phases separated by a workgroup barrier: 30-40 us
+//                         on ONE compute unit whatever the batch size -- a fifth of a one-spectrum model selection's kernel time
+//   level_weights + level_resample   two launches that spread a sightline over many compute units: the lanes' chunks by
+//                         16 one-wave workgroups (all of a lane's reads in flight at once), the searches by `groups`
+//                         workgroups that each rebuild the cumulative array in their LDS (1024 exponentials, S multiply-adds)
+//                         and take a share of the uniforms.
 // ---------------------------------------------------------------------------------------------
+namespace lvl {
+__device__ __forceinline__ double *x_m(const LevelArgs &a, long b) { return a.exch + b * DLAGP_LEVEL_EXCH; }
+__device__ __forceinline__ double *x_s(const LevelArgs &a, long b) { return x_m(a, b) + DLAGP_LEVEL_LANES; }
+__device__ __forceinline__ double *x_cnt(const LevelArgs &a, long b) { return x_s(a, b) + DLAGP_LEVEL_LANES; }
+__device__ __forceinline__ double *column(const LevelArgs &a, long b) { return a.sample_ll + (b * a.max_dlas + a.level) * a.S; }
 
-__device__ __forceinline__ double block_reduce(double x, bool take_max, double *red) {
-    for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_xor(x, off);
-        x = take_max ? fmax(x, o) : x + o;
-    }
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[wave] = x;
-    __syncthreads();
-    double total = red[0];
-    for (int w = 1; w < DLAGP_LEVEL_THREADS / 64; ++w) total = take_max ? fmax(total, red[w]) : total + red[w];
-    return total;
+__device__ __forceinline__ double wave_max(double x) {
+    for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_xor(x, off));
+    return x;
 }
 
-// CDF_IN_LDS: the cdf the resampling searches lives in dynamic LDS (8 S bytes) instead of the global scratch.  Every
-// sample's binary search is ~14 DEPENDENT reads; from L2 they made the resampling the longest part of the kernel (62 us
-// per level for S = 10 000, a third of a one-spectrum model selection's kernel time), from LDS they are a tenth of that.
-// The values, and so the indices, are the same.
-template <bool CDF_IN_LDS>
-__global__ __launch_bounds__(DLAGP_LEVEL_THREADS) void level_finish(
-    const double *__restrict__ ll, long S, int level, int max_dlas, SampleSource src, double min_z_separation,
-    const double *__restrict__ uniforms, double *__restrict__ sample_ll, double *__restrict__ evidences,
-    int *__restrict__ base, double *__restrict__ cdf_scratch, int *__restrict__ alive,
-    const int *__restrict__ status, int *__restrict__ sticky_status) {
-    extern __shared__ double cdf_lds[];
-    __shared__ double red[DLAGP_LEVEL_THREADS / 64];
-    __shared__ double scan[DLAGP_LEVEL_THREADS];
-    const int tid = threadIdx.x;
-    const long b = blockIdx.x;
-    if (b == 0 && tid == 0 && *status) *sticky_status = 1;  // the next level's accumulate clears *status
-    if (!alive[b]) return;  // an earlier level's evidence was NaN: the reference stopped there
-    const double log_s = log((double)S);
-    const double *in = ll + b * S;
-    double *col = sample_ll + (b * max_dlas + level) * S;
-    const int kd = level + 1;
-    // With the cdf in LDS the same array first holds the level's values and then their weights: every later phase reads
-    // LDS instead of walking global memory again (each walk was ~10 dependent trips to L2 per thread: four of them made
-    // up most of the kernel's 46-98 us).  Same values, same summation orders as the global-memory form below.
-    double *work = CDF_IN_LDS ? cdf_lds : col;
-
-    // 1. Occam term, separation mask, running maximum.  Four samples per thread at a time, their reads issued together:
-    // a sample's redshifts sit behind the index table (base -> z: two dependent trips), and one sample after the other
-    // a thread paid those trips ten times over.  "Two absorbers closer than the cut" is tested pair by pair: the smallest
-    // gap of the sorted redshifts (reference dla_gp.py:164-177: diff of the sort) IS the smallest pairwise distance, a
-    // NaN redshift compares false either way, and no sorting loop keeps the reads from being hoisted.
-    constexpr int BATCH = 4;
+// Phase A for virtual lane vt (the calling wave = the 64 consecutive lanes vt & ~63 ..).  Values of the lane's chunk --
+// Occam term, separation mask -- into the level's column of sample_ll, BATCH samples at a time with their reads issued
+// together: a sample's redshifts sit behind the index table (base -> z: two dependent trips).  "Two absorbers closer than
+// the cut" is tested pair by pair: the smallest gap of the sorted redshifts (reference dla_gp.py:164-177: diff of the sort)
+// IS the smallest pairwise distance, a NaN redshift compares false either way, and no sorting loop keeps the reads from
+// being hoisted.  Then the weights relative to the chunk's own maximum, their sum, the count of finite samples.
+template <int BATCH>
+__device__ __forceinline__ void lane_weights(const LevelArgs &a, long b, int vt) {
+    const long S = a.S;
+    const int level = a.level, kd = a.level + 1;
+    const double *in = a.ll + b * S;
+    double *col = column(a, b);
+    double *W = a.weights + b * S;
+    const long chunk = (S + DLAGP_LEVEL_LANES - 1) / DLAGP_LEVEL_LANES;
+    const long lo = (long)vt * chunk < S ? (long)vt * chunk : S, hi = lo + chunk < S ? lo + chunk : S;
     double top = -__builtin_inf();
-    for (long i0 = tid; i0 < S; i0 += (long)BATCH * DLAGP_LEVEL_THREADS) {
+    double kept[BATCH];
+    for (long i0 = lo; i0 < hi; i0 += BATCH) {
         double v[BATCH];
         double zs[BATCH][DLAGP_MAX_ABSORBERS_DEV];
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const long i = i0 + (long)u * DLAGP_LEVEL_THREADS;
-            const long ii = i < S ? i : S - 1;
-            v[u] = in[ii] - log_s;
+            const long i = i0 + u;
+            const long ii = i < hi ? i : hi - 1;
+            v[u] = in[ii] - a.log_s;
             if (level > 0)
 #pragma unroll
                 for (int j = 0; j < DLAGP_MAX_ABSORBERS_DEV; ++j)
-                    if (j < kd) zs[u][j] = sample_z(src, b, ii, j, S, kd);
+                    if (j < kd) zs[u][j] = sample_z(a.src, b, ii, j, S, kd);
         }
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const long i = i0 + (long)u * DLAGP_LEVEL_THREADS;
-            if (i >= S) continue;
+            const long i = i0 + u;
             double value = v[u];
             if (level > 0) {
                 bool close = false;
@@ -1009,76 +1006,140 @@ __global__ __launch_bounds__(DLAGP_LEVEL_THREADS) void level_finish(
                 for (int p = 1; p < DLAGP_MAX_ABSORBERS_DEV; ++p)
 #pragma unroll
                     for (int q = 0; q < p; ++q)
-                        if (p < kd) close |= fabs(zs[u][p] - zs[u][q]) < min_z_separation;
+                        if (p < kd) close |= fabs(zs[u][p] - zs[u][q]) < a.min_z_separation;
                 if (close) value = __builtin_nan("");
             }
-            col[i] = value;
-            if (CDF_IN_LDS) work[i] = value;
-            if (value == value) top = fmax(top, value);
+            kept[u] = value;
+            if (i < hi) {
+                col[i] = value;
+                if (value == value) top = fmax(top, value);
+            }
         }
     }
-    top = block_reduce(top, true, red);
-
-    // 2. evidence; the weights exp(v - top) (0 for a NaN sample) replace the values in LDS
+    const bool in_registers = hi - lo <= BATCH;  // the chunk was one batch: its values are still here
     double sum = 0.0, count = 0.0;
-    for (long i = tid; i < S; i += DLAGP_LEVEL_THREADS) {
-        const double v = work[i];
-        double w = 0.0;
-        if (v == v) {
-            w = exp(v - top);
+    for (long i0 = lo; i0 < hi; i0 += BATCH) {
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const long i = i0 + u;
+            if (i >= hi) continue;
+            const double value = in_registers ? kept[u] : col[i];
+            double w = 0.0;
+            if (value == value) {
+                w = exp(value - top);
+                count += 1.0;
+            }
             sum += w;
-            count += 1.0;
+            W[i] = w;
         }
-        if (CDF_IN_LDS) work[i] = w;
     }
-    sum = block_reduce(sum, false, red);
-    count = block_reduce(count, false, red);
-    const double evidence = count > 0.0 ? top + log(sum / count) - level * log_s : __builtin_nan("");
-    if (tid == 0) {
-        evidences[b * max_dlas + level] = evidence;
-        if (!(evidence == evidence)) alive[b] = 0;
-    }
-    if (level + 1 == max_dlas || !(evidence == evidence)) return;
+    for (int off = 32; off > 0; off >>= 1) count += __shfl_xor(count, off);
+    x_m(a, b)[vt] = top;
+    x_s(a, b)[vt] = sum;
+    if ((threadIdx.x & 63) == 0) x_cnt(a, b)[vt >> 6] = count;
+}
 
-    // 3. resample: cdf of W / sum(W) by a blocked scan (each thread owns a contiguous chunk)
-    double *cdf = CDF_IN_LDS ? cdf_lds : cdf_scratch + b * S;
-    const long chunk = (S + DLAGP_LEVEL_THREADS - 1) / DLAGP_LEVEL_THREADS;
-    const long lo = tid * chunk, hi = lo + chunk < S ? lo + chunk : S;
-    auto weight = [&](long i) -> double {
-        if (CDF_IN_LDS) return work[i];
-        const double v = col[i];
-        return v == v ? exp(v - top) : 0.0;
-    };
-    double local = 0.0;
-    for (long i = lo; i < hi; ++i) local += weight(i) / sum;
-    scan[tid] = local;
+// LDS of phase B besides the cumulative array
+struct ResampleShared {
+    double scale[DLAGP_LEVEL_LANES];  // f_t = exp(m_t - M)
+    double incl[DLAGP_LEVEL_LANES];   // inclusive scan of f_t s_t within the lane's wave
+    double tot[16], offs[18], red[16];
+};
+
+// Phase B, a workgroup of `threads` threads (a multiple of 64, a divisor of 1024) that is number `group` of `groups` of
+// its sightline: the level's maximum, the lanes' scales and scans, the evidence (group 0 writes it), the cumulative
+// weights of ALL samples into `cum` (LDS; or, IN_PLACE, over the weights in memory -- one group only), then this
+// group's share of the searches.
+template <bool IN_PLACE>
+__device__ __forceinline__ void resample(const LevelArgs &a, long b, int tid, int threads, int group, int groups, double *cum_lds,
+                                         ResampleShared &sh) {
+    const long S = a.S;
+    const int level = a.level;
+    const double *xm = x_m(a, b), *xs = x_s(a, b);
+    const int lane = tid & 63;
+    double top = -__builtin_inf();
+    for (int vl = tid; vl < DLAGP_LEVEL_LANES; vl += threads) top = fmax(top, xm[vl]);
+    top = wave_max(top);
+    if (lane == 0) sh.red[tid >> 6] = top;
     __syncthreads();
-    for (int off = 1; off < DLAGP_LEVEL_THREADS; off <<= 1) {  // inclusive Hillis-Steele scan
-        const double add = tid >= off ? scan[tid - off] : 0.0;
-        __syncthreads();
-        scan[tid] += add;
-        __syncthreads();
-    }
-    const double last = scan[DLAGP_LEVEL_THREADS - 1];
-    double running = tid > 0 ? scan[tid - 1] : 0.0;
-    for (long i = lo; i < hi; ++i) {
-        running += weight(i) / sum;
-        cdf[i] = running / last;  // in LDS: overwrites the weight it was made from, chunk by chunk
+    top = sh.red[0];
+    for (int w = 1; w < threads / 64; ++w) top = fmax(top, sh.red[w]);
+    for (int vl = tid; vl < DLAGP_LEVEL_LANES; vl += threads) {  // the real wave holds one whole virtual wave per turn
+        const double m = xm[vl];
+        const double f = m > -__builtin_inf() ? exp(m - top) : 0.0;
+        double incl = f * xs[vl];
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        sh.scale[vl] = f;
+        sh.incl[vl] = incl;
+        if (lane == 63) sh.tot[vl >> 6] = incl;
     }
     __syncthreads();
-    __threadfence_block();
-    int *out = base + (b * (max_dlas - 1) + level) * S;
-    const double *u = uniforms + (b * (max_dlas - 1) + level) * S;
-    // four searches per thread in flight: each is ~14 dependent reads of the cdf
-    for (long i0 = tid; i0 < S; i0 += (long)BATCH * DLAGP_LEVEL_THREADS) {
-        double ui[BATCH];
+    if (tid == 0) {
+        const double *cnt = x_cnt(a, b);
+        double run = 0.0, count = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            sh.offs[w] = run;
+            run += sh.tot[w];
+            count += cnt[w];
+        }
+        sh.offs[16] = run;
+        sh.offs[17] = count;
+    }
+    __syncthreads();
+    const double last = sh.offs[16], count = sh.offs[17];
+    const double evidence = count > 0.0 ? top + log(last / count) - level * a.log_s : __builtin_nan("");
+    if (group == 0 && tid == 0) {
+        a.evidences[b * a.max_dlas + level] = evidence;
+        if (!(evidence == evidence)) a.alive[b] = 0;
+    }
+    if (level + 1 == a.max_dlas || !(evidence == evidence)) return;
+
+    double *W = a.weights + b * S;
+    double *cum = IN_PLACE ? W : cum_lds;
+    const long chunk = (S + DLAGP_LEVEL_LANES - 1) / DLAGP_LEVEL_LANES;
+    constexpr int KEEP = 12;  // S <= 12 288: a chunk's reads are issued together
+    for (int vl = tid; vl < DLAGP_LEVEL_LANES; vl += threads) {
+        const long lo = (long)vl * chunk, hi = lo + chunk < S ? lo + chunk : S;
+        if (lo >= S) break;
+        const double f = sh.scale[vl];
+        double run = sh.offs[vl >> 6] + ((vl & 63) ? sh.incl[vl - 1] : 0.0);
+        if (chunk <= KEEP) {
+            double w[KEEP];
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) w[k] = lo + k < hi ? W[lo + k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k)
+                if (lo + k < hi) {
+                    run += f * w[k];
+                    cum[lo + k] = run;
+                }
+        } else {
+            for (long i = lo; i < hi; ++i) {
+                run += f * W[i];
+                cum[i] = run;
+            }
+        }
+    }
+    __syncthreads();
+
+    int *out = a.base + (b * (a.max_dlas - 1) + level) * S;
+    const double *u = a.uniforms + (b * (a.max_dlas - 1) + level) * S;
+    const double margin = DLAGP_TIE_MARGIN * last;
+    constexpr int BATCH = 5;  // searches per thread in flight: each is ~14 dependent reads of the cumulative array
+    const long stride = (long)groups * threads;
+    int near = 0;
+    for (long i0 = (long)group * threads + tid; i0 < S; i0 += (long)BATCH * stride) {
+        double x[BATCH];
         long left[BATCH], right[BATCH];
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
-            const long i = i0 + (long)k * DLAGP_LEVEL_THREADS;
-            ui[k] = u[i < S ? i : S - 1];
+            const long i = i0 + (long)k * stride;
+            x[k] = u[i < S ? i : S - 1] * last;
             left[k] = 0;
-            right[k] = S;  // first index with cdf[index] > u  (searchsorted side="right")
+            right[k] = i < S ? S : 0;  // first index with cum[index] > x  (searchsorted side="right")
         }
         bool busy = true;
         while (busy) {
@@ -1087,17 +1148,64 @@ __global__ __launch_bounds__(DLAGP_LEVEL_THREADS) void level_finish(
             for (int k = 0; k < BATCH; ++k)
                 if (left[k] < right[k]) {
                     const long mid = (left[k] + right[k]) >> 1;
-                    if (cdf[mid] <= ui[k]) left[k] = mid + 1;
+                    if (cum[mid] <= x[k]) left[k] = mid + 1;
                     else right[k] = mid;
                     busy = true;
                 }
         }
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
-            const long i = i0 + (long)k * DLAGP_LEVEL_THREADS;
-            if (i < S) out[i] = (int)(left[k] < S ? left[k] : S - 1);
+            const long i = i0 + (long)k * stride;
+            if (i >= S) continue;
+            const long at = left[k];
+            out[i] = (int)(at < S ? at : S - 1);
+            // the steps on either side of the answer: cum[at] (the first above x) and cum[at - 1] (the last not above)
+            const bool above = at < S && cum[at] - x[k] <= margin;
+            const bool below = at > 0 && x[k] - cum[at - 1] <= margin;
+            near += (above || below) ? 1 : 0;
         }
     }
+    if (a.ties) {
+        for (int off = 32; off > 0; off >>= 1) near += __shfl_xor(near, off);
+        if (lane == 0 && near) atomicAdd(a.ties + b * (a.max_dlas - 1) + level, near);
+    }
+}
+
+// bookkeeping every form does first, by one thread of the launch's first kernel
+__device__ __forceinline__ void begin(const LevelArgs &a, long b, bool first_block, int tid) {
+    if (first_block && b == 0 && tid == 0 && *a.status) *a.sticky_status = 1;  // the next level's accumulate clears *status
+    if (first_block && tid == 0 && a.ties && a.level + 1 < a.max_dlas) a.ties[b * (a.max_dlas - 1) + a.level] = 0;
+}
+}  // namespace lvl
+
+// ---- the one-workgroup form
+template <bool CUM_IN_LDS>
+__global__ __launch_bounds__(DLAGP_LEVEL_THREADS) void level_finish_fused(LevelArgs a) {
+    extern __shared__ double cum_lds[];
+    __shared__ lvl::ResampleShared sh;
+    const int tid = threadIdx.x;
+    const long b = blockIdx.x;
+    lvl::begin(a, b, true, tid);
+    if (!a.alive[b]) return;  // an earlier level's evidence was NaN: the reference stopped there
+    lvl::lane_weights<4>(a, b, tid);
+    __syncthreads();
+    lvl::resample<!CUM_IN_LDS>(a, b, tid, DLAGP_LEVEL_THREADS, 0, 1, cum_lds, sh);
+}
+
+// ---- the spread form: grid (workgroups per sightline, sightlines)
+__global__ __launch_bounds__(64) void level_weights(LevelArgs a) {
+    const long b = blockIdx.y;
+    lvl::begin(a, b, blockIdx.x == 0, threadIdx.x);
+    if (!a.alive[b]) return;
+    lvl::lane_weights<12>(a, b, (int)blockIdx.x * 64 + (int)threadIdx.x);  // grid.x == 16: one wave of virtual lanes per workgroup
+}
+
+__global__ __launch_bounds__(DLAGP_LEVEL_SEARCH_THREADS) void level_resample(LevelArgs a) {
+    extern __shared__ double cum_lds[];
+    __shared__ lvl::ResampleShared sh;
+    const long b = blockIdx.y;
+    if (!a.alive[b]) return;
+    lvl::resample<false>(a, b, threadIdx.x, DLAGP_LEVEL_SEARCH_THREADS, blockIdx.x, gridDim.x, cum_lds, sh);
 }
 
 // Start of an occupation sweep in one launch (reference dla_gp.py:112-119: NaN-initialised likelihoods and evidences,

@@ -231,8 +231,9 @@ def sweep_sharded_samples_device(batch, sample_z: np.ndarray, sample_nhi: np.nda
     d_sample_ll = torch.empty((nb, max_dlas, S), **f64)
     d_evidences = torch.empty((nb, max_dlas), **f64)
     d_base = torch.zeros((nb, max(max_dlas - 1, 1), S), dtype=torch.int32, device=dev)
-    d_flags = torch.zeros(nb + 2, dtype=torch.int32, device=dev)
-    d_cdf = torch.empty((nb, S), **f64)
+    levels = max(max_dlas - 1, 0)
+    d_flags = torch.zeros(nb + 2 + nb * levels, dtype=torch.int32, device=dev)  # alive, status x 2, near-tie counts
+    d_cdf = torch.empty(nb * (S + _lib.LEVEL_EXCHANGE), **f64)
     per_rank = -(-S // world_size)  # equal slices (the last may be short): one fixed-size collective per level
     mine = slices if slices is not None else [(min(rank * per_rank, S), min((rank + 1) * per_rank, S))]
     d_local = torch.zeros((nb, per_rank if slices is None else max(hi - lo for lo, hi in mine)), **f64)
@@ -264,7 +265,20 @@ def sweep_sharded_samples_device(batch, sample_z: np.ndarray, sample_nhi: np.nda
             ptr(d_evidences), ptr(d_base), ptr(d_cdf), ptr(d_flags), dev.index, stream))
     torch.cuda.synchronize(dev)
     base = d_base[:, : max_dlas - 1].cpu().numpy() if max_dlas > 1 else np.zeros((nb, 0, S), dtype=np.int32)
-    return (d_evidences.cpu().numpy(), np.ascontiguousarray(d_sample_ll.cpu().numpy().transpose(0, 2, 1)), base)
+    evidences = d_evidences.cpu().numpy()
+    sample_ll = np.ascontiguousarray(d_sample_ll.cpu().numpy().transpose(0, 2, 1))
+    if levels:
+        # every rank holds the same likelihoods, uniforms and near-tie counts, so every rank settles the same levels the
+        # same way (a level whose indices change is redone locally, all samples on this rank's device: no collective)
+        from .sightline import settle_near_ties
+
+        ties = d_flags[nb + 2:].cpu().numpy().reshape(nb, levels)
+        if ties.any():
+            base = np.ascontiguousarray(base)
+            settle_near_ties(ties, evidences, sample_ll, base, np.asarray(uniforms, dtype=np.float64),
+                             np.asarray(sample_z, dtype=np.float64), np.asarray(sample_nhi, dtype=np.float64),
+                             float(min_z_separation), lambda b, z, n: batch.sightlines[b].eval(z, n))
+    return evidences, sample_ll, base
 
 
 def sweep_batch(

@@ -195,6 +195,70 @@ class DeviceSightline:
         _lib.check(_lib.load().dlagp_eval_device(self._handle, S, kd, d_z, d_nhi, d_out, stream))
 
 
+def exact_choice(level_ll: np.ndarray, uniforms: np.ndarray) -> np.ndarray:
+    """
+    `np.random.choice(np.arange(S).astype(np.int32), size=S, replace=True, p=W / W.sum())` of the reference
+    (dla_gp.py:209-218) for the uniforms its `random_sample(S)` would have drawn: W = exp(ll - nanmax), NaN -> 0, and the
+    legacy generator's own steps -- `cdf = p.cumsum(); cdf /= cdf[-1]; cdf.searchsorted(uniforms, side="right")` -- in
+    NumPy, so that every rounding is NumPy's.
+    """
+    weights = np.exp(level_ll - np.nanmax(level_ll))
+    weights[np.isnan(weights)] = 0.0
+    cdf = (weights / weights.sum()).cumsum()
+    cdf /= cdf[-1]
+    return cdf.searchsorted(uniforms, side="right").astype(np.int32)
+
+
+def settle_near_ties(ties, evidences, sample_ll, base, uniforms, sample_z, sample_nhi, min_z_separation: float, level_eval):
+    """
+    Makes a device sweep's `base_sample_inds` np.random.choice's by construction.  The library's cdf and NumPy's differ by
+    rounding (~1e-16), so the two can disagree on an index only where a uniform lies that close to a cdf step; the library
+    counts, per sightline and level, the searches that ended within 1e-11 of a step (`ties`, dlagp_batch_resample_ties).
+    For those levels -- about two in a thousand at S = 10 000 -- the indices are recomputed here with NumPy's own arithmetic
+    (`exact_choice`) from the level's likelihoods as the device returned them.  They have never differed outside tests
+    that plant uniforms on the steps; if they do, the sightline's remaining levels are redone from that level on with the
+    host half of every level in NumPy (`level_eval(b, z (S, kd), nhi (S, kd)) -> (S,)` evaluates on the device).
+
+    Arrays of the whole batch, modified in place: evidences (nb, max_dlas), sample_ll (nb, S, max_dlas), base
+    (nb, max_dlas - 1, S), uniforms (nb, max_dlas - 1, S), sample_z (nb, S), sample_nhi (S,) or (nb, S).
+    :return: number of (sightline, level) pairs whose indices changed
+    """
+    from .dla_gp import level_parameters
+
+    ties = np.asarray(ties)
+    changed = 0
+    nb, S, max_dlas = sample_ll.shape
+    for b in np.flatnonzero(ties.any(axis=1)):
+        nhi = sample_nhi if sample_nhi.ndim == 1 else sample_nhi[b]
+        level = 0
+        while level + 1 < max_dlas:
+            if np.isnan(evidences[b, level]):
+                break  # the sweep stopped here (reference dla_gp.py:200-206): nothing was resampled
+            if ties[b, level]:
+                exact = exact_choice(sample_ll[b, :, level], uniforms[b, level])
+                if not np.array_equal(exact, base[b, level]):
+                    # NumPy draws another index somewhere: this level's indices are NumPy's, and everything behind them is
+                    # recomputed -- device evaluations, host half of the levels in NumPy (all of them "tied" from here on)
+                    changed += 1
+                    base[b, level] = exact
+                    base[b, level + 1:] = 0
+                    sample_ll[b, :, level + 1:] = np.nan
+                    evidences[b, level + 1:] = np.nan
+                    ties[b, level + 1:] = 1
+                    z, n, idx = level_parameters(sample_z[b], nhi, base[b], level + 1)
+                    sample_ll[b, :, level + 1] = np.asarray(level_eval(b, z, n), dtype=np.float64) - np.log(S)
+                    column = sample_ll[b, :, level + 1]
+                    too_close = np.any(np.diff(np.sort(sample_z[b][idx], axis=0), axis=0) < min_z_separation, axis=0)
+                    column[too_close] = np.nan  # reference dla_gp.py:164-177
+                    if np.isnan(column).all():
+                        evidences[b, level + 1] = np.nan
+                    else:
+                        top = np.nanmax(column)
+                        evidences[b, level + 1] = top + np.log(np.nanmean(np.exp(column - top))) - np.log(S) * (level + 1)
+            level += 1
+    return changed
+
+
 class DeviceBatch:
     """Sightlines of one device evaluated by one launch sequence; arrays are [nb][S][kd]."""
 
@@ -207,7 +271,9 @@ class DeviceBatch:
         _lib.check(lib.dlagp_batch_create(ctypes.byref(handle), arr, nb))
         self._handle = handle
         self.nb = nb
-        self._pending = None  # (S, max_dlas) between model_evidences_start and model_evidences_finish
+        self._pending = None  # (S, max_dlas, ...) between model_evidences_start and model_evidences_finish
+        self.last_ties = None  # near-tie counts of the last multi-level sweep, and how many levels `settle_near_ties` changed
+        self.last_changed = 0
 
     def close(self) -> None:
         if getattr(self, "_handle", None):
@@ -237,6 +303,27 @@ class DeviceBatch:
 
     def eval_device(self, S: int, kd: int, d_z: int, d_nhi: int, d_out: int, stream: int = 0) -> None:
         _lib.check(_lib.load().dlagp_batch_eval_device(self._handle, S, kd, d_z, d_nhi, d_out, stream))
+
+    def resample_ties(self, max_dlas: int) -> np.ndarray:
+        """(nb, max_dlas - 1) near-tie counts of the batch's most recent sweep (dlagp_batch_resample_ties)"""
+        out = np.zeros((self.nb, max(max_dlas - 1, 0)), dtype=np.int32)
+        if out.size:
+            _lib.check(_lib.load().dlagp_batch_resample_ties(
+                self._handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), out.size))
+        return out
+
+    def _settle(self, evidences, sample_ll, base, uniforms, sample_z, sample_nhi, min_z_separation):
+        """`settle_near_ties` for a sweep this batch has just run; returns the (possibly copied) result arrays"""
+        max_dlas = evidences.shape[1]
+        if max_dlas < 2:
+            return evidences, sample_ll, base
+        ties = self.resample_ties(max_dlas)
+        self.last_ties = ties
+        if ties.any():
+            self.last_changed = settle_near_ties(
+                ties, evidences, sample_ll, base, uniforms, sample_z, sample_nhi, min_z_separation,
+                lambda b, z, n: self.sightlines[b].eval(z, n))
+        return evidences, sample_ll, base
 
     def nulls(self) -> np.ndarray:
         """null-model evidence of every member (NullGP.log_model_evidence, null_gp.py:294-305), one launch"""
@@ -283,7 +370,7 @@ class DeviceBatch:
         # (nb, S, max_dlas) as a VIEW of the level-major buffer the library fills: a contiguous copy costs 50 us per
         # sightline, and the consumers' reductions over the samples (np.nanargmax(..., axis=0) of the MAP estimate)
         # run ten times faster along the buffer's contiguous axis
-        return evidences, sample_ll.transpose(0, 2, 1), base
+        return self._settle(evidences, sample_ll.transpose(0, 2, 1), base, uniforms, sample_z, sample_nhi, min_z_separation)
 
     def model_evidences(self, sub_sample_z, sub_sample_nhi, sample_z, sample_nhi, max_dlas: int,
                         min_z_separation: float, uniforms=None):
@@ -332,7 +419,7 @@ class DeviceBatch:
             _lib.ptr(sub_ll), _lib.ptr(evidences), _lib.ptr(sample_ll),
             base.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) if max_dlas > 1 else None))
         return (nulls, (sub_ev, sub_ll.transpose(0, 2, 1), np.zeros((nb, 0, S), dtype=np.int32)),
-                (evidences, sample_ll.transpose(0, 2, 1), base))
+                self._settle(evidences, sample_ll.transpose(0, 2, 1), base, uniforms, z, nhi, min_z_separation))
 
     def model_evidences_start(self, sub_sample_z, sub_sample_nhi, sample_z, sample_nhi, max_dlas: int,
                               min_z_separation: float) -> None:
@@ -362,13 +449,13 @@ class DeviceBatch:
         _lib.check(_lib.load().dlagp_batch_model_evidences_start(
             self._handle, S, int(max_dlas), _lib.ptr(sub_z), _lib.ptr(sub_nhi), sub_stride, _lib.ptr(z), _lib.ptr(nhi), stride,
             float(min_z_separation)))
-        self._pending = (S, int(max_dlas))
+        self._pending = (S, int(max_dlas), z, nhi, float(min_z_separation))
 
     def model_evidences_finish(self, uniforms=None):
         """second phase: same return value as `model_evidences`"""
         if self._pending is None:
             raise ValueError("model_evidences_finish without a matching model_evidences_start")
-        S, max_dlas = self._pending
+        S, max_dlas, z, nhi, min_z_separation = self._pending
         self._pending = None
         nb = self.nb
         if max_dlas > 1:
@@ -388,7 +475,7 @@ class DeviceBatch:
             _lib.ptr(evidences), _lib.ptr(sample_ll),
             base.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) if max_dlas > 1 else None))
         return (nulls, (sub_ev, sub_ll.transpose(0, 2, 1), np.zeros((nb, 0, S), dtype=np.int32)),
-                (evidences, sample_ll.transpose(0, 2, 1), base))
+                self._settle(evidences, sample_ll.transpose(0, 2, 1), base, uniforms, z, nhi, min_z_separation))
 
     def model_evidences_cancel(self) -> None:
         """give up a `model_evidences_start` that will not be finished (the caller's own work in between raised)"""
@@ -451,6 +538,18 @@ def setup_sync(device: int = 0) -> None:
 
 def set_option(name: str, value: int) -> None:
     _lib.check(_lib.load().dlagp_set_option(name.encode(), int(value)))
+
+
+def set_options_from_env(variable: str = "DLAGP_OPTIONS") -> dict:
+    """tuning runs: DLAGP_OPTIONS="level_spread=0,plan_slots=1024" sets those options; returns what it set"""
+    import os
+
+    done = {}
+    for item in filter(None, os.environ.get(variable, "").split(",")):
+        name, _, value = item.partition("=")
+        set_option(name.strip(), int(value))
+        done[name.strip()] = int(value)
+    return done
 
 
 def get_option(name: str) -> int:

@@ -76,7 +76,8 @@ typedef struct dlagp_ctx dlagp_ctx;     /* one sightline's model + data, residen
 typedef struct dlagp_batch dlagp_batch; /* a launch group of sightlines on one device       */
 typedef struct dlagp_model dlagp_model; /* the learned GP model (rest-frame grid), in HBM   */
 
-/* ABI version of this header; bumped on any signature or status-code change.  2: DLAGP_ENOMEM. */
+/* ABI version of this header; bumped on any signature or status-code change.  2: DLAGP_ENOMEM.  3: near-tie counts of the
+ * resampling (dlagp_batch_resample_ties; larger d_cdf_scratch / d_flags of dlagp_level_finish_device). */
 int dlagp_abi_version(void);
 
 /* Number of visible HIP devices (0 if none / runtime unusable). */
@@ -223,6 +224,15 @@ int dlagp_batch_null(dlagp_batch *batch, double *out);
  * The host variant is synchronous, sample_ll / base_inds may be NULL, and a non-PD B in any level
  * returns DLAGP_ELINALG.  The device variant takes HBM pointers (all required), enqueues on `stream`
  * and does not synchronise.  1 <= max_dlas <= DLAGP_MAX_ABSORBERS, S < 2^31.
+ *
+ * base_inds are np.random.choice's indices by construction, in two steps.  The library accumulates the weights in blocks
+ * (1024 chunks, each relative to its own maximum, wave scans), NumPy sequentially after normalising: the two cdfs differ by rounding (~1e-16; bounded by
+ * ~S eps), so an index could differ only where a uniform falls that close to a cdf step.  Every search that ends within
+ * DLAGP_TIE_MARGIN = 1e-11 of the step on either side of its answer is counted per (sightline, level);
+ * dlagp_batch_resample_ties returns the counts of the batch's most recent sweep, and a caller that wants the reference's
+ * indices to the last bit recomputes the levels with a non-zero count with NumPy's own arithmetic (the Python classes do:
+ * gpy_dla_detection_amd/sightline.py `settle_near_ties`; about two levels in a thousand at S = 10 000, and the recomputed
+ * indices have never differed outside planted tests).
  */
 int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double *sample_z,
                       const double *sample_nhi, int64_t nhi_stride, double min_z_separation,
@@ -232,6 +242,15 @@ int dlagp_batch_sweep_device(dlagp_batch *batch, int64_t S, int max_dlas, const 
                              const double *d_sample_nhi, int64_t nhi_stride,
                              double min_z_separation, const double *d_uniforms, double *d_evidences,
                              double *d_sample_ll, int32_t *d_base_inds, void *stream);
+
+/*
+ * ties[b * (max_dlas - 1) + level] = searches of level `level`'s resampling of sightline b, in the batch's most recent
+ * occupation sweep (any of dlagp_batch_sweep*, dlagp_batch_two_model_sweep_device, dlagp_batch_model_evidences*), that ended
+ * within 1e-11 of a cdf step -- see above.  capacity = entries `ties` has room for (nb * (max_dlas - 1) are written; none
+ * when max_dlas was 1).  After a host-pointer sweep the counts are already on the host; after a *_device sweep the call
+ * waits for that sweep's stream.  DLAGP_EINVAL before the batch's first sweep.
+ */
+int dlagp_batch_resample_ties(dlagp_batch *batch, int32_t *ties, int64_t capacity);
 
 /*
  * Two models at the SAME redshift samples in one device-resident call: a one-absorber model (the sub-DLA model,
@@ -305,9 +324,13 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
  *                                  base_inds[b][level][:] with the SAME uniforms (:155-218) -- identical indices on
  *                                  every rank, no broadcast.
  * dlagp_sweep_state_init_device NaN-/zero-fills sample_ll [nb][max_dlas][S], evidences [nb][max_dlas], base_inds
- * [nb][max_dlas-1][S] and the nb + 2 int32 flags (alive per sightline, sticky status, zero) before level 0.
- * d_cdf_scratch: nb * S doubles.  All pointers are HBM addresses; everything is enqueued on `stream`.
+ * [nb][max_dlas-1][S] and the int32 flags before level 0.
+ * d_flags: nb + 2 + nb * (max_dlas - 1) int32 -- alive per sightline, sticky non-PD status, a zero, and (ABI 3) the
+ * near-tie counts [nb][max_dlas-1] of the resampling (see dlagp_batch_sweep: every rank holds the same counts and settles
+ * the same levels).  d_cdf_scratch: nb * (S + DLAGP_LEVEL_EXCHANGE) doubles (ABI 3: the weights and what the kernels of a
+ * level hand each other).  All pointers are HBM addresses; everything is enqueued on `stream`.
  */
+#define DLAGP_LEVEL_EXCHANGE 2064
 int dlagp_batch_level_eval_device(dlagp_batch *batch, int64_t S_total, int64_t s_begin, int64_t s_count, int level,
                                   const double *d_sample_z, const double *d_sample_nhi, int64_t nhi_stride,
                                   const int32_t *d_base_inds, int base_levels, double *d_out, void *stream);
@@ -357,7 +380,11 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     identical results, bit for bit; default 1), "pair_models" (1 = dlagp_batch_model_evidences* and
  *                     dlagp_batch_two_model_sweep_device evaluate the sub-DLA model and level 1 of the DLA model in ONE
  *                     launch when both sample the same redshifts -- one Voigt optical depth per QMC point; 0 = two
- *                     launches; identical results at equal cuts, to rounding otherwise; default 1)
+ *                     launches; identical results at equal cuts, to rounding otherwise; default 1),
+ *                     "level_spread" (1 = the kernels that end an occupation level -- Occam term and separation mask,
+ *                     evidence, resampling -- run as two launches that spread a sightline over ~30 compute units; 0 = one
+ *                     1024-thread workgroup per sightline; identical results, bit for bit; default 1), "level_search_groups"
+ *                     (workgroups per sightline that share the searches of the spread form, 1..64, default 16)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.
  */
@@ -372,7 +399,8 @@ int dlagp_set_option(const char *name, int64_t value);
  * blocks, see "fuse_finalize"), "big_allocs" / "big_frees" (sweep-workspace buffers above the pool's 64 MB
  * limit allocated / freed since the library was loaded -- a free synchronises the device; a pipelined run in its steady
  * state shows neither), "work_stream_idle" (1 = the current device's shared kernel stream has nothing queued or running
- * at this instant: polled from a side thread it says how often the host leaves the device without work). */
+ * at this instant: polled from a side thread it says how often the host leaves the device without work), "last_level_spread"
+ * (1 = the most recent level finish ran in its spread form, see "level_spread"). */
 int dlagp_get_option(const char *name, int64_t *value);
 /* The work decomposition the MFMA path would choose for `groups` blocks of 16 samples of sightlines with `chunks`
  * chunks of 8 pixel slots each (pure host arithmetic, no device needed): every block is cut into `full` pieces of

@@ -26,7 +26,7 @@ def test_header_and_binding_agree():
 
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(_lib.LIB_PATH), "build with `make -C gpy_dla_detection_amd/csrc`"
-    assert _lib.load().dlagp_abi_version() == 2  # first: it maps the one HIP runtime this process is to have
+    assert _lib.load().dlagp_abi_version() == _lib.ABI_VERSION == 3  # first: it maps the one HIP runtime this process is to have
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name

@@ -804,6 +804,8 @@ def restore_options():
     set_option("finalize_wave", 1)
     set_option("fuse_finalize", 1)
     set_option("pair_models", 1)
+    set_option("level_spread", 1)
+    set_option("level_search_groups", 16)
 
 
 @pytest.mark.parametrize("shape", [dict(index=4, n_unmasked=1250, n_masked=28, k=20),
@@ -1303,6 +1305,140 @@ def test_by_sample_split_on_device_matches_reference_golden(tag):
     assert np.array_equal(results[0][2], want_base) and np.array_equal(results[1][2], want_base)
     np.testing.assert_allclose(results[0][0], want_ev, rtol=1e-12)
     np.testing.assert_allclose(results[1][1], want_ll, rtol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("S,nb,max_dlas", [(10000, 1, 4), (1200, 3, 4), (96, 2, 3), (1, 1, 2), (18000, 1, 2), (20000, 2, 3)])
+def test_level_finish_spread_over_many_workgroups_equals_one_workgroup_bit_for_bit(S, nb, max_dlas, restore_options):
+    """
+    The kernels that end a level (Occam term, separation mask, evidence, resampling: reference dla_gp.py:155-218) in
+    their two forms -- one 1024-thread workgroup per sightline, or three launches that spread a sightline over many
+    compute units, with any number of workgroups sharing the searches: evidences, likelihoods, base indices and near-tie
+    counts identical to the last bit.  (S = 20 000 does not fit the LDS: both settings run the one-workgroup kernel.)
+    """
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch, get_option
+
+    sights = [make_sightline(70 + i, n_unmasked=150 + 40 * i, n_masked=3 * i) for i in range(nb)]
+    batch = DeviceBatch([device_sightline(s) for s in sights])
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    min_sep = 3000.0 * 1000.0 / 299792458.0
+    uniforms = parallel.resampling_uniforms(nb, max_dlas, S, seed=5)
+    restore_options("level_spread", 0)
+    want = batch.sweep(zs, nhi, max_dlas, min_sep, uniforms)
+    want_ties = batch.last_ties.copy()
+    assert get_option("last_level_spread") == 0
+    if S > 1:
+        assert want[2].max() > 0  # resampling happened
+    for groups in (1, 5, 16, 64):
+        restore_options("level_spread", 1)
+        restore_options("level_search_groups", groups)
+        got = batch.sweep(zs, nhi, max_dlas, min_sep, uniforms)
+        assert get_option("last_level_spread") == (1 if S <= 18000 else 0)
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(batch.last_ties, want_ties)
+    batch.close()
+
+
+def numpy_cdf(level_ll):
+    """the cdf legacy np.random.choice searches (reference dla_gp.py:209-218), with NumPy's own roundings"""
+    weights = np.exp(level_ll - np.nanmax(level_ll))
+    weights[np.isnan(weights)] = 0.0
+    cdf = (weights / weights.sum()).cumsum()
+    cdf /= cdf[-1]
+    return cdf
+
+
+def planted_uniforms(cdf, rng):
+    """uniforms exactly ON cdf steps, one ulp below and one ulp above them, and ordinary ones in between"""
+    S = cdf.shape[0]
+    steps = cdf[rng.integers(0, S, size=S)]
+    kind = rng.integers(0, 4, size=S)
+    u = np.where(kind == 0, steps, np.where(kind == 1, np.nextafter(steps, 0.0), np.where(kind == 2, np.nextafter(steps, 2.0),
+                                                                                        rng.random(S))))
+    return np.clip(u, 0.0, np.nextafter(1.0, 0.0))  # random_sample draws from [0, 1)
+
+
+@pytest.mark.parametrize("spread", [1, 0])
+def test_resampling_draws_numpys_indices_where_uniforms_sit_on_cdf_steps(spread, restore_options):
+    """
+    `base_sample_inds` are np.random.choice's BY CONSTRUCTION (reference dla_gp.py:213-218).  The library's cdf and
+    NumPy's differ by rounding, so uniforms planted exactly on cdf steps, one ulp below and one ulp above are where the
+    two would disagree: the library counts every search that ends within 1e-11 of a step, and `settle_near_ties` redoes
+    those levels with NumPy's arithmetic -- and, when an index changes, everything behind it.  Level by level: plant on
+    the level's NumPy cdf, sweep, demand NumPy's indices.
+    """
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    restore_options("level_spread", spread)
+    rng = np.random.default_rng(11)
+    sights = [make_sightline(80, n_unmasked=310, n_masked=6), make_sightline(81, n_unmasked=280, n_masked=0)]
+    batch = DeviceBatch([device_sightline(s) for s in sights])
+    S, max_dlas, nb = 3000, 4, 2
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = make_qmc_samples(sights[0], S)[2]
+    min_sep = 3000.0 * 1000.0 / 299792458.0
+    uniforms = parallel.resampling_uniforms(nb, max_dlas, S, seed=2)
+    changed = 0
+    for level in range(max_dlas - 1):
+        # the sweep up to `level` does not depend on this level's uniforms: its likelihoods give the cdf to plant on
+        ev, ll, base = batch.sweep(zs, nhi, max_dlas, min_sep, uniforms)
+        for b in range(nb):
+            uniforms[b, level] = planted_uniforms(numpy_cdf(ll[b, :, level]), rng)
+        ev, ll, base = batch.sweep(zs, nhi, max_dlas, min_sep, uniforms)
+        # three quarters of the searches sit on a step (behind a level whose indices changed the host has taken over,
+        # and the count is a plain 'settle this level too')
+        assert (batch.last_ties[:, level] > (S // 2 if level == 0 else 0)).all()
+        changed += batch.last_changed
+        for b in range(nb):
+            for lower in range(level + 1):
+                want = numpy_cdf(ll[b, :, lower]).searchsorted(uniforms[b, lower], side="right")
+                np.testing.assert_array_equal(base[b, lower], want)
+    assert changed > 0  # the device's own answer differed somewhere, and the levels behind it were redone
+    # the redone levels are a sweep's levels: the oracle-driven host logic with the same indices injected gives the same numbers
+    for b in range(nb):
+        for level in range(1, max_dlas):
+            idx = np.concatenate([np.arange(S)[None, :], base[b, :level]], axis=0)
+            got = ll[b, :, level]
+            too_close = np.any(np.diff(np.sort(zs[b][idx], axis=0), axis=0) < min_sep, axis=0)
+            assert np.array_equal(np.isnan(got), too_close)
+            direct = batch.sightlines[b].eval(zs[b][idx].T, nhi[idx].T) - np.log(S)
+            np.testing.assert_allclose(got[~too_close], direct[~too_close], rtol=1e-12)
+    # ordinary uniforms: a handful of near ties at most, nothing changes, and the by-sample split settles the same way
+    uniforms = parallel.resampling_uniforms(nb, max_dlas, S, seed=3)
+    ev, ll, base = batch.sweep(zs, nhi, max_dlas, min_sep, uniforms)
+    assert batch.last_ties.sum() < 10
+    batch.close()
+
+
+def test_by_sample_split_settles_planted_ties_like_the_one_device_sweep():
+    """the by-sample split (every rank finishes a level with the same uniforms) counts and settles near ties too"""
+    import torch
+
+    from gpy_dla_detection_amd import parallel
+    from gpy_dla_detection_amd.sightline import DeviceBatch
+
+    torch.cuda.init()
+    rng = np.random.default_rng(12)
+    sight = make_sightline(82, n_unmasked=290, n_masked=4)
+    batch = DeviceBatch([device_sightline(sight)])
+    S, max_dlas = 2500, 3
+    z = make_qmc_samples(sight, S)[0][None, :]
+    nhi = make_qmc_samples(sight, S)[2]
+    min_sep = 3000.0 * 1000.0 / 299792458.0
+    uniforms = parallel.resampling_uniforms(1, max_dlas, S, seed=1)
+    ev, ll, base = batch.sweep(z, nhi, max_dlas, min_sep, uniforms)
+    uniforms[0, 0] = planted_uniforms(numpy_cdf(ll[0, :, 0]), rng)
+    want = batch.sweep(z, nhi, max_dlas, min_sep, uniforms)
+    np.testing.assert_array_equal(want[2][0, 0], numpy_cdf(want[1][0, :, 0]).searchsorted(uniforms[0, 0], side="right"))
+    for slices in (None, [(0, 1000), (1000, 1003), (1003, S)]):
+        got = parallel.sweep_sharded_samples_device(batch, z, nhi, max_dlas, min_sep, uniforms, slices=slices)
+        np.testing.assert_array_equal(got[2], want[2])
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-12)
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-12, equal_nan=True)
+    batch.close()
 
 
 def test_device_sweep_stops_a_sightline_on_nan_evidence():

@@ -43,6 +43,9 @@ def loop(spectra, z_qsos, param, prior, dla_samples, subdla_samples, learned, ma
 
 
 def main():
+    from gpy_dla_detection_amd.sightline import set_options_from_env
+
+    options = set_options_from_env()
     num = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
     param = Parameters(num_dla_samples=S)
@@ -66,7 +69,7 @@ def main():
         pstats.Stats(pr).sort_stats("cumtime").print_stats(30)
     print(json.dumps({"route": "A (reference driver loop, imports swapped)", "spectra": num, "S": S, "max_dlas": 4,
                       "seconds": t, "spectra_per_s": num / t, "ms_per_spectrum": 1e3 * t / num,
-                      "argmax_counts": np.bincount(argmax, minlength=6).tolist()}))
+                      "argmax_counts": np.bincount(argmax, minlength=6).tolist(), "options": options}))
 
 
 if __name__ == "__main__":
