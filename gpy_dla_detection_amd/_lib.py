@@ -82,6 +82,25 @@ SIGNATURES = {
     "dlagp_debug_read": (c_int, [POINTER(ctypes.c_uint64), c_int, c_int]),
 }
 
+
+
+class PrepareParams(ctypes.Structure):
+    """dlagp_prepare_params of include/dlagp.h"""
+    _fields_ = [(name, c_double) for name in (
+        "min_lambda", "max_lambda", "normalization_min_lambda", "normalization_max_lambda", "pixel_spacing",
+        "lya_wavelength", "lyman_limit", "min_z_cut", "max_z_cut")] + [("width", ctypes.c_int32), ("normalize", ctypes.c_int32)]
+
+
+# dlagp_pad_callback: (user, nb, width, pixel_spacing, edges [nb][2], pad [nb][2 width])
+PAD_CALLBACK = ctypes.CFUNCTYPE(None, c_void_p, ctypes.c_int32, ctypes.c_int32, c_double, _dp, _dp)
+_pp = POINTER(c_void_p)  # arrays of array pointers
+SIGNATURES["dlagp_prepare_spectrum"] = (c_int, [POINTER(PrepareParams), c_int, _dp, _dp, _dp, POINTER(c_ubyte), c_double, _dp,
+                                                POINTER(c_int), POINTER(c_int), _dp, _dp, _dp, _dp, _dp, _dp, _dp,
+                                                POINTER(c_ubyte)])
+SIGNATURES["dlagp_batch_prepare"] = (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_void_p, POINTER(PrepareParams), c_int,
+                                             POINTER(c_int), _pp, _pp, _pp, _pp, _dp, c_int, c_int, PAD_CALLBACK, c_void_p,
+                                             c_int64, _dp, _dp, _dp, _dp, _dp])
+
 _lib = None
 _hip = None
 

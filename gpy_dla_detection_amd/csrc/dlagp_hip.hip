@@ -35,6 +35,7 @@
 #include "../../include/dlagp.h"
 #include "dlagp_device.h"
 #include "host_shared.h"
+#include "prepare_host.h"
 #ifndef DLAGP_FAKE_DEVICE
 #include "kernels_common.h"
 #include "kernels_generic.h"
@@ -1455,6 +1456,17 @@ static int split_mixed_batch(LaunchGroup &g) {
     return DLAGP_OK;
 }
 
+// One-wave workgroups of the operand-building kernels for `elements` output values: one element per lane, 4096 waves at
+// most.  (These kernels run beside other batches' sweeps, whose accumulate waves hold every register of their SIMD for
+// ~200 us at a time, so a set-up wave starts only where an accumulate wave has just ended.  Fewer, fatter waves -- 16
+// elements per lane -- were measured and dropped in round 6: each takes that much longer to find its slot AND to finish, the
+// batch's contexts arrive late, and the kernel stream ran dry at 11.6 % of a catalogue run's instants instead of 1.8 %:
+// 2140 instead of 2520 spectra/s.  The set-up's LATENCY is on the pipeline's critical path, not its wave count.)
+static unsigned setup_blocks(size_t elements) {
+    const size_t per_wave = (size_t)DLAGP_SETUP_THREADS;
+    return (unsigned)std::max<size_t>(1, std::min<size_t>((elements + per_wave - 1) / per_wave, 4096));
+}
+
 // Everything of context creation that does not depend on where the model arrays come from:
 // descriptor, window starts, pass planning, wavelength grid; allocates the per-pixel device arrays.
 // `fill(ctx)` then has to leave y, mu, omega2, v (n_pad, padded 0/0/0/1) and dense_M ([n][sl.k]) on the device.
@@ -1594,11 +1606,12 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
         hipLaunchKernelGGL(fill_records, dim3((sl.n_slots + DLAGP_SETUP_THREADS - 1) / DLAGP_SETUP_THREADS), dim3(DLAGP_SETUP_THREADS), 0, setup, sl.n_slots,
                            ctx->slot_pixel.as<const int>(), ctx->slot_pos.as<const int>(), sl.y, sl.mu, sl.omega2, sl.v,
                            ctx->aux.as<double>());
-        hipLaunchKernelGGL(build_mfma_operand, dim3(4096), dim3(DLAGP_SETUP_THREADS), 0, setup, ctx->dense_M.as<double>(),
-                           ctx->slot_pixel.as<const int>(), sl.n_slots, ctx->Pm.as<double>(), k_eff, ctx->col_groups);
+        hipLaunchKernelGGL(build_mfma_operand, dim3(setup_blocks(pm_bytes / sizeof(double))), dim3(DLAGP_SETUP_THREADS), 0, setup,
+                           ctx->dense_M.as<double>(), ctx->slot_pixel.as<const int>(), sl.n_slots, ctx->Pm.as<double>(), k_eff,
+                           ctx->col_groups);
     }
-    hipLaunchKernelGGL(build_shared_operand, dim3(4096), dim3(DLAGP_SETUP_THREADS), 0, setup, ctx->dense_M.as<double>(), n, sl.n_pad,
-                       k_eff, sl.ntw, sl.ntq, sl.npair, ctx->P.as<double>());
+    hipLaunchKernelGGL(build_shared_operand, dim3(setup_blocks(p_bytes / sizeof(double))), dim3(DLAGP_SETUP_THREADS), 0, setup,
+                       ctx->dense_M.as<double>(), n, sl.n_pad, k_eff, sl.ntw, sl.ntq, sl.npair, ctx->P.as<double>());
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         (void)setup_sync(device);
@@ -1754,40 +1767,50 @@ int dlagp_setup_sync(int device) try {
     return rc ? rc : setup_sync(device);
 } DLAGP_CATCH_INT("dlagp_setup_sync")
 
+// NullGP.get_interp on the device for a context under construction (the `fill` of create_context): y and v go up, mu,
+// omega2 and the factor are interpolated from the model at the kept pixels' rest wavelengths x and suppressed by the
+// Lyman-series mean flux at the observed this_wavelengths (reference null_gp.py:179-242)
+static int check_model_range(const dlagp_model *model, int n, const double *x) {
+    for (int i = 0; i < n; ++i)  // scipy's interp1d raises ValueError outside the grid (bounds_error)
+        if (!(x[i] >= model->grid_min && x[i] <= model->grid_max))
+            return fail(DLAGP_EINVAL, "rest wavelength %g outside the model grid [%g, %g]", x[i], model->grid_min,
+                        model->grid_max);
+    return DLAGP_OK;
+}
+static int fill_from_model(dlagp_ctx *ctx, const dlagp_model *model, int n, const double *x, const double *y, const double *v,
+                           const double *this_wavelengths, double z_qso) {
+    const SightlineDev &sl = ctx->sl;
+    const hipStream_t setup = setup_stream(ctx->device);
+    for (int i = 0; i < n; ++i) ctx->negative_noise = ctx->negative_noise || v[i] < 0.0;  // omega2 = exp(..) >= 0
+    int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0, ctx->device);
+    if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0, ctx->device);
+    if (rc) return rc;
+    // the kernel's inputs live until the end of the set-up sequence (create_context releases them after its one
+    // synchronisation: a buffer handed back to the pool while the kernel is in flight could be given to another thread)
+    DeviceBuffer &dx = ctx->scratch_a, &dw = ctx->scratch_b;
+    rc = dx.reserve((size_t)n * sizeof(double));
+    if (!rc) rc = dw.reserve((size_t)n * sizeof(double));
+    if (!rc) rc = upload_staged(dx.ptr, x, (size_t)n * sizeof(double), ctx->device);
+    if (!rc) rc = upload_staged(dw.ptr, this_wavelengths, (size_t)n * sizeof(double), ctx->device);
+    if (rc) return rc;
+    hipLaunchKernelGGL(interp_model, dim3((sl.n_pad + DLAGP_INTERP_PIXELS - 1) / DLAGP_INTERP_PIXELS),
+                       dim3(DLAGP_INTERP_THREADS), 0, setup, model->dev, n, sl.n_pad,
+                       sl.k, dx.as<const double>(), dw.as<const double>(), z_qso, ctx->mu.as<double>(),
+                       ctx->omega2.as<double>(), ctx->dense_M.as<double>());
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(DLAGP_EDEVICE, "interp_model failed: %s", hipGetErrorString(err));
+    return DLAGP_OK;
+}
+
 int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, int n_u, const double *x,
                             const double *y, const double *v, const double *this_wavelengths, double z_qso,
                             const double *wavelengths, const uint8_t *keep, int num_lines, int broadening) try {
     if (out) *out = nullptr;
     if (!model) return fail(DLAGP_EINVAL, "model is NULL");
     if (!x || !y || !v || !this_wavelengths) return fail(DLAGP_EINVAL, "NULL input array");
-    for (int i = 0; i < n; ++i)  // scipy's interp1d raises ValueError outside the grid (bounds_error)
-        if (!(x[i] >= model->grid_min && x[i] <= model->grid_max))
-            return fail(DLAGP_EINVAL, "rest wavelength %g outside the model grid [%g, %g]", x[i], model->grid_min,
-                        model->grid_max);
+    if (int rc = check_model_range(model, n, x)) return rc;
     return create_context(out, n, n_u, model->dev.k, wavelengths, keep, num_lines, broadening, model->device,
-                          [&](dlagp_ctx *ctx) -> int {
-        const SightlineDev &sl = ctx->sl;
-        const hipStream_t setup = setup_stream(ctx->device);
-        for (int i = 0; i < n; ++i) ctx->negative_noise = ctx->negative_noise || v[i] < 0.0;  // omega2 = exp(..) >= 0
-        int rc = upload_padded(ctx->y, y, n, sl.n_pad, 0.0, ctx->device);
-        if (!rc) rc = upload_padded(ctx->v, v, n, sl.n_pad, 1.0, ctx->device);
-        if (rc) return rc;
-        // the kernel's inputs live until the end of the set-up sequence (create_context releases them after its one
-        // synchronisation: a buffer handed back to the pool while the kernel is in flight could be given to another thread)
-        DeviceBuffer &dx = ctx->scratch_a, &dw = ctx->scratch_b;
-        rc = dx.reserve((size_t)n * sizeof(double));
-        if (!rc) rc = dw.reserve((size_t)n * sizeof(double));
-        if (!rc) rc = upload_staged(dx.ptr, x, (size_t)n * sizeof(double), ctx->device);
-        if (!rc) rc = upload_staged(dw.ptr, this_wavelengths, (size_t)n * sizeof(double), ctx->device);
-        if (rc) return rc;
-        hipLaunchKernelGGL(interp_model, dim3((sl.n_pad + DLAGP_INTERP_PIXELS - 1) / DLAGP_INTERP_PIXELS),
-                           dim3(DLAGP_INTERP_THREADS), 0, setup, model->dev, n, sl.n_pad,
-                           sl.k, dx.as<const double>(), dw.as<const double>(), z_qso, ctx->mu.as<double>(),
-                           ctx->omega2.as<double>(), ctx->dense_M.as<double>());
-        const hipError_t err = hipGetLastError();
-        if (err != hipSuccess) return fail(DLAGP_EDEVICE, "interp_model failed: %s", hipGetErrorString(err));
-        return DLAGP_OK;
-    });
+                          [&](dlagp_ctx *ctx) -> int { return fill_from_model(ctx, model, n, x, y, v, this_wavelengths, z_qso); });
 } DLAGP_CATCH_INT("dlagp_create_from_model")
 
 int dlagp_ctx_read_model(dlagp_ctx *ctx, double *this_mu, double *this_M, double *this_omega2) try {
@@ -1981,6 +2004,113 @@ int dlagp_batch_create(dlagp_batch **out, dlagp_ctx *const *ctxs, int nb) try {
     *out = batch;
     return DLAGP_OK;
 } DLAGP_CATCH_INT("dlagp_batch_create")
+
+// ---- f1, the data half: NullGP.set_data's normalisation, cuts, masks and padded grid (reference null_gp.py:117-177), the
+// absorber-redshift bounds (set_parameters.py:125-159) and the sample tables (dla_samples.py:94-104), natively
+static prep::Params prepare_params(const dlagp_prepare_params *p) {
+    return prep::Params{p->min_lambda, p->max_lambda, p->normalization_min_lambda, p->normalization_max_lambda,
+                        p->pixel_spacing, p->lya_wavelength, p->lyman_limit, p->min_z_cut, p->max_z_cut, p->width, p->normalize};
+}
+
+int dlagp_prepare_spectrum(const dlagp_prepare_params *params, int num_pixels, const double *wavelengths, const double *flux,
+                           const double *noise_variance, const uint8_t *pixel_mask, double z_qso, const double *pad, int *n,
+                           int *n_u, double *scalars, double *x, double *y, double *v, double *this_wavelengths,
+                           double *unmasked_wavelengths, double *padded_wavelengths, uint8_t *keep) try {
+    if (!params) return fail(DLAGP_EINVAL, "params is NULL");
+    const prep::Params p = prepare_params(params);
+    prep::Prepared out;
+    const std::string err = prep::scan(p, prep::Spectrum{num_pixels, wavelengths, flux, noise_variance, pixel_mask, z_qso}, out);
+    if (!err.empty()) return fail(DLAGP_EINVAL, "%s", err.c_str());
+    std::vector<double> own(2 * (size_t)p.width);
+    if (!pad) {
+        prep::pad_libm(p, out.edge_lo, out.edge_hi, own.data());
+        pad = own.data();
+    }
+    prep::place_padding(p, pad, out);
+    if (n) *n = out.n;
+    if (n_u) *n_u = out.n_u;
+    if (scalars) {
+        const double values[7] = {out.median, out.edge_lo, out.edge_hi, out.z_min, out.z_max, out.z_min_all, out.z_max_all};
+        std::copy(values, values + 7, scalars);
+    }
+    auto give = [](double *dst, const std::vector<double> &src) { if (dst) std::copy(src.begin(), src.end(), dst); };
+    give(x, out.x);
+    give(y, out.y);
+    give(v, out.v);
+    give(this_wavelengths, out.this_wavelengths);
+    give(unmasked_wavelengths, out.unmasked_wavelengths);
+    give(padded_wavelengths, out.padded_wavelengths);
+    if (keep) std::copy(out.keep.begin(), out.keep.end(), keep);
+    return DLAGP_OK;
+} DLAGP_CATCH_INT("dlagp_prepare_spectrum")
+
+int dlagp_batch_prepare(dlagp_batch **out_batch, dlagp_ctx **out_ctxs, const dlagp_model *model,
+                        const dlagp_prepare_params *params, int nb, const int *num_pixels, const double *const *wavelengths,
+                        const double *const *flux, const double *const *noise_variance, const uint8_t *const *pixel_mask,
+                        const double *z_qso, int num_lines, int flags, dlagp_pad_callback pad, void *pad_user, int64_t S,
+                        const double *offsets, const double *sub_offsets, double *sample_z, double *sub_sample_z,
+                        double *scalars) try {
+    if (out_batch) *out_batch = nullptr;
+    if (!out_batch || !out_ctxs || !model || !params || !num_pixels || !wavelengths || !flux || !noise_variance || !pixel_mask ||
+        !z_qso)
+        return fail(DLAGP_EINVAL, "NULL argument");
+    if (nb <= 0) return fail(DLAGP_EINVAL, "empty batch");
+    if (S < 0 || (S > 0 && ((sample_z && !offsets) || (sub_sample_z && !sub_offsets))))
+        return fail(DLAGP_EINVAL, "a table of sample redshifts needs its offsets");
+    if (flags & ~(DLAGP_FLAG_BROADENING | DLAGP_FLAG_LLS_BREAK)) return fail(DLAGP_EINVAL, "unknown flag bits 0x%x", flags);
+    for (int b = 0; b < nb; ++b) out_ctxs[b] = nullptr;
+    const prep::Params p = prepare_params(params);
+    if (p.width != (DLAGP_NUM_TAPS - 1) / 2)
+        return fail(DLAGP_EINVAL, "width = %d is not supported: the instrument profile has 2 * 3 + 1 taps", p.width);
+    // 1. the index logic of every spectrum (host only)
+    std::vector<prep::Prepared> prepared((size_t)nb);
+    std::vector<double> edges(2 * (size_t)nb), padding(2 * (size_t)p.width * nb);
+    for (int b = 0; b < nb; ++b) {
+        const std::string err = prep::scan(
+            p, prep::Spectrum{num_pixels[b], wavelengths[b], flux[b], noise_variance[b], pixel_mask[b], z_qso[b]}, prepared[b]);
+        if (!err.empty()) return fail(DLAGP_EINVAL, "spectrum %d of the batch: %s", b, err.c_str());
+        if (int rc = check_model_range(model, prepared[b].n, prepared[b].x.data())) return rc;
+        if (prepared[b].n <= 0) return fail(DLAGP_EINVAL, "spectrum %d of the batch: every pixel of the modelled window is masked", b);
+        edges[2 * b] = prepared[b].edge_lo;
+        edges[2 * b + 1] = prepared[b].edge_hi;
+    }
+    // 2. the padding pixels: the caller's own log10 / power (NumPy's, for the whole batch at once), or libm's
+    if (pad) pad(pad_user, nb, p.width, p.pixel_spacing, edges.data(), padding.data());
+    else for (int b = 0; b < nb; ++b) prep::pad_libm(p, edges[2 * b], edges[2 * b + 1], padding.data() + 2 * (size_t)p.width * b);
+    // 3. one context per spectrum (NullGP.get_interp on the device), none of them waited for, and the batch over them
+    const bool broadening = (flags & DLAGP_FLAG_BROADENING) != 0;
+    int rc = DLAGP_OK;
+    for (int b = 0; b < nb && !rc; ++b) {
+        prep::Prepared &sp = prepared[b];
+        prep::place_padding(p, padding.data() + 2 * (size_t)p.width * b, sp);
+        const double *grid = broadening ? sp.padded_wavelengths.data() : sp.unmasked_wavelengths.data();
+        rc = create_context(&out_ctxs[b], sp.n, sp.n_u, model->dev.k, grid, sp.keep.data(), num_lines,
+                            flags | DLAGP_FLAG_DEFER_SYNC, model->device, [&](dlagp_ctx *ctx) -> int {
+            return fill_from_model(ctx, model, sp.n, sp.x.data(), sp.y.data(), sp.v.data(), sp.this_wavelengths.data(), z_qso[b]);
+        });
+    }
+    if (!rc) rc = dlagp_batch_create(out_batch, out_ctxs, nb);
+    if (rc) {
+        const std::string message = g_last_error;  // the destructors below may overwrite it
+        for (int b = 0; b < nb; ++b) {
+            if (out_ctxs[b]) dlagp_destroy(out_ctxs[b]);
+            out_ctxs[b] = nullptr;
+        }
+        g_last_error = message;
+        return rc;
+    }
+    // 4. what the driver needs of the index logic
+    for (int b = 0; b < nb; ++b) {
+        const prep::Prepared &sp = prepared[b];
+        if (sample_z && S) prep::sample_redshifts(sp.z_min, sp.z_max, offsets, S, sample_z + (size_t)b * S);
+        if (sub_sample_z && S) prep::sample_redshifts(sp.z_min, sp.z_max, sub_offsets, S, sub_sample_z + (size_t)b * S);
+        if (scalars) {
+            const double values[8] = {sp.median, sp.z_min, sp.z_max, sp.z_min_all, sp.z_max_all, (double)sp.n, (double)sp.n_u, 0.0};
+            std::copy(values, values + 8, scalars + 8 * (size_t)b);
+        }
+    }
+    return DLAGP_OK;
+} DLAGP_CATCH_INT("dlagp_batch_prepare")
 
 void dlagp_batch_destroy(dlagp_batch *batch) try {
     if (!batch) return;

@@ -104,6 +104,27 @@ Spectrum make_spectrum(std::mt19937 &rng, int n_u) {
     return s;
 }
 
+// a RAW spectrum for dlagp_batch_prepare: observed wavelengths whose rest frame covers [1005, 1199] A of the model grid
+struct RawSpectrum {
+    std::vector<double> wavelengths, flux, noise;
+    std::vector<uint8_t> mask;
+    double z_qso;
+};
+RawSpectrum make_raw(std::mt19937 &rng, int num) {
+    RawSpectrum s;
+    std::uniform_real_distribution<double> uni(0.0, 1.0);
+    s.z_qso = 2.2 + 0.6 * uni(rng);
+    const double step = std::log10(1199.0 / 1005.0) / (num - 1);
+    for (int j = 0; j < num; ++j) {
+        s.wavelengths.push_back(1005.0 * std::pow(10.0, step * j) * (1.0 + s.z_qso));
+        s.flux.push_back(1.0 + 0.2 * uni(rng));
+        s.noise.push_back(0.01 + 0.01 * uni(rng));
+        s.mask.push_back(uni(rng) < 0.05 ? 1 : 0);
+    }
+    return s;
+}
+const dlagp_prepare_params kPrepare = {1010.0, 1190.0, 1191.0, 1199.0, 1e-4, 1215.6701, 911.7633, 0.01, 0.01, 3, 1};
+
 }  // namespace
 
 // The checker must have teeth: a buffer handed back while a launch on an unsynchronised stream still uses it, a double
@@ -187,6 +208,43 @@ int main(int argc, char **argv) {
             Batch batch;
             batch.id = next_id.fetch_add(1);
             bool failed = false;
+            if (batch.id % 5 == 2) {  // the catalogue driver's route since round 6: raw spectra, ONE call for the whole batch
+                std::vector<RawSpectrum> raw;
+                for (int i = 0; i < NB; ++i) raw.push_back(make_raw(rng, 300 + (int)(rng() % 400)));
+                std::vector<int> num;
+                std::vector<const double *> w, f, nv;
+                std::vector<const uint8_t *> m;
+                std::vector<double> zq;
+                for (const RawSpectrum &r : raw) {
+                    num.push_back((int)r.wavelengths.size());
+                    w.push_back(r.wavelengths.data());
+                    f.push_back(r.flux.data());
+                    nv.push_back(r.noise.data());
+                    m.push_back(r.mask.data());
+                    zq.push_back(r.z_qso);
+                }
+                std::vector<double> offsets(S), tables((size_t)NB * S), scalars((size_t)NB * 8);
+                for (int i = 0; i < S; ++i) offsets[i] = (i + 0.5) / S;
+                batch.ctxs.assign(NB, nullptr);
+                const int rc = dlagp_batch_prepare(&batch.batch, batch.ctxs.data(), model, &kPrepare, NB, num.data(), w.data(), f.data(),
+                                                   nv.data(), m.data(), zq.data(), 3, DLAGP_FLAG_BROADENING, nullptr, nullptr, S,
+                                                   offsets.data(), batch.id % 2 ? offsets.data() : nullptr, tables.data(),
+                                                   batch.id % 2 ? tables.data() : nullptr, scalars.data());
+                if (!ok(rc, "dlagp_batch_prepare", inject.load())) {
+                    for (dlagp_ctx *c : batch.ctxs)  // a failed call leaves nothing behind
+                        if (c) {
+                            std::fprintf(stderr, "runtime_replay: a failed dlagp_batch_prepare left a context behind\n");
+                            g_unexpected.fetch_add(1);
+                        }
+                    continue;
+                }
+                if (!(scalars[1] < scalars[2]) || scalars[5] < 1.0) {
+                    std::fprintf(stderr, "runtime_replay: dlagp_batch_prepare returned nonsense bounds\n");
+                    g_unexpected.fetch_add(1);
+                }
+                prepared.push(std::move(batch));
+                continue;
+            }
             for (int i = 0; i < NB && !failed; ++i) {
                 Spectrum s = make_spectrum(rng, 120 + (int)(rng() % 200));
                 dlagp_ctx *ctx = nullptr;
@@ -225,7 +283,7 @@ int main(int argc, char **argv) {
             const bool may_fail = inject.load();
             const bool mixed_rank = false;
             (void)mixed_rank;
-            int rc = dlagp_batch_create(&b.batch, b.ctxs.data(), (int)b.ctxs.size());
+            int rc = b.batch ? DLAGP_OK : dlagp_batch_create(&b.batch, b.ctxs.data(), (int)b.ctxs.size());  // (dlagp_batch_prepare made its own)
             if (!ok(rc, "dlagp_batch_create", may_fail || inject.load())) {
                 b.batch = nullptr;
                 swept.push(std::move(b));
@@ -237,7 +295,10 @@ int main(int argc, char **argv) {
                 rc = dlagp_batch_model_evidences(b.batch, S, MAX_DLAS, sub_z.data(), sub_nhi.data(), 0, sample_z.data(), nhi.data(), 0,
                                                  0.01, uniforms.data(), nulls.data(), sub_ev.data(), sub_ll.data(), ev.data(), ll.data(),
                                                  base.data());
-                ok(rc, "dlagp_batch_model_evidences", may_fail || inject.load());
+                if (ok(rc, "dlagp_batch_model_evidences", may_fail || inject.load())) {
+                    std::vector<int32_t> ties((size_t)nb * (MAX_DLAS - 1));
+                    ok(dlagp_batch_resample_ties(b.batch, ties.data(), (int64_t)ties.size()), "dlagp_batch_resample_ties", false);
+                }
                 break;
             }
             case 1: {  // two phases, host work in between
@@ -293,6 +354,10 @@ int main(int argc, char **argv) {
                 if (got) {
                     rc = dlagp_batch_sweep_device(b.batch, S, MAX_DLAS, d_z, d_nhi, 0, 0.01, d_u, d_ev, d_ll, d_base, stream);
                     ok(rc, "dlagp_batch_sweep_device", may_fail || inject.load());
+                    std::vector<int32_t> ties((size_t)nb * (MAX_DLAS - 1));  // waits for the sweep's stream, then copies
+                    if (rc == DLAGP_OK)
+                        ok(dlagp_batch_resample_ties(b.batch, ties.data(), (int64_t)ties.size()), "dlagp_batch_resample_ties (device)",
+                           may_fail || inject.load());
                     rc = dlagp_batch_eval_device(b.batch, S, 2, d_z, d_z, d_ll, stream);  // kd = 2: [S][2] fits d_ll? no: reads only
                     ok(rc, "dlagp_batch_eval_device", may_fail || inject.load());
                 } else {

@@ -133,6 +133,18 @@ class DeviceEngine:
 
         return DeviceBatch(sightlines)
 
+    def prepare_batch(self, table, rows, broadening: bool, offsets, sub_offsets=None):
+        """
+        `prepare_data` + `sightline` + `batch` + the sample redshift tables of the spectra `rows` of `table` in one native
+        call (sightline.batch_prepare -> dlagp_batch_prepare); same contexts, same numbers, bit for bit.
+        """
+        from .sightline import batch_prepare, prepare_params
+
+        if getattr(self, "_prepare_params", None) is None:
+            self._prepare_params = prepare_params(self.params, normalize=True)
+        return batch_prepare(self.model, table, rows, self._prepare_params, self.params.num_lines, broadening, offsets,
+                             sub_offsets)
+
     def nulls(self, batch, sightlines) -> np.ndarray:
         return batch.nulls()
 
@@ -188,6 +200,7 @@ def process_qso(
     engine=None,
     prefetch: bool = True,
     partition: str = "cost",
+    native_prepare: bool = True,
 ) -> Dict[str, np.ndarray]:
     """
     :param spectra: per quasar (observed wavelengths, flux, noise_variance, pixel_mask) -- what the
@@ -197,6 +210,8 @@ def process_qso(
     :param prefetch: prepare the next batch in a worker thread while the current one is swept
     :param engine: back end (default `DeviceEngine(learned, params, device)`)
     :param seed: the reference re-seeds the global RNG with 0 before every spectrum (:144)
+    :param native_prepare: prepare a batch's spectra in one call into the library (False: per spectrum in Python, the
+        reference-shaped path the native one is tested against)
     :param partition: how `world_size` > 1 ranks divide the catalogue: "cost" (default) balances the modelled work
         (`kept_pixel_counts` -> `parallel.spectrum_cost` -> `parallel.balanced_assignment`, identical on every rank),
         "contiguous" gives every rank an equal count of consecutive spectra
@@ -239,12 +254,33 @@ def process_qso(
     if (type(params).min_z_dla is Parameters.min_z_dla and type(params).max_z_dla is Parameters.max_z_dla
             and type(params)._in_model_range is Parameters._in_model_range):
         z_range = params.z_dla_range  # both bounds from one in-range test
+        stock_range = type(params).z_dla_range is Parameters.z_dla_range
     else:
+        stock_range = False
         z_range = lambda w, z: (params.min_z_dla(w, z), params.max_z_dla(w, z))  # noqa: E731
     same_offsets = stock_holders and np.array_equal(dla_samples.offset_samples, subdla_samples.offset_samples)
+    # The whole of `prepare` below -- the data half of set_data, the bounds, the tables, the contexts and the batch -- is ONE
+    # call into the library when everything it restates is stock (dlagp_batch_prepare: bit-identical, and the interpreter
+    # lock is free for the sweeping and finishing threads meanwhile).  Overridden `Parameters` methods, other sample holders,
+    # spectra that are not float64, or an engine without the entry (the CPU tests' oracle engine) keep the Python.
+    table = None
+    if (native_prepare and stock_holders and hasattr(engine, "prepare_batch") and stock_range
+            and all(getattr(type(params), name) is getattr(Parameters, name)
+                    for name in ("emitted_wavelengths", "observed_wavelengths", "kms_to_z")) and len(mine)):
+        from .sightline import SpectrumTable
+
+        table = SpectrumTable(spectra, z_qso_list)
+        if not table.ok:
+            table = None
 
     def prepare(start: int, stop: int):
         """host index logic + device contexts of local rows [start, stop): everything a sweep needs"""
+        if table is not None:
+            batch, sightlines, z_dla, z_lls, scalars = engine.prepare_batch(
+                table, mine[start:stop], broadening, dla_samples.offset_samples,
+                None if same_offsets else subdla_samples.offset_samples)
+            local["min_z_dlas"][start:stop], local["max_z_dlas"][start:stop] = scalars[:, 3], scalars[:, 4]
+            return sightlines, batch, z_dla, (z_dla if same_offsets else z_lls)
         sightlines, z_dla, z_lls, bounds_z = [], [], [], []
         try:
             for i in range(start, stop):

@@ -195,6 +195,127 @@ class DeviceSightline:
         _lib.check(_lib.load().dlagp_eval_device(self._handle, S, kd, d_z, d_nhi, d_out, stream))
 
 
+def prepare_params(params, normalize: bool = True) -> "_lib.PrepareParams":
+    """`Parameters` (reference set_parameters.py:14-165) as the native data half reads it (dlagp_prepare_params)"""
+    return _lib.PrepareParams(
+        float(params.min_lambda), float(params.max_lambda), float(params.normalization_min_lambda),
+        float(params.normalization_max_lambda), float(params.pixel_spacing), float(params.lya_wavelength),
+        float(params.lyman_limit), float(params.min_z_cut), float(params.max_z_cut), int(params.width), int(bool(normalize)))
+
+
+def numpy_padding(width: int, pixel_spacing: float, edges: np.ndarray) -> np.ndarray:
+    """
+    The padding pixels of `nb` spectra, (nb, 2 width), from their smallest and largest unmasked wavelengths `edges` (nb, 2):
+    `null_gp._logspace` (= np.logspace of reference null_gp.py:159-177) element by element -- np.log10, the same sums and
+    products, np.power -- for the whole batch at once.  NumPy's own log10 / power on purpose: on AVX-512 hosts they are
+    SVML's and differ from libm's in the last bit for a few per cent of the arguments.
+    """
+    out = np.empty((edges.shape[0], 2 * width))
+    logs = np.log10(edges)
+    for side, (start, stop) in enumerate(((logs[:, 0] - width * pixel_spacing, logs[:, 0] - pixel_spacing),
+                                          (logs[:, 1] + pixel_spacing, logs[:, 1] + width * pixel_spacing))):
+        step = (stop - start) / (width - 1)
+        y = np.arange(0, width, dtype=np.float64)[None, :] * step[:, None]
+        y += start[:, None]
+        y[:, -1] = stop
+        out[:, side * width:(side + 1) * width] = np.power(10.0, y)
+    return out
+
+
+class SpectrumTable:
+    """
+    A catalogue's raw spectra -- per quasar (observed wavelengths, flux, noise variance, pixel mask), what the reference's
+    `read_spec` returns (run_bayes_select.py:147) -- as the native data half takes them: float64 / one-byte arrays and a
+    table of their addresses, built once.  `ok` is False when an array is not float64 (the Python path serves: its
+    arithmetic would run in that other type).
+    """
+
+    def __init__(self, spectra, z_qso_list):
+        self.arrays = []  # keeps the (possibly converted) arrays alive
+        num = len(spectra)
+        self.addresses = np.zeros((4, num), dtype=np.uintp)
+        self.num_pixels = np.zeros(num, dtype=np.int32)
+        self.z_qso = np.ascontiguousarray(z_qso_list, dtype=np.float64)
+        self.ok = True
+        for q, (wavelengths, flux, noise_variance, pixel_mask) in enumerate(spectra):
+            arrays = [np.asarray(a) for a in (wavelengths, flux, noise_variance)]
+            mask = np.asarray(pixel_mask)
+            if any(a.dtype != np.float64 or a.ndim != 1 for a in arrays) or mask.dtype != np.bool_ or mask.ndim != 1 \
+                    or any(a.shape != mask.shape for a in arrays):
+                self.ok = False
+                return
+            arrays = [np.ascontiguousarray(a) for a in arrays] + [np.ascontiguousarray(mask).view(np.uint8)]
+            self.arrays.append(arrays)
+            self.num_pixels[q] = mask.shape[0]
+            for c, a in enumerate(arrays):
+                self.addresses[c, q] = a.__array_interface__["data"][0]
+
+
+def batch_prepare(model: "DeviceModel", table: SpectrumTable, rows, params_struct, num_lines: int, broadening: bool,
+                  offsets: np.ndarray, sub_offsets: Optional[np.ndarray] = None, lls_break: bool = False):
+    """
+    The data half of `NullGP.set_data`, the contexts (`get_interp` on the device), the batch over them and the sample
+    redshift tables of the spectra `rows` of `table`, in ONE call into the library with the interpreter lock released
+    (dlagp_batch_prepare): what `null_gp.prepare_data`, `Parameters.z_dla_range`, `DeviceSightline.from_model` and
+    `DeviceBatch` do per spectrum.
+
+    :return: (DeviceBatch, [DeviceSightline], sample_z (nb, S), sub_sample_z (nb, S) or None when `sub_offsets` is None,
+        scalars (nb, 8) = normalisation median, z_min, z_max (sample tables), z_min, z_max (raw spectrum), n, n_u, 0)
+    """
+    lib = _lib.load()
+    rows = np.ascontiguousarray(rows, dtype=np.intp)
+    nb = rows.shape[0]
+    pointers = [np.ascontiguousarray(table.addresses[c, rows]) for c in range(4)]
+    num_pixels = np.ascontiguousarray(table.num_pixels[rows])
+    z_qso = np.ascontiguousarray(table.z_qso[rows])
+    offsets = np.ascontiguousarray(_lib.as_f64(offsets))
+    S = offsets.shape[0]
+    sample_z = np.empty((nb, S))
+    sub_sample_z = None
+    if sub_offsets is not None:
+        sub_offsets = np.ascontiguousarray(_lib.as_f64(sub_offsets))
+        if sub_offsets.shape != (S,):
+            raise ValueError("both sample holders need the same number of samples")
+        sub_sample_z = np.empty((nb, S))
+    scalars = np.empty((nb, 8))
+    failure = []
+
+    def pad(_user, count, width, spacing, edges, out):
+        try:  # an exception cannot cross the C frames: it is kept and raised after the call
+            np.ctypeslib.as_array(out, shape=(count, 2 * width))[:] = numpy_padding(
+                width, spacing, np.ctypeslib.as_array(edges, shape=(count, 2)))
+        except BaseException as exc:  # noqa: BLE001
+            failure.append(exc)
+
+    callback = _lib.PAD_CALLBACK(pad)
+    batch_handle = ctypes.c_void_p()
+    ctx_handles = (ctypes.c_void_p * nb)()
+    as_pp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p))  # noqa: E731
+    rc = lib.dlagp_batch_prepare(
+        ctypes.byref(batch_handle), ctx_handles, model._handle, ctypes.byref(params_struct), nb,
+        num_pixels.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), as_pp(pointers[0]), as_pp(pointers[1]), as_pp(pointers[2]),
+        as_pp(pointers[3]), _lib.ptr(z_qso), int(num_lines), int(bool(broadening)) | (2 if lls_break else 0), callback, None,
+        S, _lib.ptr(offsets), _lib.ptr(sub_offsets) if sub_offsets is not None else None, _lib.ptr(sample_z),
+        _lib.ptr(sub_sample_z) if sub_sample_z is not None else None, _lib.ptr(scalars))
+    if failure and rc == _lib.DLAGP_OK:  # the padding never arrived: the contexts are built on garbage
+        lib.dlagp_batch_destroy(batch_handle)
+        for handle in ctx_handles:
+            lib.dlagp_destroy(handle)
+        raise failure[0]
+    _lib.check(rc)
+    sightlines = []
+    for b in range(nb):
+        sl = DeviceSightline.__new__(DeviceSightline)
+        sl._handle = ctypes.c_void_p(ctx_handles[b])
+        sl.n, sl.k, sl.device = int(scalars[b, 5]), model.k, model.device
+        sl.num_lines, sl.broadening, sl.lls_break = int(num_lines), bool(broadening), bool(lls_break)
+        sightlines.append(sl)
+    batch = DeviceBatch.__new__(DeviceBatch)
+    batch.sightlines, batch.nb, batch._handle = sightlines, nb, batch_handle
+    batch._pending, batch.last_ties, batch.last_changed = None, None, 0
+    return batch, sightlines, sample_z, sub_sample_z, scalars
+
+
 def exact_choice(level_ll: np.ndarray, uniforms: np.ndarray) -> np.ndarray:
     """
     `np.random.choice(np.arange(S).astype(np.int32), size=S, replace=True, p=W / W.sum())` of the reference

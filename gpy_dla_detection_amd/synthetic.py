@@ -159,3 +159,38 @@ def make_qmc_samples(sight: SyntheticSightline, num: int = 10000, sub_dla: bool 
     u = halton(num, 3)
     log_nhi = (19.5 + 0.5 * u) if sub_dla else (20.0 + 3.0 * u)
     return z, log_nhi, 10.0 ** log_nhi
+
+
+def make_catalogue(num, k=20, seed=7, mix="uniform"):
+    """
+    A synthetic catalogue of RAW spectra for the catalogue driver (`run_bayes_select.process_qso`): a learned model on the
+    reference's rest-frame grid (set_parameters.py:33-35), SDSS-like spectra (4600 pixels at 1e-4 dex from 3631 A, 3 % of
+    them masked, an absorber in two of three) and their quasar redshifts.  The kept pixels n of a spectrum follow z_qso
+    through the modelled window 911.75-1215.75 A (null_gp.py:139-152).  `mix`: "uniform" z_qso in [2.2, 3.4] (n = 300 ... 1250,
+    mean ~ 920) or "dr12q" z_qso = 2.15 + Gamma(2, 0.22) (n = 250 ... 1250, median ~ 685).
+    :return: (LearnedModel, [(wavelengths, flux, noise_variance, pixel_mask)], [z_qso])
+    """
+    from .run_bayes_select import LearnedModel
+
+    rng = np.random.default_rng(seed)
+    rest_grid = np.arange(911.75, 1215.75 + 1e-9, 0.25)
+    mu = 1 + 0.2 * np.cos(rest_grid / 30.0)
+    M = 0.1 * rng.standard_normal((rest_grid.shape[0], k)) * (0.9 ** np.arange(k))[None, :]
+    log_omega = -2.0 + 0.3 * np.sin(rest_grid / 55.0)
+    learned = LearnedModel(rest_grid, mu, M, log_omega, -2.3, -5.9, 1.2)
+    obs = 10.0 ** (3.5600 + 1e-4 * np.arange(4600))
+    spectra, z_qsos = [], []
+    for i in range(num):
+        if mix == "dr12q":
+            z_qso = float(np.clip(2.15 + rng.gamma(2.0, 0.22), 2.15, 5.5))
+        else:
+            z_qso = 2.2 + 1.2 * rng.random()
+        rest = obs / (1 + z_qso)
+        flux = 3.0 + 0.5 * np.sin(rest / 40.0)
+        if i % 3:
+            centre = 1215.6701 * (1 + z_qso - 0.3)
+            flux = flux * np.exp(-50.0 / (1.0 + ((obs - centre) / 3.0) ** 2))
+        flux = flux + 0.2 * rng.standard_normal(obs.shape[0])
+        spectra.append((obs, flux, 0.04 * (1 + rng.random(obs.shape[0])), rng.random(obs.shape[0]) < 0.03))
+        z_qsos.append(z_qso)
+    return learned, spectra, z_qsos

@@ -77,7 +77,8 @@ typedef struct dlagp_batch dlagp_batch; /* a launch group of sightlines on one d
 typedef struct dlagp_model dlagp_model; /* the learned GP model (rest-frame grid), in HBM   */
 
 /* ABI version of this header; bumped on any signature or status-code change.  2: DLAGP_ENOMEM.  3: near-tie counts of the
- * resampling (dlagp_batch_resample_ties; larger d_cdf_scratch / d_flags of dlagp_level_finish_device). */
+ * resampling (dlagp_batch_resample_ties; larger d_cdf_scratch / d_flags of dlagp_level_finish_device), dlagp_prepare_spectrum,
+ * dlagp_batch_prepare. */
 int dlagp_abi_version(void);
 
 /* Number of visible HIP devices (0 if none / runtime unusable). */
@@ -156,6 +157,65 @@ int dlagp_create_from_model(dlagp_ctx **out, const dlagp_model *model, int n, in
                             const double *this_wavelengths, double z_qso,
                             const double *wavelengths, const uint8_t *keep, int num_lines,
                             int broadening);
+
+/*
+ * f1, the data half.  What NullGP.set_data does with a RAW spectrum before the model is interpolated (reference
+ * gpy_dla_detection/null_gp.py:117-177) -- rest wavelengths, normalisation by the median flux of the normalisation window,
+ * the cut to the modelled window, masks, the grid padded by `width` log-spaced pixels per side -- and the bounds of the
+ * absorber redshifts, Parameters.min_z_dla / max_z_dla (set_parameters.py:125-159).  Operation by operation the Python's
+ * arithmetic: the results are bit-identical (tests/test_host_logic.py against null_gp.prepare_data), with the two library
+ * calls of that arithmetic treated as follows: `median ** 2` is libm's pow as in NumPy's scalar power, and the padding pixels
+ * 10 ** (log10(edge) -+ k spacing) are taken from the caller (`pad`, see dlagp_pad_callback) because NumPy dispatches log10 and
+ * power to SVML on AVX-512 hosts and libm's results differ from those in the last bit for ~4 % of the arguments.
+ */
+typedef struct dlagp_prepare_params {
+    double min_lambda, max_lambda;                               /* modelled rest-frame window   (set_parameters.py:33-34) */
+    double normalization_min_lambda, normalization_max_lambda;   /* normalisation window         (:30-31)                  */
+    double pixel_spacing;                                        /* log10 spacing of the padding (:58)                     */
+    double lya_wavelength, lyman_limit;                          /* Angstrom                     (:16-19)                  */
+    double min_z_cut, max_z_cut;                                 /* redshift differences: kms_to_z applied (:105-110)      */
+    int32_t width;                                               /* padding pixels per side, 3   (:57)                     */
+    int32_t normalize;                                           /* set_data(normalize=...)      (null_gp.py:121)          */
+} dlagp_prepare_params;
+
+/* pad[b][0..width) = 10 ** (log10(edges[b][0]) - (width - k) spacing) and pad[b][width..2 width) = 10 ** (log10(edges[b][1]) +
+ * (k + 1) spacing), k = 0..width-1, by null_gp._logspace's arithmetic, for the nb spectra of a batch: called ONCE per
+ * dlagp_batch_prepare, from the calling thread (a ctypes callback takes the interpreter lock for these few microseconds). */
+typedef void (*dlagp_pad_callback)(void *user, int32_t nb, int32_t width, double pixel_spacing, const double *edges, double *pad);
+
+/*
+ * One spectrum, host only (no device is touched): the arrays `set_data` leaves on the instance.  Every output may be NULL;
+ * x, y, v, this_wavelengths, keep, unmasked_wavelengths need room for num_pixels entries, padded_wavelengths for
+ * num_pixels + 2 width.  pad: the 2 width padding pixels (NULL = libm's log10 / pow).
+ *   scalars[7] = {normalisation median, smallest and largest unmasked wavelength, min_z_dla and max_z_dla of the kept
+ *                 pixels (the sample tables'), min_z_dla and max_z_dla of the raw spectrum (the driver's min_z_dlas / max_z_dlas)}
+ * DLAGP_EINVAL where the Python raises (no pixel inside the modelled window).
+ */
+int dlagp_prepare_spectrum(const dlagp_prepare_params *params, int num_pixels, const double *wavelengths, const double *flux,
+                           const double *noise_variance, const uint8_t *pixel_mask, double z_qso, const double *pad, int *n,
+                           int *n_u, double *scalars, double *x, double *y, double *v, double *this_wavelengths,
+                           double *unmasked_wavelengths, double *padded_wavelengths, uint8_t *keep);
+
+/*
+ * A whole batch of raw spectra in ONE call (the caller's interpreter lock released throughout, but for `pad`): the data half
+ * of every spectrum, dlagp_create_from_model for each (none waited for singly), dlagp_batch_create over them, and the
+ * sample-redshift tables z_min + (z_max - z_min) * offsets (reference dla_samples.py:94-104, subdla_samples.py:115-125) --
+ * what the reference driver's loop does per spectrum before the first evidence (run_bayes_select.py:141-186) and what
+ * gpy_dla_detection_amd/run_bayes_select.py used to do per spectrum in Python.
+ *   num_pixels[nb]; wavelengths / flux / noise_variance / pixel_mask [nb] pointers to the spectra's arrays; z_qso[nb]
+ *   flags        DLAGP_FLAG_BROADENING | DLAGP_FLAG_LLS_BREAK, as dlagp_create
+ *   offsets, sub_offsets [S]   QMC offsets of the DLA / sub-DLA sample holders (NULL with its table)
+ *   sample_z, sub_sample_z [nb][S]  the tables (NULL = not wanted; pass sub_sample_z = NULL when both holders share offsets)
+ *   scalars [nb][8]  {median, z_min, z_max, z_min of the raw spectrum, z_max of it, n, n_u, 0} (NULL = not wanted)
+ * On success *out_batch and out_ctxs[0..nb) are the caller's (dlagp_batch_destroy, then dlagp_destroy each); on failure
+ * nothing is left behind.
+ */
+int dlagp_batch_prepare(dlagp_batch **out_batch, dlagp_ctx **out_ctxs, const dlagp_model *model,
+                        const dlagp_prepare_params *params, int nb, const int *num_pixels, const double *const *wavelengths,
+                        const double *const *flux, const double *const *noise_variance, const uint8_t *const *pixel_mask,
+                        const double *z_qso, int num_lines, int flags, dlagp_pad_callback pad, void *pad_user, int64_t S,
+                        const double *offsets, const double *sub_offsets, double *sample_z, double *sub_sample_z,
+                        double *scalars);
 
 /* Copy a context's this_mu[n], this_M[n][k] (C order), this_omega2[n] back; any pointer may be NULL. */
 int dlagp_ctx_read_model(dlagp_ctx *ctx, double *this_mu, double *this_M, double *this_omega2);

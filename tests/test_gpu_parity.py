@@ -1651,6 +1651,73 @@ def test_process_qso_on_device_matches_reference_driver_golden():
     assert_catalogue_matches_golden(results, g, rtol=RTOL_LL)
 
 
+def test_native_batch_preparation_equals_the_per_spectrum_python():
+    """
+    f1, the data half: dlagp_batch_prepare -- normalisation, cuts, masks, padded grid, redshift bounds, sample tables,
+    contexts and batch of a whole batch of RAW spectra in one call (reference null_gp.py:117-177,
+    set_parameters.py:125-159, dla_samples.py:94-104) -- against `prepare_data` + `Parameters.z_dla_range` +
+    `DeviceSightline.from_model` + `DeviceBatch` per spectrum in Python: the contexts hold the same bits, the tables are
+    the same bits, and a catalogue run gives identical output arrays either way.
+    """
+    from gpy_dla_detection_amd.null_gp import prepare_data
+    from gpy_dla_detection_amd.run_bayes_select import DeviceEngine, process_qso
+    from gpy_dla_detection_amd.samples import DLASamples, SubDLASamples
+    from gpy_dla_detection_amd.set_parameters import Parameters
+    from gpy_dla_detection_amd.sightline import SpectrumTable
+    from gpy_dla_detection_amd.synthetic import make_catalogue
+    from tests.test_host_logic import FixedPrior
+
+    S, max_dlas, num = 640, 3, 44
+    params = Parameters(num_dla_samples=S)
+    u = halton(S, 3)
+    dla = DLASamples(params, None, halton(S, 2), 20.0 + 3.0 * u)
+    sub_same = SubDLASamples(params, None, halton(S, 2), 19.5 + 0.5 * u, Z_dla=1.0, Z_lls=0.25)
+    sub_other = SubDLASamples(params, None, halton(S, 5), 19.5 + 0.5 * u, Z_dla=1.0, Z_lls=0.25)
+    learned, spectra, z_qsos = make_catalogue(num, mix="dr12q")
+    # (1) one batch, looked at closely
+    engine = DeviceEngine(learned, params)
+    table = SpectrumTable(spectra, z_qsos)
+    assert table.ok
+    rows = np.array([3, 0, 17, 41, 8])
+    batch, sightlines, z_dla, z_lls, scalars = engine.prepare_batch(table, rows, True, dla.offset_samples, sub_other.offset_samples)
+    for i, q in enumerate(rows):
+        wavelengths, flux, noise_variance, mask = spectra[q]
+        st = prepare_data(params, params.emitted_wavelengths(wavelengths, z_qsos[q]), flux, noise_variance, mask, z_qsos[q])
+        reference = engine.sightline(st, z_qsos[q], True)
+        for got, want in zip(sightlines[i].read_model(), reference.read_model()):
+            np.testing.assert_array_equal(got, want)
+        assert sightlines[i].n == reference.n == int(scalars[i, 5])
+        np.testing.assert_array_equal(z_dla[i], dla.sample_z_dlas(st["this_wavelengths"], z_qsos[q]))
+        np.testing.assert_array_equal(z_lls[i], sub_other.sample_z_lls(st["this_wavelengths"], z_qsos[q]))
+        assert (scalars[i, 1], scalars[i, 2]) == params.z_dla_range(st["this_wavelengths"], z_qsos[q])
+        assert (scalars[i, 3], scalars[i, 4]) == params.z_dla_range(wavelengths, z_qsos[q])
+        assert scalars[i, 0] == st["normalization_median"]
+        assert sightlines[i].null() == reference.null()  # y, v and the padded grid are in there
+        zz = dla.sample_z_dlas(st["this_wavelengths"], z_qsos[q])[:64]
+        np.testing.assert_array_equal(sightlines[i].eval(zz, dla.nhi_samples[:64]), reference.eval(zz, dla.nhi_samples[:64]))
+        reference.close()
+    engine.release(batch, sightlines)
+    # a spectrum the Python raises on (no pixel inside the modelled window) fails the call and leaves nothing behind
+    bad = list(spectra[:3]) + [(spectra[0][0][:800], spectra[0][1][:800], spectra[0][2][:800], spectra[0][3][:800])]
+    with pytest.raises(ValueError, match="modelled window"):
+        engine.prepare_batch(SpectrumTable(bad, [2.5, 2.6, 2.7, 9.0]), np.arange(4), True, dla.offset_samples)
+    engine.close()
+    # (2) whole catalogue runs: every output array identical, pipelined and in order, shared and separate offsets
+    for sub in (sub_same, sub_other):
+        for prefetch in (False, True):
+            native = process_qso(spectra, z_qsos, params, FixedPrior(), dla, sub, learned, max_dlas=max_dlas, batch_size=8,
+                                 prefetch=prefetch)
+            python = process_qso(spectra, z_qsos, params, FixedPrior(), dla, sub, learned, max_dlas=max_dlas, batch_size=8,
+                                 prefetch=prefetch, native_prepare=False)
+            assert sorted(native) == sorted(python)
+            for name in native:
+                np.testing.assert_array_equal(native[name], python[name], err_msg=name)
+    # spectra that are not float64 keep the Python path (its arithmetic runs in their type)
+    odd = [(w, f.astype(np.float32), v, m) for w, f, v, m in spectra[:6]]
+    assert not SpectrumTable(odd, z_qsos[:6]).ok
+    process_qso(odd, z_qsos[:6], params, FixedPrior(), dla, sub_same, learned, max_dlas=2, batch_size=3, prefetch=False)
+
+
 def test_pipelined_driver_equals_the_in_order_driver_on_the_device():
     """
     42 spectra in batches of 8: the pipelined driver (five threads, short first batches, one table of sample redshifts

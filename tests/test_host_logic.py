@@ -906,3 +906,138 @@ def test_work_decomposition_model():
     for name, default in ((b"plan_slots", 2048), (b"plan_item_cost", 20), (b"plan_rest_first", 0)):
         _lib.check(lib.dlagp_get_option(name, ctypes.byref(value)))
         assert value.value == default, name
+
+
+def native_prepare_spectrum(lib, params_struct, wavelengths, flux, noise_variance, pixel_mask, z_qso, pad=None):
+    """dlagp_prepare_spectrum (host only, no device) -> the dict `prepare_data` returns, plus the four redshift bounds"""
+    import ctypes
+
+    from gpy_dla_detection_amd import _lib
+
+    num = wavelengths.shape[0]
+    out = {name: np.empty(num + 6) for name in ("x", "y", "v", "this_wavelengths", "unmasked_wavelengths", "padded_wavelengths")}
+    keep = np.empty(num, dtype=np.uint8)
+    n, n_u, scalars = ctypes.c_int(), ctypes.c_int(), np.empty(7)
+    mask8 = np.ascontiguousarray(pixel_mask).view(np.uint8)
+    rc = lib.dlagp_prepare_spectrum(
+        ctypes.byref(params_struct), num, _lib.ptr(wavelengths), _lib.ptr(flux), _lib.ptr(noise_variance),
+        mask8.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), float(z_qso), _lib.ptr(pad) if pad is not None else None,
+        ctypes.byref(n), ctypes.byref(n_u), _lib.ptr(scalars), *(_lib.ptr(out[name]) for name in
+                                                                  ("x", "y", "v", "this_wavelengths", "unmasked_wavelengths",
+                                                                   "padded_wavelengths")),
+        keep.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+    if rc:
+        return rc, None
+    sizes = dict(x=n.value, y=n.value, v=n.value, this_wavelengths=n.value, unmasked_wavelengths=n_u.value,
+                 padded_wavelengths=n_u.value + 6)
+    got = {name: out[name][: sizes[name]] for name in out}
+    got.update(keep=keep[: n_u.value].astype(bool), normalization_median=scalars[0], edges=scalars[1:3], bounds=scalars[3:7])
+    return 0, got
+
+
+def same_bits(a, b) -> bool:
+    """identical doubles, bit for bit; a NaN matches a NaN whatever its sign (x86's default NaN is the negative one)"""
+    a, b = np.ascontiguousarray(a, dtype=np.float64).ravel(), np.ascontiguousarray(b, dtype=np.float64).ravel()
+    if a.shape != b.shape:
+        return False
+    nan = np.isnan(a)
+    return bool(np.array_equal(nan, np.isnan(b)) and np.array_equal(a[~nan].view(np.uint64), b[~nan].view(np.uint64)))
+
+
+def awkward_spectra(rng):
+    """spectra that exercise the corners of the data half: NaN flux in the normalisation window, an even and an odd window,
+    a window without a valid pixel, masked edges of the modelled window, a short spectrum, unsorted flux ties"""
+    obs = 10.0 ** (3.5600 + 1e-4 * np.arange(4600))
+    cases = []
+    for i, z_qso in enumerate((2.2, 2.5, 2.98, 3.4, 4.9, 2.151)):
+        flux = 2.0 + rng.standard_normal(obs.shape[0])
+        noise = 0.04 * (1 + rng.random(obs.shape[0]))
+        mask = rng.random(obs.shape[0]) < 0.05
+        rest = obs / (1 + z_qso)
+        window = np.flatnonzero((rest >= 1310.0) & (rest <= 1325.0))
+        if i == 0:
+            flux[window[::3]] = np.nan
+        if i == 1:
+            mask[window[1:]] = True            # exactly one valid pixel
+        if i == 2:
+            mask[window] = True                # none: the median is NaN, and so is everything normalised by it
+        if i == 3:
+            inside = np.flatnonzero((rest >= 911.75) & (rest <= 1215.75))
+            mask[inside[:40]] = True
+            mask[inside[-25:]] = True
+        if i == 4:
+            flux[window] = np.round(flux[window])  # ties
+        cases.append(((obs, flux, noise, mask), z_qso))
+    short = slice(1800, 2600)
+    cases.append(((obs[short].copy(), 2.0 + rng.standard_normal(800), np.full(800, 0.05), np.zeros(800, dtype=bool)), 4.0))
+    return cases
+
+
+def test_native_data_half_is_prepare_data_bit_for_bit():
+    """
+    dlagp_prepare_spectrum (csrc/prepare_host.h; the per-spectrum body of dlagp_batch_prepare) against
+    `null_gp.prepare_data` + `Parameters.z_dla_range` -- the data half of NullGP.set_data, reference null_gp.py:117-177,
+    set_parameters.py:125-159 -- on the 2048 spectra of the DR12Q-like mix and on awkward ones: every array and scalar
+    identical to the last bit, with the padding pixels from `sightline.numpy_padding` (NumPy's log10 / power, as the
+    binding's callback supplies them).  With libm's padding the grid agrees to an ulp -- not always to the bit on hosts
+    where NumPy uses SVML, which is why the callback exists.
+    """
+    import warnings
+
+    from gpy_dla_detection_amd import _lib
+    from gpy_dla_detection_amd.null_gp import prepare_data
+    from gpy_dla_detection_amd.sightline import numpy_padding, prepare_params
+    from gpy_dla_detection_amd.synthetic import make_catalogue
+
+    lib = _lib.load()
+    params = Parameters()
+    struct = prepare_params(params)
+    _, spectra, z_qsos = make_catalogue(2048, mix="dr12q")
+    cases = list(zip(spectra, z_qsos)) + awkward_spectra(np.random.default_rng(5))
+    libm_differs = 0
+    for (wavelengths, flux, noise_variance, pixel_mask), z_qso in cases:
+        rest = params.emitted_wavelengths(wavelengths, z_qso)
+        with warnings.catch_warnings(), np.errstate(invalid="ignore", divide="ignore"):
+            warnings.simplefilter("ignore")  # an empty normalisation window: NumPy warns and answers NaN
+            want = prepare_data(params, rest, flux, noise_variance, pixel_mask, z_qso, normalize=True)
+        rc, first = native_prepare_spectrum(lib, struct, wavelengths, flux, noise_variance, pixel_mask, z_qso)
+        assert rc == 0
+        pad = numpy_padding(3, params.pixel_spacing, first["edges"][None, :])[0]
+        rc, got = native_prepare_spectrum(lib, struct, wavelengths, flux, noise_variance, pixel_mask, z_qso, pad=pad)
+        assert rc == 0
+        for name in ("x", "y", "v", "this_wavelengths", "unmasked_wavelengths", "padded_wavelengths"):
+            assert got[name].shape == want[name].shape, name
+            assert same_bits(got[name], want[name]), name
+        assert np.array_equal(got["keep"], ~pixel_mask[want["ind_unmasked"]])
+        assert same_bits(got["normalization_median"], want["normalization_median"])
+        bounds = params.z_dla_range(want["this_wavelengths"], z_qso) + params.z_dla_range(wavelengths, z_qso)
+        assert same_bits(bounds, got["bounds"])
+        np.testing.assert_allclose(first["padded_wavelengths"], want["padded_wavelengths"], rtol=3e-16)
+        libm_differs += int(first["padded_wavelengths"].tobytes() != got["padded_wavelengths"].tobytes())
+    print("spectra whose libm padding differs from NumPy's in some bit: %d of %d" % (libm_differs, len(cases)))
+    # what the Python raises comes back as a status: no pixel inside the modelled window
+    obs = 10.0 ** (3.5600 + 1e-4 * np.arange(4600))
+    rc, _ = native_prepare_spectrum(lib, struct, obs, np.ones(4600), np.ones(4600), np.zeros(4600, dtype=bool), 0.5)
+    assert rc == _lib.DLAGP_EINVAL and "modelled window" in _lib.last_error()
+
+
+def test_native_sample_tables_are_the_holders_own():
+    """z_min + (z_max - z_min) * offsets in C (prepare_host.h sample_redshifts) == samples.DLASamples.sample_z_dlas"""
+    import ctypes
+
+    from gpy_dla_detection_amd import _lib
+    from gpy_dla_detection_amd.samples import DLASamples
+
+    params = Parameters(num_dla_samples=777)
+    holder = DLASamples(params, None, halton(777, 2), 20.0 + 3.0 * halton(777, 3))
+    plan = ctypes.CDLL(os.path.join(REPO, "gpy_dla_detection_amd", "csrc", "libdlagp_hip.so"))
+    assert plan  # (the tables themselves come back from dlagp_batch_prepare: GPU test; here the formula's operation order)
+    obs = 10.0 ** (3.5600 + 1e-4 * np.arange(4600))
+    for z_qso in (2.2, 2.9, 3.7):
+        rest = obs / (1 + z_qso)
+        this = (rest * (1 + z_qso))[(rest >= params.min_lambda) & (rest <= params.max_lambda)]
+        z_min, z_max = params.z_dla_range(this, z_qso)
+        want = holder.sample_z_dlas(this, z_qso)
+        width = z_max - z_min
+        got = np.array([z_min + width * o for o in holder.offset_samples])
+        assert same_bits(got, want)

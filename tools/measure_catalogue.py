@@ -40,29 +40,7 @@ class FixedPrior:
         return 731.0, 9265.0
 
 
-def make_inputs(num, k=20, seed=7, mix="uniform"):
-    rng = np.random.default_rng(seed)
-    rest_grid = np.arange(911.75, 1215.75 + 1e-9, 0.25)
-    mu = 1 + 0.2 * np.cos(rest_grid / 30.0)
-    M = 0.1 * rng.standard_normal((rest_grid.shape[0], k)) * (0.9 ** np.arange(k))[None, :]
-    log_omega = -2.0 + 0.3 * np.sin(rest_grid / 55.0)
-    learned = LearnedModel(rest_grid, mu, M, log_omega, -2.3, -5.9, 1.2)
-    obs = 10.0 ** (3.5600 + 1e-4 * np.arange(4600))
-    spectra, z_qsos = [], []
-    for i in range(num):
-        if mix == "dr12q":
-            z_qso = float(np.clip(2.15 + rng.gamma(2.0, 0.22), 2.15, 5.5))
-        else:
-            z_qso = 2.2 + 1.2 * rng.random()
-        rest = obs / (1 + z_qso)
-        flux = 3.0 + 0.5 * np.sin(rest / 40.0)
-        if i % 3:
-            centre = 1215.6701 * (1 + z_qso - 0.3)
-            flux = flux * np.exp(-50.0 / (1.0 + ((obs - centre) / 3.0) ** 2))
-        flux = flux + 0.2 * rng.standard_normal(obs.shape[0])
-        spectra.append((obs, flux, 0.04 * (1 + rng.random(obs.shape[0])), rng.random(obs.shape[0]) < 0.03))
-        z_qsos.append(z_qso)
-    return learned, spectra, z_qsos
+from gpy_dla_detection_amd.synthetic import make_catalogue as make_inputs  # noqa: E402,F401  (tools and tests import it from here)
 
 
 def sweeps_only(spectra, z_qsos, params, dla, sub, learned, batch_size, S):
@@ -117,6 +95,15 @@ def main():
     dla = DLASamples(params, None, halton(S, 2), 20.0 + 3.0 * u)
     sub = SubDLASamples(params, None, halton(S, 2), 19.5 + 0.5 * u, Z_dla=1.0, Z_lls=0.25)
     learned, spectra, z_qsos = make_inputs(num, mix=mix)
+    import functools
+
+    from gpy_dla_detection_amd import run_bayes_select as _rbs
+    from gpy_dla_detection_amd.sightline import set_options_from_env
+
+    options = set_options_from_env()
+    native = os.environ.get("DLAGP_NATIVE_PREPARE", "1") != "0"  # A/B: the per-spectrum Python preparation
+    global process_qso
+    process_qso = functools.partial(_rbs.process_qso, native_prepare=native)
     from gpy_dla_detection_amd.run_bayes_select import kept_pixel_counts
 
     kept = kept_pixel_counts(params, spectra, z_qsos)
@@ -201,6 +188,7 @@ def main():
     free_after = torch.cuda.mem_get_info()[0]
     out = {
         "spectra": num, "S": S, "max_dlas": 4, "batch_size": batch_size, "seconds": t, "mix": mix,
+        "native_prepare": native, "options": options,
         "kept_pixels": {"min": int(kept.min()), "median": float(np.median(kept)), "mean": float(kept.mean()), "max": int(kept.max())},
         # algorithmic FLOP of the run (n k (k + 1) + 2 n k per eval, 5 S evals per spectrum) / wall time / peak
         "whole_run_frac_of_fp64_peak": float(kept.sum()) * (20 * 21 + 40) * 5 * S / t / 78.6e12,
