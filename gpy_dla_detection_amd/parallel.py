@@ -104,7 +104,11 @@ def gather_rows(local_rows: np.ndarray, total_rows: int, group=None, device=None
     import torch
     import torch.distributed as dist
 
-    local_rows = np.ascontiguousarray(local_rows, dtype=np.float64)
+    # the rows travel in their own type: base indices as int32 (index data has no business in floating point), everything
+    # else as float64
+    local_rows = np.asarray(local_rows)
+    dtype = local_rows.dtype if local_rows.dtype in (np.int32, np.int64) else np.dtype(np.float64)
+    local_rows = np.ascontiguousarray(local_rows, dtype=dtype)
     if not (dist.is_available() and dist.is_initialized()):
         assert local_rows.shape[0] == total_rows
         if assignment is not None:
@@ -128,11 +132,14 @@ def gather_rows(local_rows: np.ndarray, total_rows: int, group=None, device=None
             device = torch.device("cuda", torch.cuda.current_device())
         else:
             device = torch.device("cpu")
-    send = torch.full((largest, m), float("nan"), dtype=torch.float64, device=device)
+    if dtype == np.float64:
+        send = torch.full((largest, m), float("nan"), dtype=torch.float64, device=device)
+    else:
+        send = torch.zeros((largest, m), dtype=torch.int32 if dtype == np.int32 else torch.int64, device=device)
     send[: local_rows.shape[0]] = torch.from_numpy(local_rows).to(device)
     recv = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(recv, send, group=group)
-    out = np.empty((total_rows, m), dtype=np.float64)
+    out = np.empty((total_rows, m), dtype=dtype)
     for r in range(world):
         idx = np.asarray(assignment[r])
         out[idx] = recv[r][: len(idx)].cpu().numpy()

@@ -16,7 +16,8 @@ comes back under the same dataset name and shape.  What differs is the execution
 Spectra arrive as arrays -- reading SDSS FITS files (`read_spec`, :147) is outside this package.
 Multi-GPU: `rank` / `world_size` shard the catalogue over one process per GPU, balanced by the spectra's kept pixels
 (`parallel.balanced_assignment`: a spectrum's work follows z_qso through the modelled window, null_gp.py:139-152);
-every rank returns the full arrays, in catalogue order, after one all-gather per output (`parallel.gather_rows`).
+every rank returns the per-quasar scalars and small vectors of the whole catalogue, in catalogue order, after ONE all-gather
+(`parallel.gather_rows`); the per-sample arrays stay rank-local (`gather_samples`, `write_results`, `merge_results`).
 """
 from collections import namedtuple
 import os
@@ -37,6 +38,10 @@ LearnedModel = namedtuple(
     "rest_wavelengths mu M log_omega log_c_0 log_tau_0 log_beta prev_tau_0 prev_beta",
     defaults=(0.0023, 3.65),
 )
+
+# ... of which these hold a row of S samples per quasar -- 80 KB x (2 max_dlas) per quasar at S = 10 000, 99.8 % of a run's
+# output -- and stay on the rank that computed them unless `gather_samples` asks otherwise (`process_qso`)
+PER_SAMPLE = ("sample_log_likelihoods_dla", "base_sample_inds", "sample_log_likelihoods_lls")
 
 # datasets of processed_qsos_multi_meanflux.h5 that hold one row per quasar (run_bayes_select.py:270-291)
 PER_QUASAR = (
@@ -201,6 +206,7 @@ def process_qso(
     prefetch: bool = True,
     partition: str = "cost",
     native_prepare: bool = True,
+    gather_samples: bool = False,
 ) -> Dict[str, np.ndarray]:
     """
     :param spectra: per quasar (observed wavelengths, flux, noise_variance, pixel_mask) -- what the
@@ -210,6 +216,10 @@ def process_qso(
     :param prefetch: prepare the next batch in a worker thread while the current one is swept
     :param engine: back end (default `DeviceEngine(learned, params, device)`)
     :param seed: the reference re-seeds the global RNG with 0 before every spectrum (:144)
+    :param gather_samples: with `world_size` > 1, all-gather the per-SAMPLE arrays (`PER_SAMPLE`) too, so that every rank
+        returns every array whole (the behaviour up to round 5; 320 KB per quasar on every rank).  Default: they stay with
+        the rank that computed them -- the result then carries `local_rows` (their catalogue indices), `rank` and
+        `world_size`, `write_results` writes them as a per-rank shard and `merge_results` puts a catalogue back together
     :param native_prepare: prepare a batch's spectra in one call into the library (False: per spectrum in Python, the
         reference-shaped path the native one is tested against)
     :param partition: how `world_size` > 1 ranks divide the catalogue: "cost" (default) balances the modelled work
@@ -460,13 +470,35 @@ def process_qso(
         engine.close()
 
     results = {}
-    for name in PER_QUASAR:
-        if world_size == 1:
+    if world_size == 1:
+        for name in PER_QUASAR:
             results[name] = local[name]  # no copy: the per-sample arrays are 80 KB x (2 max_dlas) per quasar
-            continue
-        rows = local[name].reshape(len(mine), int(np.prod(local[name].shape[1:])))
-        full = parallel.gather_rows(rows, num, group=group, assignment=assignment)
-        results[name] = full.reshape((num,) + local[name].shape[1:]).astype(local[name].dtype)
+    else:
+        # Every rank gets the per-quasar scalars and small vectors of the WHOLE catalogue -- priors, likelihoods, posteriors,
+        # MAP values, p_dlas: (12 + 4 max_dlas + 2 max_dlas^2) doubles = 480 B per quasar at max_dlas = 4 -- in ONE padded
+        # all-gather (RCCL over xGMI when the group is `nccl`).  The per-SAMPLE arrays are 320 KB per quasar: all-gathered they
+        # would put the whole catalogue's 100 GB (300 000 quasars) on every rank's host and, padded, world_size times that
+        # through device staging.  They stay rank-local (rows `local_rows`, written as per-rank shard files by
+        # `write_results` and reassembled by `merge_results`; the reference's own multi-job runs are merged from per-chunk
+        # files the same way, CDDF_analysis/sbatch_reunion.py:13-40) unless `gather_samples` restores the replicated form.
+        small = [name for name in PER_QUASAR if name not in PER_SAMPLE]
+        widths = [int(np.prod(local[name].shape[1:])) for name in small]
+        packed = np.concatenate([local[name].reshape(len(mine), w) for name, w in zip(small, widths)], axis=1)
+        full = parallel.gather_rows(packed, num, group=group, assignment=assignment)
+        at = 0
+        for name, w in zip(small, widths):
+            results[name] = np.ascontiguousarray(full[:, at:at + w]).reshape((num,) + local[name].shape[1:])
+            at += w
+        for name in PER_SAMPLE:
+            if gather_samples:
+                rows = local[name].reshape(len(mine), int(np.prod(local[name].shape[1:])))
+                full = parallel.gather_rows(rows, num, group=group, assignment=assignment)  # int32 rows travel as int32
+                results[name] = full.reshape((num,) + local[name].shape[1:])
+            else:
+                results[name] = local[name]
+        if not gather_samples:
+            results["local_rows"] = np.asarray(mine, dtype=np.int64)  # catalogue index of every row of the per-sample arrays
+            results["rank"], results["world_size"] = np.asarray(rank), np.asarray(world_size)
     # model settings and bookkeeping the reference stores next to the results (:250-268, :293-295)
     for name in ("prior_z_qso_increase", "k", "normalization_min_lambda", "normalization_max_lambda",
                  "min_z_cut", "max_z_cut", "num_dla_samples", "num_lines", "num_forest_lines"):
@@ -477,11 +509,7 @@ def process_qso(
     return results
 
 
-def write_results(results: Dict[str, np.ndarray], filename: str = "processed_qsos_multi_meanflux.h5") -> str:
-    """
-    Write `process_qso`'s output under the reference's dataset names (run_bayes_select.py:248-295):
-    HDF5 when h5py is installed, otherwise the same names in a NumPy .npz next to it.
-    """
+def _write_one(results: Dict[str, np.ndarray], filename: str) -> str:
     try:
         import h5py
     except ImportError:
@@ -495,3 +523,68 @@ def write_results(results: Dict[str, np.ndarray], filename: str = "processed_qso
             else:
                 f.create_dataset(name, data=value)
     return filename
+
+
+def shard_filename(filename: str, rank: int) -> str:
+    """`processed_qsos_multi_meanflux.h5` -> `processed_qsos_multi_meanflux.rank3.h5`"""
+    stem, dot, ext = filename.rpartition(".")
+    return "{}.rank{}.{}".format(stem, rank, ext) if dot else "{}.rank{}".format(filename, rank)
+
+
+def write_results(results: Dict[str, np.ndarray], filename: str = "processed_qsos_multi_meanflux.h5") -> str:
+    """
+    Write `process_qso`'s output under the reference's dataset names (run_bayes_select.py:248-295):
+    HDF5 when h5py is installed, otherwise the same names in a NumPy .npz next to it.
+
+    A result of a multi-rank run with rank-local per-sample arrays (`local_rows` present): every rank writes its shard
+    `<name>.rank<r>.<ext>` -- the per-sample arrays of its own quasars and `local_rows` -- and rank 0 also writes
+    `filename` with everything else (the whole catalogue's per-quasar values).  `merge_results` reads them back.
+    :return: the path this rank's main product went to (the shard, for ranks other than 0)
+    """
+    if "local_rows" not in results:
+        return _write_one(results, filename)
+    rank = int(results["rank"])
+    shard = {name: results[name] for name in PER_SAMPLE + ("local_rows", "rank", "world_size")}
+    written = _write_one(shard, shard_filename(filename, rank))
+    if rank == 0:
+        written = _write_one({name: value for name, value in results.items() if name not in PER_SAMPLE + ("local_rows", "rank")},
+                             filename)
+    return written
+
+
+def _read_one(filename: str) -> Dict[str, np.ndarray]:
+    if filename.endswith(".npz"):
+        with np.load(filename, allow_pickle=False) as f:
+            return {name: f[name] for name in f.files}
+    import h5py
+
+    with h5py.File(filename, "r") as f:
+        return {name: f[name][()] for name in f}
+
+
+def merge_results(main, shards) -> Dict[str, np.ndarray]:
+    """
+    One catalogue from the products of a multi-rank run: `main` = rank 0's main file (or its dict), `shards` = every
+    rank's shard (paths or dicts, any order).  Returns the dict a single-process run returns -- the reference's dataset
+    names, per-sample arrays whole and in catalogue order.  (Precedent: the reference merges the chunk files of its
+    multi-job runs, CDDF_analysis/sbatch_reunion.py:13-40.)  The per-sample arrays are assembled here, on ONE host, when
+    somebody wants them whole: 320 KB per quasar.
+    """
+    out = dict(main if isinstance(main, dict) else _read_one(main))
+    shards = [s if isinstance(s, dict) else _read_one(s) for s in shards]
+    num = out["z_qsos"].shape[0]
+    covered = np.zeros(num, dtype=bool)
+    for name in PER_SAMPLE:
+        first = shards[0][name]
+        out[name] = np.empty((num,) + first.shape[1:], dtype=first.dtype)
+    for shard in shards:
+        rows = np.asarray(shard["local_rows"], dtype=np.int64)
+        if covered[rows].any():
+            raise ValueError("two shards hold the same quasar")
+        covered[rows] = True
+        for name in PER_SAMPLE:
+            out[name][rows] = shard[name]
+    if not covered.all():
+        raise ValueError("the shards cover %d of %d quasars" % (int(covered.sum()), num))
+    out.pop("world_size", None)
+    return out

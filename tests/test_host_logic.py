@@ -283,12 +283,33 @@ out = parallel.model_evidences_sharded(sights, num_samples=24, max_dlas=2, rank=
                                        make_batch=lambda s, device: OracleBatch(s))
 np.save(os.path.join(os.environ["DLAGP_OUT"], "rank%d.npy" % rank), out)
 
-# the catalogue driver, 3 spectra over 2 ranks (2 + 1), every output all-gathered
-from gpy_dla_detection_amd.run_bayes_select import process_qso
+# the catalogue driver, 3 spectra over 2 ranks (2 + 1): the per-quasar values of the whole catalogue on every rank after
+# ONE all-gather, the per-sample arrays rank-local and written as shards; what every rank allocated and sent is recorded
+import json
+from gpy_dla_detection_amd import run_bayes_select as rbs
 from tests.test_host_logic import FixedPrior, OracleEngine, catalogue_inputs
 learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(96)
-res = process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=3,
-                  rank=rank, world_size=world, engine=OracleEngine(learned, params))
+record = {"gathers": [], "allocated": {}}
+plain_gather, plain_empty = parallel.gather_rows, rbs._empty_results
+def spying_gather(rows, total, **kw):
+    record["gathers"].append([int(np.asarray(rows).shape[0]), int(np.asarray(rows).shape[1]), str(np.asarray(rows).dtype)])
+    return plain_gather(rows, total, **kw)
+def spying_empty(num, S, max_dlas):
+    out = plain_empty(num, S, max_dlas)
+    record["allocated"] = {name: list(a.shape) for name, a in out.items()}
+    return out
+parallel.gather_rows, rbs._empty_results = spying_gather, spying_empty
+res = rbs.process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=3,
+                      rank=rank, world_size=world, engine=OracleEngine(learned, params))
+record["returned"] = {name: list(np.asarray(a).shape) for name, a in res.items()}
+json.dump(record, open(os.path.join(os.environ["DLAGP_OUT"], "catalogue_record%d.json" % rank), "w"))
+rbs.write_results(res, os.path.join(os.environ["DLAGP_OUT"], "catalogue.h5"))  # no h5py here: .npz, main file + shards
+# ... and with gather_samples every rank holds every array whole (the behaviour up to round 5; int32 rows travel as int32)
+record["gathers"] = []
+res = rbs.process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=3,
+                      rank=rank, world_size=world, engine=OracleEngine(learned, params), gather_samples=True)
+assert ["int32"] == sorted({g[2] for g in record["gathers"] if g[2] != "float64"}), record["gathers"]
+parallel.gather_rows, rbs._empty_results = plain_gather, plain_empty
 np.savez(os.path.join(os.environ["DLAGP_OUT"], "catalogue_rank%d.npz" % rank), **res)
 
 # ONE sightline, its samples split over the ranks: all-gather of S / world doubles per level, every rank resamples
@@ -360,6 +381,31 @@ def test_sharded_evidences_gloo_world_size_2(tmp_path, nproc):
         np.testing.assert_allclose(got["ev"], g5["dla_evidences"], rtol=1e-12)
         np.testing.assert_allclose(got["sll"], g5["dla_sample_ll"], rtol=1e-12, equal_nan=True)
     assert_catalogue_matches_golden(cat0, g_cat, rtol=1e-10)
+    # the default: per-sample arrays rank-local.  No rank allocates, returns or sends more than its share of them; the
+    # merged shards are the single-process result, array for array
+    import json
+
+    from gpy_dla_detection_amd import run_bayes_select as rbs
+
+    per_quasar = 12 + 4 * 3 + 2 * 3 * 3  # doubles per quasar of everything that is not per-sample, max_dlas = 3
+    shares = []
+    for r in range(nproc):
+        record = json.load(open(tmp_path / ("catalogue_record%d.json" % r)))
+        share = record["allocated"]["sample_log_likelihoods_dla"][0]
+        shares.append(share)
+        for name in rbs.PER_SAMPLE:
+            assert record["allocated"][name][0] == share and record["returned"][name][0] == share, (r, name)
+        assert record["returned"]["local_rows"] == [share] and record["returned"]["log_posteriors_dla"] == [3, 3]
+        assert record["gathers"] == [[share, per_quasar, "float64"]]  # ONE collective, 42 doubles per quasar
+    assert sum(shares) == 3 and max(shares) <= -(-3 // nproc) + 1
+    merged = rbs.merge_results(str(tmp_path / "catalogue.npz"),
+                               [str(tmp_path / ("catalogue.rank%d.npz" % r)) for r in range(nproc)])
+    assert sorted(merged) == sorted(cat0.files)
+    for name in cat0.files:
+        np.testing.assert_array_equal(merged[name], cat0[name], err_msg=name)
+        assert merged[name].dtype == cat0[name].dtype, name
+    with pytest.raises(ValueError, match="cover"):
+        rbs.merge_results(str(tmp_path / "catalogue.npz"), [str(tmp_path / "catalogue.rank0.npz")])
 
 
 # ------------------------------------------------------------------------------------------------
