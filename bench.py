@@ -65,18 +65,22 @@ def algorithmic_flops_per_eval(n: int, k: int) -> float:
     return float(n * k * (k + 1) + 2 * n * k)
 
 
-def measured_hbm_traffic(config: int):
+def measured_hbm_traffic(config: int, n: int, S: int, profiles_dir: str = None):
     """
     HBM bytes per accumulate-kernel launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, collected in
-    their own rocprofv3 runs of this same command, gfx950 read-side correction applied).  None when absent.
+    their own rocprofv3 runs of this same command, gfx950 read-side correction applied) -- only from a file that was
+    collected on THIS workload: same configuration, same kept pixels n, same sample count S (a file that does not say
+    counts for nothing).  (None, None) otherwise: a run on other pixels or samples has no measured traffic to report.
     """
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    profiles_dir = profiles_dir or os.path.join(REPO, "profiles")
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json",
+                 "r02_pmc_traffic.json"):
         try:
-            with open(os.path.join(REPO, "profiles", name)) as f:
+            with open(os.path.join(profiles_dir, name)) as f:
                 data = json.load(f)
-            if int(data.get("config", 2)) == config:
+            if (int(data["config"]), int(data["n"]), int(data["S"])) == (int(config), int(n), int(S)):
                 return float(data["hbm_bytes_per_launch"]), name
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, TypeError):
             pass
     return None, None
 
@@ -405,8 +409,8 @@ def gpu_local_cpus(index: int, sysfs: str = "/sys", visible=None):
     """
     CPUs of the NUMA node that GPU `index` of this process's device numbering hangs off, read from sysfs WITHOUT touching
     the GPU (a rank binds itself before its first HIP call): the KFD topology lists the compute nodes in the runtime's
-    enumeration order (`simd_count` > 0: a GPU; `drm_render_minor` names its DRM node), `HIP_VISIBLE_DEVICES` /
-    `ROCR_VISIBLE_DEVICES` (a list of ordinals) select and reorder them, and the DRM device's `local_cpulist` (or the
+    enumeration order (`simd_count` > 0: a GPU; `drm_render_minor` names its DRM node), `ROCR_VISIBLE_DEVICES` and then
+    `HIP_VISIBLE_DEVICES` (lists of ordinals; the second indexes into what the first left) select and reorder them, and the DRM device's `local_cpulist` (or the
     `cpulist` of its `numa_node`) gives the CPUs.  Returns (cpus, description); ([], why) when anything is missing --
     binding is an optimisation, never a requirement.
     """
@@ -427,13 +431,20 @@ def gpu_local_cpus(index: int, sysfs: str = "/sys", visible=None):
             continue
         if int(props.get("simd_count", "0") or 0) > 0 and "drm_render_minor" in props:
             gpus.append(int(props["drm_render_minor"]))
+    # The two lists COMPOSE: ROCR_VISIBLE_DEVICES filters and reorders what the HSA runtime enumerates, and
+    # HIP_VISIBLE_DEVICES then indexes into THAT.  Only lists of ordinals are understood: a UUID ("GPU-...") or anything
+    # else that is not an integer makes the answer "unknown" -- no binding -- rather than a guess.
     if visible is None:
-        visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or ""
-    if visible.strip():
+        lists = [os.environ.get("ROCR_VISIBLE_DEVICES", ""), os.environ.get("HIP_VISIBLE_DEVICES", "")]
+    else:
+        lists = [visible]
+    for which in lists:
+        if not which.strip():
+            continue
         try:
-            gpus = [gpus[int(tok)] for tok in visible.split(",") if tok.strip()]
+            gpus = [gpus[int(tok)] for tok in which.split(",") if tok.strip()]
         except (ValueError, IndexError):
-            return [], "cannot interpret the visible-devices list %r" % visible
+            return [], "cannot interpret the visible-devices list %r" % which
     if not 0 <= index < len(gpus):
         return [], "GPU %d not among the %d GPUs of the KFD topology" % (index, len(gpus))
     device = os.path.join(sysfs, "class", "drm", "renderD%d" % gpus[index], "device")
@@ -880,8 +891,12 @@ def main(argv=None) -> None:
             names = ["voigt", "conv", "mfma_loop", "epilogue", "passes+epilogue", None, "prologue"]
             print("stamps: waves=%d  " % st[5] + "  ".join("%s=%.0f" % (n, st[i] / st[5]) for i, n in enumerate(names) if n) + "  (cycles per wave)", file=sys.stderr)
 
+    rank_spread = None
     if env.dist_on:
-        elapsed = env.max_over_ranks([elapsed])[0]
+        # the slowest rank's time is the job's; the fastest rank's beside it shows an imbalance without a second run
+        slowest, minus_fastest = env.max_over_ranks([elapsed, -elapsed])
+        rank_spread = {"min": -minus_fastest / steps * 1e3, "max": slowest / steps * 1e3}
+        elapsed = slowest
         if not work.gathered_matches():
             raise SystemExit("rank %d: the gathered evidences differ from the local ones" % rank)
     evidence = float(work.evidences[0].item())
@@ -905,7 +920,10 @@ def main(argv=None) -> None:
         # timed accumulate launches of this rank: all MFMA-path launches of the step (config 4's null launch is the
         # generic kernel on one sample per sightline and is timed with them; its FLOPs are not counted)
         achieved = mfma_evals_per_step * steps * flops / kernel_s_total / 1e12 if kernel_s_total > 0 else 0.0
-        traffic, traffic_file = measured_hbm_traffic(config)
+        traffic, traffic_file = measured_hbm_traffic(config, n_pixels, S)
+        # the whole step against the same peak: everything between two steps' starts -- finalisation, level evidence,
+        # launch boundaries -- counts, which is what `value` corresponds to (`frac` is the dominant kernel alone)
+        step_achieved = mfma_evals_per_step * steps * flops / elapsed / 1e12
         line = {
             "metric": "QMC log-likelihood evals/sec",
             "value": value,
@@ -939,7 +957,9 @@ def main(argv=None) -> None:
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
                 "frac_cold": frac_cold,
-                "traffic": traffic if S == NUM_SAMPLES else None,
+                "step_achieved": step_achieved,
+                "step_frac": step_achieved / PEAK_FP64_MFMA_TFLOPS,
+                "traffic": traffic,
                 "traffic_unit": "HBM bytes per accumulate launch (PMC, profiles/%s)" % traffic_file if traffic_file else None,
                 "kernel": "accumulate_mfma (all instantiations launched in the timed region)",
                 "kernel_ms": kernel_ms / max(launches, 1),
@@ -948,6 +968,8 @@ def main(argv=None) -> None:
             },
             "evidence": evidence,
         }
+        if rank_spread is not None:
+            line["ms_per_step_ranks"] = rank_spread
         if binding is not None:
             line["cpu_binding_rank0"] = binding
         if others is not None:

@@ -125,6 +125,30 @@ static Option g_opt_path = 0;
 static Option g_opt_timing = 0;
 static Option g_opt_debug = 0;  // bit 1: stamped instantiation of the MFMA kernel (diagnostics)
 static Option g_opt_core_patch = 1;     // MFMA kernel: line cores repaired outside the sample loop when eligible
+static Option g_opt_fuse_finalize = 1;  // single-piece plans: the accumulate waves finish their own blocks (see fused_eligible)
+static Option g_opt_pair_models = 1;    // the sub-DLA sweep rides in level 1's launch of the DLA sweep (see pair_eligible)
+
+// The options that decide a call's launch SHAPES are read once per exported call and the call works from that snapshot:
+// another thread's dlagp_set_option in the middle of a sweep (tools and tests do that) can then neither make the levels of
+// one sweep disagree about its shape nor leave a two-phase call half started.  Nested scopes keep the outermost snapshot.
+struct CallOptions {
+    int64_t path, debug, core_patch, fuse_finalize, pair_models;
+};
+static CallOptions read_call_options() { return {g_opt_path, g_opt_debug, g_opt_core_patch, g_opt_fuse_finalize, g_opt_pair_models}; }
+static thread_local const CallOptions *t_call_options = nullptr;
+struct CallOptionsScope {
+    CallOptions snapshot;
+    bool mine;
+    CallOptionsScope() : snapshot(read_call_options()), mine(t_call_options == nullptr) {
+        if (mine) t_call_options = &snapshot;
+    }
+    ~CallOptionsScope() {
+        if (mine) t_call_options = nullptr;
+    }
+    CallOptionsScope(const CallOptionsScope &) = delete;
+    CallOptionsScope &operator=(const CallOptionsScope &) = delete;
+};
+static CallOptions call_options() { return t_call_options ? *t_call_options : read_call_options(); }
 static Option g_opt_profile_cache = 1;  // multi-level sweeps keep level-1 profiles in HBM (0 = recompute)
 // never more than this for the cache (MB), and never more than half of the free HBM
 static Option g_opt_profile_cache_max_mb = 196608;
@@ -594,7 +618,7 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
 // repaired once per wave; 2 several absorbers per sample, repaired pass by pass.  1 and 2 need three lines and a
 // log-uniform wavelength grid.
 static int patch_mode(const LaunchGroup &g, int kd) {
-    if (g.num_lines != 3 || !g.grid_uniform || g_opt_core_patch == 0 || kd < 1) return 0;
+    if (g.num_lines != 3 || !g.grid_uniform || call_options().core_patch == 0 || kd < 1) return 0;
     return kd == 1 ? 1 : 2;
 }
 
@@ -635,11 +659,11 @@ static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table
                 }
             }
             if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(3, BROADEN, false, 1, 1);
-            else if (g_opt_debug & 2) DLAGP_LAUNCH_MFMA(3, BROADEN, true, 0, 1);  // with per-phase cycle stamps
+            else if (call_options().debug & 2) DLAGP_LAUNCH_MFMA(3, BROADEN, true, 0, 1);  // with per-phase cycle stamps
             else DLAGP_LAUNCH_MFMA(3, BROADEN, false, 0, 1);
             return;
         }
-        if (patch == 2 && !(g_opt_debug & 2)) {  // several absorbers per sample, cores repaired pass by pass
+        if (patch == 2 && !(call_options().debug & 2)) {  // several absorbers per sample, cores repaired pass by pass
             if constexpr (BROADEN) {
                 if (fused_out) {
                     DLAGP_LAUNCH_MFMA(3, true, false, 0, 2, false, true);
@@ -651,7 +675,7 @@ static void launch_mfma(dim3 grid, hipStream_t stream, const SightlineDev *table
         }
     }
     if (src.cache_mode == 1) DLAGP_LAUNCH_MFMA(LINES, BROADEN, false, 1);  // level 1 of a cached sweep: also stores the profiles
-    else if (g_opt_debug & 2) DLAGP_LAUNCH_MFMA(LINES, BROADEN, true);     // diagnostic instantiation with per-phase cycle stamps
+    else if (call_options().debug & 2) DLAGP_LAUNCH_MFMA(LINES, BROADEN, true);     // diagnostic instantiation with per-phase cycle stamps
     else DLAGP_LAUNCH_MFMA(LINES, BROADEN, false);
 }
 
@@ -661,18 +685,17 @@ static bool mfma_path_serves(const LaunchGroup &g, int kd, bool cached = false) 
     // the MFMA kernel keeps its 16 samples' per-absorber constants in dynamic LDS
     const size_t mfma_prep_lds = (size_t)(DLAGP_MFMA_GROUP + 1) * std::max(kd, 1) * ((g.lls_break ? 5 : g.num_lines) + 1 + 2) * sizeof(double);
     if (g.lls_break && !cached && g.num_lines != 3) return false;  // the Lyman-limit term lives in the 3-line sample loop
-    return g.mfma_ok && kd >= 1 && mfma_prep_lds <= 40 * 1024 && g_opt_path != 1;
+    return g.mfma_ok && kd >= 1 && mfma_prep_lds <= 40 * 1024 && call_options().path != 1;
 }
 
 // Whether the accumulate waves of a launch finish their own blocks (kernels_mfma.h, FUSED): every block is ONE piece (the
 // plans of batches: more blocks than wave slots), rank 20, and the flavour is one of the production instantiations
 // that exist in that form -- 3 lines with broadening, no Lyman-limit term, the line cores repaired outside the sample
 // loop; the cached levels of a sweep.  Option "fuse_finalize" = 0 keeps the two-kernel form (the cross-check).
-static Option g_opt_fuse_finalize = 1;
 static Option g_last_launch_fused = 0;
 static bool fused_eligible(const LaunchGroup &g, const LaunchPlan *plan, int patch, int cache_mode) {
-    if (!g_opt_fuse_finalize || !plan || plan->max_parts != 1 || g.col_groups != 1 || g.k != DLAGP_FIN_K) return false;
-    if (g_opt_debug & 2) return false;  // the stamped diagnostic instantiation is unfused
+    if (!call_options().fuse_finalize || !plan || plan->max_parts != 1 || g.col_groups != 1 || g.k != DLAGP_FIN_K) return false;
+    if (call_options().debug & 2) return false;  // the stamped diagnostic instantiation is unfused
     if (cache_mode == 2) return true;
     return g.num_lines == 3 && g.broadening && !g.lls_break && (patch == 1 || (patch == 2 && cache_mode == 0));
 }
@@ -681,11 +704,10 @@ static bool fused_eligible(const LaunchGroup &g, const LaunchPlan *plan, int pat
 // virtual samples when both models sample the same redshifts.  Needs the one-absorber production kernel (3 lines,
 // broadening, cores repaired once per wave, rank 20, a homogeneous batch); finished by the waves themselves on single-piece
 // plans and by finalize_rank20 otherwise.  Option "pair_models" = 0 keeps the two launches (the cross-check).
-static Option g_opt_pair_models = 1;
 static Option g_last_sweep_paired = 0;
 static int64_t pair_virtual_samples(int64_t S) { return 16 * ((S + 7) / 8); }
 static bool pair_eligible(LaunchGroup &g, int64_t S) {
-    if (!g_opt_pair_models || !g.parts.empty() || (g_opt_debug & 2)) return false;
+    if (!call_options().pair_models || !g.parts.empty() || (call_options().debug & 2)) return false;
     return mfma_path_serves(g, 1) && patch_mode(g, 1) == 1 && g.broadening && !g.lls_break && g.col_groups == 1 &&
            g.k == DLAGP_FIN_K && S >= 1;
 }
@@ -710,6 +732,7 @@ static void launch_finalize_general(hipStream_t stream, const double *part, int 
 // must not clear it (an earlier part of the same level may have raised it).
 static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src, double *d_out, hipStream_t stream,
                       int *status_shared = nullptr, bool keep_status = false, double *d_out2 = nullptr) {
+    CallOptionsScope options_of_this_call;
     if (S <= 0) return DLAGP_OK;
     Workspace &ws = g.ws;
     const int nb = (int)g.ctxs.size();
@@ -719,7 +742,7 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
     if ((rc = enter_stream(g, stream))) return rc;
 
     bool use_mfma = mfma_path_serves(g, kd, src.cache_mode == 2);
-    if (g_opt_path == 2 && kd >= 1 && !use_mfma)
+    if (call_options().path == 2 && kd >= 1 && !use_mfma)
         return fail(DLAGP_EINVAL, "MFMA path requested but this group is not eligible (negative noise variance, mixed line counts / broadening / Lyman-limit flags, or kd x lines too large)");
     if (!use_mfma && src.cache_mode)
         return fail(DLAGP_EINVAL, "internal: the profile cache is only served by the MFMA path");
@@ -737,7 +760,7 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
     // single-piece plans: the accumulate waves finish their own blocks, no partial sums cross HBM (and none are allocated)
     const bool fused = use_mfma && fused_eligible(g, plan, patch, src.cache_mode);
     if (src.pair_S && !(use_mfma && patch == 1 && d_out2 && kd == 1 && g.num_lines == 3 && g.broadening && !g.lls_break &&
-                        g.col_groups == 1 && g.k == DLAGP_FIN_K && !(g_opt_debug & 2)))
+                        g.col_groups == 1 && g.k == DLAGP_FIN_K && !(call_options().debug & 2)))
         return fail(DLAGP_EINVAL, "internal: a pair launch needs the one-absorber 3-line MFMA kernel (see pair_eligible)");
     const size_t part_bytes = fused ? 0
                               : grouped ? (size_t)g.col_groups * nparts * nblocks * DLAGP_MFMA_ROW_WIDTH * 16 * sizeof(double)
@@ -774,8 +797,11 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
     // kernel as two commands: another thread's kernel that slips in between is counted into this launch's interval
     // (three threads: the sum of the intervals came out 14 % above the wall time's share, profiles/r05_experiments.txt
     // item 23).  While timing is on, launches therefore enqueue one at a time.
-    static std::mutex timing_order;
-    std::unique_lock<std::mutex> one_at_a_time(timing_order, std::defer_lock);
+    // (one lock per device: launches on different devices never share a stream.  The timed catalogue figures of
+    // profiles/r05_catalogue_pipeline*.json and r06_* were therefore taken with a batch's launches enqueued strictly one
+    // after the other -- a slightly different enqueue order than production's, which takes no lock.)
+    static std::mutex timing_order[16];
+    std::unique_lock<std::mutex> one_at_a_time(timing_order[(unsigned)g.device % 16], std::defer_lock);
     if (timing) one_at_a_time.lock();
 
     int *status = status_shared ? status_shared : ws.status.as<int>();
@@ -860,6 +886,7 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
 // on the same stream, all raising the one non-PD flag of `g`.
 static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &src, double *d_out,
                         hipStream_t stream) {
+    CallOptionsScope options_of_this_call;
     g_last_launch_groups = g.parts.empty() ? 1 : (int64_t)g.parts.size();
     int rc = enter_stream(g, stream);
     if (rc) return rc;
@@ -944,17 +971,23 @@ static hipStream_t work_stream(int device) {
     return s;
 }
 
+static std::mutex g_shared_stream_mutex;
+static std::map<int, hipStream_t> g_shared_streams;  // the one kernel stream per device (option shared_work_stream)
 static hipStream_t compute_stream(int device) {
     if (!g_opt_shared_work_stream) return work_stream(device);
-    static std::mutex mutex;
-    static std::map<int, hipStream_t> streams;
-    std::lock_guard<std::mutex> lock(mutex);
-    auto it = streams.find(device);
-    if (it != streams.end()) return it->second;
+    std::lock_guard<std::mutex> lock(g_shared_stream_mutex);
+    auto it = g_shared_streams.find(device);
+    if (it != g_shared_streams.end()) return it->second;
     hipStream_t s = nullptr;
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
-    streams[device] = s;
+    g_shared_streams[device] = s;
     return s;
+}
+// ... without creating it: nullptr when no call has launched on the device yet
+static hipStream_t shared_stream_if_any(int device) {
+    std::lock_guard<std::mutex> lock(g_shared_stream_mutex);
+    auto it = g_shared_streams.find(device);
+    return it != g_shared_streams.end() ? it->second : nullptr;
 }
 
 // the calling thread's pair of events that order its transfer stream against the kernel stream within one call.  Like the
@@ -1173,6 +1206,7 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
                         int64_t nhi_stride, double min_z_separation, const double *d_uniforms, double *d_evidences,
                         double *d_sample_ll, int *d_base, hipStream_t stream, bool keep_sticky_flag = false,
                         const PairSpec *pair = nullptr, int phase = SWEEP_ALL, int *cache_decision = nullptr) {
+    CallOptionsScope options_of_this_call;
     Workspace &ws = g.ws;
     const int nb = (int)g.ctxs.size();
     const size_t rows = (size_t)nb * S;
@@ -2204,6 +2238,7 @@ int dlagp_batch_sweep_device(dlagp_batch *batch, int64_t S, int max_dlas, const 
                              const double *d_sample_nhi, int64_t nhi_stride, double min_z_separation,
                              const double *d_uniforms, double *d_evidences, double *d_sample_ll, int32_t *d_base_inds,
                              void *stream) try {
+    CallOptionsScope options_of_this_call;  // one reading of the launch-shaping options for the whole call
     int rc = check_sweep_args(batch, S, max_dlas, d_sample_z, d_sample_nhi, nhi_stride, d_uniforms, d_evidences);
     if (rc) return rc;
     if (!d_sample_ll || (max_dlas > 1 && !d_base_inds))
@@ -2220,6 +2255,7 @@ int dlagp_batch_two_model_sweep_device(dlagp_batch *batch, int64_t S, int max_dl
                                        int64_t nhi_stride, double min_z_separation, const double *d_uniforms,
                                        double *d_sub_evidences, double *d_sub_sample_ll, double *d_evidences,
                                        double *d_sample_ll, int32_t *d_base_inds, void *stream_) try {
+    CallOptionsScope options_of_this_call;  // one reading of the launch-shaping options for the whole call
     int rc = check_sweep_args(batch, S, max_dlas, d_sample_z, d_sample_nhi, nhi_stride, d_uniforms, d_evidences);
     if (rc) return rc;
     if ((rc = check_sweep_args(batch, S, 1, d_sample_z, d_sub_nhi, sub_nhi_stride, nullptr, d_sub_evidences))) return rc;
@@ -2247,6 +2283,7 @@ int dlagp_batch_two_model_sweep_device(dlagp_batch *batch, int64_t S, int max_dl
 int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double *sample_z, const double *sample_nhi,
                       int64_t nhi_stride, double min_z_separation, const double *uniforms, double *evidences,
                       double *sample_ll, int32_t *base_inds) try {
+    CallOptionsScope options_of_this_call;  // one reading of the launch-shaping options for the whole call
     int rc = check_sweep_args(batch, S, max_dlas, sample_z, sample_nhi, nhi_stride, uniforms, evidences);
     if (rc) return rc;
     cancel_pending(batch);
@@ -2295,6 +2332,7 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
 int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dlas, const double *sub_sample_z,
                                       const double *sub_sample_nhi, int64_t sub_nhi_stride, const double *sample_z,
                                       const double *sample_nhi, int64_t nhi_stride, double min_z_separation) try {
+    CallOptionsScope options_of_this_call;  // one reading of the launch-shaping options for the whole call
     double dummy = 0.0;  // check_sweep_args wants the output arrays of the one-call form: they come with _finish
     int rc = check_sweep_args(batch, S, max_dlas, sample_z, sample_nhi, nhi_stride, max_dlas > 1 ? &dummy : nullptr, &dummy);
     if (rc) return rc;
@@ -2365,6 +2403,7 @@ int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dla
 int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniforms, double *null_evidences,
                                        double *sub_evidences, double *sub_sample_ll, double *evidences, double *sample_ll,
                                        int32_t *base_inds) try {
+    CallOptionsScope options_of_this_call;  // one reading of the launch-shaping options for the whole call
     int rc = batch_alive(batch);
     if (rc) return rc;
     if (!batch->pending.active) return fail(DLAGP_EINVAL, "dlagp_batch_model_evidences_finish without a matching _start");
@@ -2679,9 +2718,16 @@ int dlagp_get_option(const char *name, int64_t *value) try {
     else if (!strcmp(name, "work_stream_idle")) {
         // diagnostics (tools/measure_catalogue.py, DLAGP_POLL_IDLE): 1 when the current device's shared kernel stream has
         // nothing queued or running -- polled from a side thread it says how often the host leaves the device without work
+        // (asks without side effects: no stream is created for the question, and the "not ready" answer of a busy stream is
+        // not left behind as the polling thread's last HIP error)
         int device = 0;
         HIP_TRY(hipGetDevice(&device));
-        *value = g_opt_shared_work_stream && hipStreamQuery(compute_stream(device)) == hipSuccess;
+        hipStream_t shared = shared_stream_if_any(device);
+        if (!g_opt_shared_work_stream || !shared) *value = 0;
+        else {
+            *value = hipStreamQuery(shared) == hipSuccess;
+            (void)hipGetLastError();
+        }
     }
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
     return DLAGP_OK;

@@ -389,9 +389,15 @@ def process_qso(
     # `prefetch=False` -- and seed=None, whose draws come from the global RNG in catalogue order -- runs everything in
     # this thread, in order.
     bounds = [(start, min(start + batch_size, len(mine))) for start in range(0, len(mine), batch_size)]
-    if prefetch and seed is not None and len(mine) > 3 * batch_size >= 12:
-        # the device waits while the first batch is prepared: the pipeline starts on a quarter and a half batch (a
-        # spectrum's results do not depend on the batch it rides in)
+    # A spectrum's numbers do not depend on the batch it rides in AS LONG AS the batch's launches are single-piece (more
+    # blocks of 16 samples than the planner's 2048 wave slots: one wave then takes a block from the first pixel to the
+    # log-likelihood).  A batch of a few spectra, or of few samples, is cut into pieces and its sums round differently
+    # (~1e-13; exactly-settled base indices can then differ where the likelihoods do): so the short first batches are used
+    # only where a quarter batch is still single-piece -- nb ceil(S / 8) virtual blocks in a pair launch -- and a short LAST
+    # batch agrees with its spectra's results in any other batch to rounding, not to the bit.
+    single_piece = (batch_size // 4) * -(-S // 8) > 2048
+    if prefetch and seed is not None and len(mine) > 3 * batch_size >= 12 and single_piece:
+        # the device waits while the first batch is prepared: the pipeline starts on a quarter and a half batch
         ramp = (batch_size // 4, batch_size // 4 + batch_size // 2)
         bounds = [(0, ramp[0]), ramp] + [(start, min(start + batch_size, len(mine)))
                                          for start in range(ramp[1], len(mine), batch_size)]

@@ -132,6 +132,16 @@ def test_bind_reads_the_gpus_numa_cpus_from_sysfs_without_touching_the_gpu(bench
     assert bench.gpu_local_cpus(0, str(root), visible="3,0")[0] == [4, 5, 6, 7, 12]  # the visible list reorders
     assert bench.gpu_local_cpus(4, str(root), visible="")[0] == []                    # not that many GPUs
     assert bench.gpu_local_cpus(0, str(tmp_path / "nothing"))[0] == []                # no topology: no binding, no error
+    # both lists set: they COMPOSE -- ROCR_VISIBLE_DEVICES filters first, HIP_VISIBLE_DEVICES indexes into the result
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "2,3,0")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    assert bench.gpu_local_cpus(0, str(root))[0] == [0, 1, 2, 3]        # HIP 0 -> ROCR entry 2 -> GPU 0 (socket 0)
+    assert bench.gpu_local_cpus(1, str(root))[0] == [4, 5, 6, 7, 12]    # HIP 1 -> ROCR entry 0 -> GPU 2 (socket 1)
+    assert bench.gpu_local_cpus(2, str(root))[0] == []
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "GPU-0123456789abcdef")  # a UUID list: unknown, so no binding, not a guess
+    cpus, why = bench.gpu_local_cpus(0, str(root))
+    assert cpus == [] and "cannot interpret" in why
+    assert not bench.bind_to_gpu_numa_node(0, str(root))["bound"]
     # the binding itself: only CPUs this process may use, and nothing at all when there are none
     pinned = []
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {0, 1, 5, 6})
@@ -143,6 +153,17 @@ def test_bind_reads_the_gpus_numa_cpus_from_sysfs_without_touching_the_gpu(bench
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: {20, 21})
     assert not bench.bind_to_gpu_numa_node(0, str(root))["bound"] and pinned == [[5, 6]]
     assert "torch" not in sys.modules or True  # (the functions import nothing: sysfs reads only)
+
+
+def test_measured_traffic_belongs_to_the_workload_it_was_measured_on(bench, tmp_path):
+    """`roofline.traffic`: only from a PMC file collected on the run's configuration, kept pixels AND sample count"""
+    import json
+
+    (tmp_path / "r06_pmc_traffic.json").write_text(json.dumps({"config": 2, "n": 3000, "S": 10000, "hbm_bytes_per_launch": 1.5e6}))
+    (tmp_path / "r05_pmc_traffic.json").write_text(json.dumps({"config": 2, "hbm_bytes_per_launch": 9e9}))  # says no n, no S
+    assert bench.measured_hbm_traffic(2, 3000, 10000, str(tmp_path)) == (1.5e6, "r06_pmc_traffic.json")
+    for other in ((2, 671, 10000), (2, 3000, 5000), (3, 3000, 10000)):
+        assert bench.measured_hbm_traffic(*other, str(tmp_path)) == (None, None)
 
 
 def test_design_tables_render_from_the_committed_profiles():

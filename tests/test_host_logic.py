@@ -650,12 +650,13 @@ def test_batch_bookkeeping_is_the_per_spectrum_loop():
 
 def test_pipeline_starts_on_short_batches():
     """
-    the pipelined driver begins with a quarter and a half batch (the device waits for the first batch's preparation);
-    every spectrum's row lands where the in-order run puts it
+    the pipelined driver begins with a quarter and a half batch (the device waits for the first batch's preparation) --
+    where a quarter batch's launches are still single-piece (nb ceil(S / 8) > 2048 wave slots: a spectrum's numbers then do
+    not depend on the batch it rides in); every spectrum's row lands where the in-order run puts it
     """
     from gpy_dla_detection_amd.run_bayes_select import process_qso
 
-    S = 64
+    S = 8208  # a quarter of a batch of 8: 2 x 1026 virtual blocks
     learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(S)
     spectra, z_qsos = list(spectra) * 10, [z + 0.001 * i for i, z in enumerate(list(z_qsos) * 10)]
 
@@ -674,6 +675,12 @@ def test_pipeline_starts_on_short_batches():
     for name in ("log_likelihoods_no_dla", "min_z_dlas", "max_z_dlas", "sample_log_likelihoods_dla", "base_sample_inds"):
         np.testing.assert_array_equal(a[name], b[name], err_msg=name)
     assert len(set(a["log_likelihoods_no_dla"])) == 30
+    # few samples: a quarter batch would be cut into pieces and round differently -- no short first batches
+    learned, few, few_z, params, dla_samples, sub_samples = catalogue_inputs(64)
+    few, few_z = list(few) * 10, [z + 0.001 * i for i, z in enumerate(list(few_z) * 10)]
+    short = Engine()
+    process_qso(few, few_z, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=2, batch_size=8, engine=short)
+    assert sorted(t[1].shape[0] for t in short.tables) == [6, 8, 8, 8]
 
 
 def prepare_state(params, spectrum, z_qso):

@@ -24,7 +24,7 @@ from tools.measure_catalogue import FixedPrior, make_inputs  # noqa: E402
 
 def main():
     num = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    S = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 10000  # (the recorded runs' size; batches of few samples are multi-piece)
     rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     params = Parameters(num_dla_samples=S)
     u = halton(S, 3)

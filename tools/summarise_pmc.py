@@ -3,7 +3,7 @@
 profiles/r03_pmc_traffic.json from the per-kernel counter means tools/pmc_pass.sh printed (one rocprofv3 --pmc pass per
 counter group of `bench.py --steps 5 --warmup 1 --ramp-ms 0 --no-cpu-baseline`), gfx950 read-side correction applied
 (MI355X_MICROARCH.md, HBM: FETCH_SIZE counts 128-byte requests at 64 bytes for 16-byte-per-lane streaming reads).
-usage: tools/summarise_pmc.py gpurun_out/pmc_r02_counters.txt > profiles/r03_pmc_traffic.json
+usage: tools/summarise_pmc.py gpurun_out/pmc_r02_counters.txt [n = 3000] [S = 10000] > profiles/r03_pmc_traffic.json
 """
 import json
 import re
@@ -22,7 +22,8 @@ fin = [k for k in acc if "finalize_rank20" in k][0]
 c, f = acc[name], acc[fin]
 cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
 out = {
-    "config": 2,
+    # the workload the counters were collected on: bench.py attaches the traffic to a run only when all three match
+    "config": 2, "n": int(sys.argv[2]) if len(sys.argv) > 2 else 3000, "S": int(sys.argv[3]) if len(sys.argv) > 3 else 10000,
     "kernel": "accumulate_mfma<3, true, false, 0, true, false> (3 lines, broadening, core patch; 14 full tiles + 2 small MFMAs per step)",
     "command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --steps 5 --warmup 1 --ramp-ms 0 --no-cpu-baseline  (one pass per counter group; tools/pmc_pass.sh)",
     "workload": "configs[1]: 1 sightline x 10000 samples, n=3000, k=20; 2500 work items (3 full pieces + remainder per block of 16 samples)",
