@@ -107,6 +107,23 @@ struct SampleSource {
     long pair_S;         // QMC points per sightline of a pair launch; 0 = an ordinary launch
 };
 
+// Many small transfers as ONE copy and one kernel.  A host <-> device transfer of a few KB is a blit kernel of its own
+// (4 us on an idle device, queued behind the previous one): a context's set-up made nine of them, a one-spectrum model
+// selection a dozen in and out -- 7 % of its kernel time and all of it on the caller's critical path.  The pieces are laid
+// end to end in a pack buffer, which crosses the bus in one copy; `copy_segments` moves them between the pack and their
+// device arrays (host-to-device: after the copy; device-to-host: in front of it).
+#define DLAGP_COPY_SEGMENTS 24
+struct CopySegment {
+    unsigned long long device_ptr;  // the piece's device array
+    unsigned long long offset;      // of the piece in the pack buffer, bytes (a multiple of 256)
+    unsigned long long bytes;       // a multiple of 4
+};
+struct CopyTable {
+    int count;
+    int to_pack;  // 1: device arrays -> pack (results on their way out), 0: pack -> device arrays
+    CopySegment seg[DLAGP_COPY_SEGMENTS];
+};
+
 // What the kernels that end an occupation level need (reference dla_gp.py:155-218; kernels_common.h "level finish").
 // One struct, passed by value, for the one-workgroup kernel and for the three kernels of the spread form.
 //   weights  [nb][S]  exp(value - max) of the level, 0 for a NaN sample

@@ -356,8 +356,10 @@ struct Workspace {
     DeviceBuffer sub_z, sub_nhi, sub_evidences, sub_ll;  // the one-absorber model of dlagp_batch_model_evidences
     DeviceBuffer sub_level_ll, sub_alive;  // pair launches: the one-absorber model's raw level and its per-sightline flags
     PinnedBuffer stage;           // host staging of the host-pointer entry points
+    DeviceBuffer pack;            // ... and its device-side twin: small transfers cross the bus as one copy (Transfers)
     void release() {
         stage.release();
+        pack.release();
         cache.release();
         level_ll.release();
         cdf.release();
@@ -1036,6 +1038,17 @@ static int call_events(int device, CallEvents **out) {
     return DLAGP_OK;
 }
 
+// launches copy_segments for `table` on `stream`: enough blocks for the largest piece, a row of them per piece
+static void launch_copy_segments(const CopyTable &table, void *pack, hipStream_t stream) {
+    size_t largest = 0;
+    for (int i = 0; i < table.count; ++i) largest = std::max<size_t>(largest, (size_t)table.seg[i].bytes);
+    const unsigned blocks = (unsigned)std::max<size_t>(
+        1, std::min<size_t>((largest / 16 + DLAGP_SETUP_THREADS - 1) / DLAGP_SETUP_THREADS, 256));
+    hipLaunchKernelGGL(copy_segments, dim3(blocks, (unsigned)table.count), dim3(DLAGP_SETUP_THREADS), 0, stream, table,
+                       static_cast<unsigned char *>(pack));
+}
+
+static Option g_opt_pack_transfers = 1;
 // One batch of host <-> device transfers through the workspace's pinned staging buffer.
 //   add(): registers a transfer and returns nothing; run_uploads() copies host -> stage -> device (async on
 //   the call's stream, the stage is not reused before the final synchronisation); run_downloads() enqueues
@@ -1048,32 +1061,67 @@ struct Transfers {
         size_t offset;
     };
     PinnedBuffer &stage;
+    DeviceBuffer *pack;  // the workspace's device-side twin of `stage` (nullptr: every transfer a copy of its own)
     int device;
     hipStream_t compute, transfer;  // kernels of the call / copies of the call (may be the same stream)
     std::vector<Item> up, down;
     size_t total = 0;
     size_t base = 0;  // first byte of the staging buffer this call may use (a two-phase call's second phase: behind the first's)
+    size_t up_bytes = 0;  // the uploads' stretch of the staging buffer: [base, base + up_bytes); the downloads follow
+    bool packed = false;
     // Every transfer, small ones included, goes through the page-locked staging buffer as an ASYNCHRONOUS copy: a
     // blocking hipMemcpy of a few bytes costs 50-90 us of host time each, and a call made for ONE spectrum (the drop-in
     // classes: a dozen arrays in and out per model selection) spent 0.9 ms of its 1.4 ms in them
     // (profiles/r04_route_a_trace.txt).  One host wait per call, in run_downloads.
+    // Round 6: a call's small transfers also cross the bus TOGETHER.  Each copy is a blit kernel of its own (4 us, one after
+    // the other on the transfer stream: sixteen per spectrum on the drop-in route, all on the caller's critical path): up
+    // to kPackLimit bytes in all, the pieces lie end to end in the staging buffer anyway, so one copy moves the stretch
+    // to / from the workspace's pack buffer and copy_segments distributes / collects the pieces on the device.
     static constexpr size_t kDirect = 0;
-    Transfers(PinnedBuffer &s, int dev) : stage(s), device(dev), compute(compute_stream(dev)), transfer(work_stream(dev)) {}
+    static constexpr size_t kPackLimit = (size_t)8 << 20;
+    Transfers(Workspace &ws, int dev)
+        : stage(ws.stage), pack(&ws.pack), device(dev), compute(compute_stream(dev)), transfer(work_stream(dev)) {}
     void upload(void *device_ptr, const void *host, size_t bytes) {
         if (bytes) up.push_back({device_ptr, const_cast<void *>(host), bytes, 0});
     }
     void download(void *host, const void *device_ptr, size_t bytes) {
         if (bytes && host) down.push_back({const_cast<void *>(device_ptr), host, bytes, 0});
     }
+    // `also`: bytes a later phase of the same call will need behind this one's (both buffers are sized now: growing
+    // them in the second phase would free memory the first phase's copies may still be reading)
     int reserve(size_t also = 0) {
         total = 0;
-        for (auto *list : {&up, &down})
+        for (auto *list : {&up, &down}) {
             for (Item &it : *list)
                 if (it.bytes > kDirect) {
                     it.offset = base + total;
                     total += (it.bytes + 255) & ~(size_t)255;
                 }
-        return total + also ? stage.reserve(base + total + also) : DLAGP_OK;
+            if (list == &up) up_bytes = total;
+        }
+        packed = g_opt_pack_transfers && pack && up.size() + down.size() >= 3 && base + total + also <= kPackLimit &&
+                 up.size() <= DLAGP_COPY_SEGMENTS && down.size() <= DLAGP_COPY_SEGMENTS;
+        for (const Item &it : up) packed = packed && it.bytes % 4 == 0;
+        for (const Item &it : down) packed = packed && it.bytes % 4 == 0;
+        if (!(total + also)) return DLAGP_OK;
+        const size_t want = base + total + also;
+        // A buffer that is replaced must be idle.  Every call that used it ended with a wait for its copies -- unless it
+        // failed half way (an allocation failure between its uploads and its downloads), on whichever thread's stream it
+        // ran: growth of a buffer that has been used waits for the whole device first.  (Rare: the buffers only grow.
+        // Found by the host-only sanitizer replay, round 6.)
+        if ((stage.ptr && want > stage.bytes) || (packed && pack->ptr && want > pack->bytes)) HIP_TRY(hipDeviceSynchronize());
+        int rc = stage.reserve(want);
+        if (!rc && packed) rc = pack->reserve(want);
+        return rc;
+    }
+    CopyTable table_of(const std::vector<Item> &items, int to_pack) const {
+        CopyTable t{};
+        t.count = (int)items.size();
+        t.to_pack = to_pack;
+        for (size_t i = 0; i < items.size(); ++i)
+            t.seg[i] = CopySegment{(unsigned long long)(uintptr_t)items[i].device, (unsigned long long)items[i].offset,
+                                   (unsigned long long)items[i].bytes};
+        return t;
     }
     // host -> stage -> device on the transfer stream; the kernel stream waits for them (an event, no host wait)
     int run_uploads() {
@@ -1081,11 +1129,18 @@ struct Transfers {
         for (const Item &it : up) {
             if (it.bytes > kDirect) {
                 std::memcpy(static_cast<char *>(stage.ptr) + it.offset, it.host, it.bytes);
-                HIP_TRY(hipMemcpyAsync(it.device, static_cast<char *>(stage.ptr) + it.offset, it.bytes, hipMemcpyHostToDevice, transfer));
+                if (!packed)
+                    HIP_TRY(hipMemcpyAsync(it.device, static_cast<char *>(stage.ptr) + it.offset, it.bytes, hipMemcpyHostToDevice, transfer));
                 queued = true;
             } else {
                 HIP_TRY(hipMemcpy(it.device, it.host, it.bytes, hipMemcpyHostToDevice));
             }
+        }
+        if (queued && packed) {
+            HIP_TRY(hipMemcpyAsync(static_cast<char *>(pack->ptr) + base, static_cast<char *>(stage.ptr) + base, up_bytes,
+                                   hipMemcpyHostToDevice, transfer));
+            launch_copy_segments(table_of(up, 0), pack->ptr, transfer);
+            HIP_TRY(hipGetLastError());
         }
         if (queued && transfer != compute) {
             CallEvents *ev = nullptr;
@@ -1106,9 +1161,16 @@ struct Transfers {
             HIP_TRY(hipEventRecord(ev->computed, compute));
             HIP_TRY(hipStreamWaitEvent(transfer, ev->computed, 0));
         }
-        for (const Item &it : down)
-            if (it.bytes > kDirect)
-                HIP_TRY(hipMemcpyAsync(static_cast<char *>(stage.ptr) + it.offset, it.device, it.bytes, hipMemcpyDeviceToHost, transfer));
+        if (packed && !down.empty()) {
+            launch_copy_segments(table_of(down, 1), pack->ptr, transfer);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(static_cast<char *>(stage.ptr) + base + up_bytes, static_cast<char *>(pack->ptr) + base + up_bytes,
+                                   total - up_bytes, hipMemcpyDeviceToHost, transfer));
+        } else {
+            for (const Item &it : down)
+                if (it.bytes > kDirect)
+                    HIP_TRY(hipMemcpyAsync(static_cast<char *>(stage.ptr) + it.offset, it.device, it.bytes, hipMemcpyDeviceToHost, transfer));
+        }
         HIP_TRY(hipStreamSynchronize(transfer));
         for (const Item &it : down) {
             if (it.bytes > kDirect) std::memcpy(it.host, static_cast<char *>(stage.ptr) + it.offset, it.bytes);
@@ -1127,7 +1189,7 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
     if ((rc = grow(g, ws.z, nsamp * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.nhi, nsamp * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.out, (size_t)rows * sizeof(double)))) return rc;
-    Transfers tr(ws.stage, g.device);
+    Transfers tr(ws, g.device);
     const hipStream_t stream = tr.compute;
     if (kd > 0) {
         tr.upload(ws.z.ptr, z, nsamp * sizeof(double));
@@ -1335,6 +1397,11 @@ struct SetupLane {
     PinnedBuffer buf;  // Host -> device staging, see upload_staged
     size_t used = 0;
     bool dirty = false;  // handed back with copies possibly still reading the arena: the next borrower waits first
+    // staged uploads not yet sent: they leave together (flush_uploads), one copy into `pack` and one kernel that moves the
+    // pieces to their arrays
+    DeviceBuffer pack;
+    size_t pending_begin = 0;  // arena offset of the first byte not yet sent
+    CopyTable pending{};
 };
 struct LanePool {
     std::mutex mutex;
@@ -1375,6 +1442,8 @@ static SetupLane &setup_lane(int device) {
     } else if (lane->dirty) {
         (void)hipStreamSynchronize(lane->stream);  // the previous owner's last copies have left the arena
         lane->used = 0;
+        lane->pending_begin = 0;
+        lane->pending.count = 0;
         lane->dirty = false;
     }
     mine.lanes[device] = lane;
@@ -1389,11 +1458,41 @@ static hipStream_t setup_stream(int device) { return setup_lane(device).stream; 
 typedef SetupLane SetupArena;
 static SetupArena &setup_arena(int device) { return setup_lane(device); }
 
+// Sends the calling thread's staged uploads: ONE copy of their stretch of the arena into the lane's pack buffer, one kernel
+// that moves the pieces to their arrays.  Called in front of every set-up kernel that reads uploaded data, and by setup_sync.
+static int flush_uploads(int device) {
+    SetupLane &lane = setup_lane(device);
+    if (!lane.pending.count) return DLAGP_OK;
+    const size_t total = lane.used - lane.pending_begin;
+    if (total > lane.pack.bytes) {
+        // the previous flush's kernel may still be reading the pack buffer that a larger one replaces
+        HIP_TRY(hipStreamSynchronize(lane.stream));
+        int rc = lane.pack.reserve(std::max(total * 2, (size_t)1 << 20));
+        if (rc) {
+            lane.pending.count = 0;  // nothing of this stretch will be sent: the caller fails and releases its buffers
+            lane.pending_begin = lane.used;
+            return rc;
+        }
+    }
+    lane.pending.to_pack = 0;
+    const hipError_t err = hipMemcpyAsync(lane.pack.ptr, static_cast<char *>(lane.buf.ptr) + lane.pending_begin, total,
+                                          hipMemcpyHostToDevice, lane.stream);
+    if (err == hipSuccess) launch_copy_segments(lane.pending, lane.pack.ptr, lane.stream);
+    lane.pending.count = 0;
+    lane.pending_begin = lane.used;
+    if (err != hipSuccess) return fail(DLAGP_EDEVICE, "staged upload failed: %s", hipGetErrorString(err));
+    HIP_TRY(hipGetLastError());
+    return DLAGP_OK;
+}
+
 // all staged uploads and kernels of the calling thread's set-up stream are complete on return
 static int setup_sync(int device) {
+    const int flushed = flush_uploads(device);
     HIP_TRY(hipStreamSynchronize(setup_stream(device)));
-    setup_arena(device).used = 0;
-    return DLAGP_OK;
+    SetupLane &lane = setup_lane(device);
+    lane.used = 0;
+    lane.pending_begin = 0;
+    return flushed;
 }
 
 // A context created with DLAGP_FLAG_DEFER_SYNC carries an event recorded behind its set-up work on the CREATING thread's
@@ -1418,19 +1517,48 @@ static int wait_setup(dlagp_ctx *ctx) {
     return DLAGP_OK;
 }
 
+// Staged uploads of a context's set-up: together (one copy + one copy_segments launch, flush_uploads) or each a copy of
+// its own?  Measured on one box (round 6): together is 1.3 % of a one-spectrum model selection's wall time (nine
+// dependent blits become two operations) -- and 8 % LESS throughput in a catalogue pipeline, where the set-up runs beside
+// other batches' sweeps: the copies slip through while every kernel, copy_segments included, waits ~50 us for a wave slot
+// among the accumulate waves, and the set-up's latency is on that pipeline's critical path (kernel stream dry at 5 % of the
+// instants instead of 1.5 %).  So: 2 = together exactly when the device's kernel stream is idle at the moment (a caller that
+// works one spectrum at a time), 1 = always, 0 = never.
+static Option g_opt_pack_setup_uploads = 2;
+static hipStream_t shared_stream_if_any(int device);
+static bool pack_setup_uploads_now(int device) {
+    const int64_t mode = g_opt_pack_setup_uploads;
+    if (mode != 2) return mode != 0;
+    hipStream_t shared = shared_stream_if_any(device);
+    if (!g_opt_shared_work_stream || !shared) return true;
+    const bool idle = hipStreamQuery(shared) == hipSuccess;
+    (void)hipGetLastError();
+    return idle;
+}
+// (bytes: a multiple of 4 -- doubles, ints and descriptor structs)
 static int upload_staged(void *dst, const void *src, size_t bytes, int device) {
     if (!bytes) return DLAGP_OK;
     SetupArena &arena = setup_arena(device);
     const size_t need = (bytes + 255) & ~(size_t)255;
+    int rc;
     if (arena.used + need > arena.buf.bytes) {
-        int rc = setup_sync(device);  // copies in flight still read the old arena
-        if (rc) return rc;
+        if ((rc = setup_sync(device))) return rc;  // sends what is staged; copies in flight still read the old arena
         if (need > arena.buf.bytes && (rc = arena.buf.reserve(std::max(need * 2, (size_t)4 << 20)))) return rc;
     }
+    if (arena.pending.count == DLAGP_COPY_SEGMENTS && (rc = flush_uploads(device))) return rc;
     char *slot = static_cast<char *>(arena.buf.ptr) + arena.used;
     std::memcpy(slot, src, bytes);
+    if (!pack_setup_uploads_now(device)) {  // every array a copy of its own, sent at once
+        if ((rc = flush_uploads(device))) return rc;
+        arena.used += need;
+        arena.pending_begin = arena.used;
+        HIP_TRY(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, setup_stream(device)));
+        return DLAGP_OK;
+    }
+    arena.pending.seg[arena.pending.count++] = CopySegment{(unsigned long long)(uintptr_t)dst,
+                                                           (unsigned long long)(arena.used - arena.pending_begin),
+                                                           (unsigned long long)((bytes + 3) & ~(size_t)3)};
     arena.used += need;
-    HIP_TRY(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, setup_stream(device)));
     return DLAGP_OK;
 }
 
@@ -1463,7 +1591,7 @@ static int finish_group(LaunchGroup &g, const std::vector<int> *positions = null
     if (rc) return rc;
     // the table must be in place before the group's first launch, which runs on the caller's stream
     if ((rc = upload_staged(g.d_table.ptr, table.data(), table.size() * sizeof(SightlineDev), g.device))) return rc;
-    return defer_sync ? DLAGP_OK : setup_sync(g.device);
+    return defer_sync ? flush_uploads(g.device) : setup_sync(g.device);
 }
 
 // A batch whose members could each run the MFMA kernel but differ in line count, broadening or Lyman-limit flag:
@@ -1636,6 +1764,11 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     sl.Pm = ctx->Pm.as<double>();
     sl.aux = ctx->aux.as<double>();
 
+    if ((rc = flush_uploads(device))) {  // whatever `fill` and the tables above have staged: the kernels below read it
+        (void)setup_sync(device);
+        dlagp_destroy(ctx);
+        return rc;
+    }
     if (ctx->mfma_ok) {
         hipLaunchKernelGGL(fill_records, dim3((sl.n_slots + DLAGP_SETUP_THREADS - 1) / DLAGP_SETUP_THREADS), dim3(DLAGP_SETUP_THREADS), 0, setup, sl.n_slots,
                            ctx->slot_pixel.as<const int>(), ctx->slot_pos.as<const int>(), sl.y, sl.mu, sl.omega2, sl.v,
@@ -1826,6 +1959,7 @@ static int fill_from_model(dlagp_ctx *ctx, const dlagp_model *model, int n, cons
     if (!rc) rc = dw.reserve((size_t)n * sizeof(double));
     if (!rc) rc = upload_staged(dx.ptr, x, (size_t)n * sizeof(double), ctx->device);
     if (!rc) rc = upload_staged(dw.ptr, this_wavelengths, (size_t)n * sizeof(double), ctx->device);
+    if (!rc) rc = flush_uploads(ctx->device);  // the context's arrays staged so far leave as one copy; interp_model reads x and w
     if (rc) return rc;
     hipLaunchKernelGGL(interp_model, dim3((sl.n_pad + DLAGP_INTERP_PIXELS - 1) / DLAGP_INTERP_PIXELS),
                        dim3(DLAGP_INTERP_THREADS), 0, setup, model->dev, n, sl.n_pad,
@@ -2300,7 +2434,7 @@ int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double 
     if ((rc = grow(g, ws.evidences, nb * max_dlas * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.sample_ll, rows * max_dlas * sizeof(double)))) return rc;
     if ((rc = grow(g, ws.base, std::max<size_t>(n_base, 1) * sizeof(int32_t)))) return rc;
-    Transfers tr(ws.stage, g.device);
+    Transfers tr(ws, g.device);
     const hipStream_t stream = tr.compute;
     tr.upload(ws.z.ptr, sample_z, rows * sizeof(double));
     tr.upload(ws.nhi.ptr, sample_nhi, n_nhi * sizeof(double));
@@ -2366,7 +2500,7 @@ int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dla
     // dla_samples.py:94-104 / subdla_samples.py:115-125; compared by content here): the sub-DLA sweep rides in level 1's
     // launch of the DLA sweep, one optical depth per QMC point for both (pair launch).
     const bool pair = std::memcmp(sub_sample_z, sample_z, rows * sizeof(double)) == 0 && pair_eligible(g, S);
-    Transfers tr(ws.stage, g.device);
+    Transfers tr(ws, g.device);
     const hipStream_t stream = tr.compute;
     if (!pair) tr.upload(ws.sub_z.ptr, sub_sample_z, rows * sizeof(double));
     tr.upload(ws.sub_nhi.ptr, sub_sample_nhi, n_sub_nhi * sizeof(double));
@@ -2416,7 +2550,7 @@ int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniform
     const size_t nb = g.ctxs.size();
     const size_t rows = nb * (size_t)S;
     const size_t n_base = rows * (max_dlas - 1);
-    Transfers tr(ws.stage, g.device);
+    Transfers tr(ws, g.device);
     const hipStream_t stream = tr.compute;
     if (stream != batch->pending.stream)
         return fail(DLAGP_EINVAL, "dlagp_batch_model_evidences_finish must be called by the thread that called _start");
@@ -2630,6 +2764,18 @@ int dlagp_set_option(const char *name, int64_t value) try {
     else if (!strcmp(name, "pool_mb")) {
         g_opt_pool_mb = value;
         if (value <= 0) {
+            {
+                // the pack buffers of the set-up lanes no thread holds (their streams drained first)
+                LanePool &lanes = lane_pool();
+                std::lock_guard<std::mutex> lock(lanes.mutex);
+                for (auto &kv : lanes.free) {
+                    (void)hipSetDevice(kv.first);
+                    for (SetupLane *lane : kv.second) {
+                        (void)hipStreamSynchronize(lane->stream);
+                        lane->pack.release();
+                    }
+                }
+            }
             pool_flush();
             std::lock_guard<std::mutex> lock(g_spare_mutex);
             for (auto &kv : g_spare_workspace) {
@@ -2655,6 +2801,8 @@ int dlagp_set_option(const char *name, int64_t value) try {
     else if (!strcmp(name, "finalize_wave")) g_opt_finalize_wave = value != 0;
     else if (!strcmp(name, "fuse_finalize")) g_opt_fuse_finalize = value != 0;
     else if (!strcmp(name, "pair_models")) g_opt_pair_models = value != 0;
+    else if (!strcmp(name, "pack_setup_uploads")) g_opt_pack_setup_uploads = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (!strcmp(name, "pack_transfers")) g_opt_pack_transfers = value != 0;
     else if (!strcmp(name, "level_spread")) g_opt_level_spread = value != 0;
     else if (!strcmp(name, "level_search_groups")) g_opt_level_search_groups = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
@@ -2704,6 +2852,8 @@ int dlagp_get_option(const char *name, int64_t *value) try {
     else if (!strcmp(name, "last_launch_fused")) *value = g_last_launch_fused;
     else if (!strcmp(name, "pair_models")) *value = g_opt_pair_models;
     else if (!strcmp(name, "last_sweep_paired")) *value = g_last_sweep_paired;
+    else if (!strcmp(name, "pack_setup_uploads")) *value = g_opt_pack_setup_uploads;
+    else if (!strcmp(name, "pack_transfers")) *value = g_opt_pack_transfers;
     else if (!strcmp(name, "level_spread")) *value = g_opt_level_spread;
     else if (!strcmp(name, "level_search_groups")) *value = g_opt_level_search_groups;
     else if (!strcmp(name, "last_level_spread")) *value = g_last_level_spread;

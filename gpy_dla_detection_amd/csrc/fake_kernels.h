@@ -13,6 +13,10 @@ template <bool CUM_IN_LDS>
 void level_finish_fused(LevelArgs) {}
 inline void level_weights(LevelArgs) {}
 inline void level_resample(LevelArgs) {}
+// what a segment copy touches: the device array of every piece
+inline void mark_arg(const CopyTable &t, fake::Stream *s, uint64_t ticket) {
+    for (int i = 0; i < t.count; ++i) fake::mark(reinterpret_cast<const void *>(t.seg[i].device_ptr), s, ticket);
+}
 // what a level-finish launch touches (fake::launch marks pointer arguments; this struct travels by value)
 inline void mark_arg(const LevelArgs &a, fake::Stream *s, uint64_t t) {
     for (const void *p : {(const void *)a.ll, (const void *)a.uniforms, (const void *)a.sample_ll, (const void *)a.evidences,

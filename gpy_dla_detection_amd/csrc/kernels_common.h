@@ -1223,6 +1223,28 @@ __global__ void sweep_init(double *__restrict__ sample_ll, long n_ll, double *__
     }
 }
 
+// grid (blocks, segments): see CopyTable (dlagp_device.h).  ONE-WAVE workgroups, like every kernel that runs beside other
+// batches' sweeps (host_shared.h, DLAGP_SETUP_THREADS): a workgroup of four waves finds four free wave slots on one compute
+// unit only when a sweep's launch drains -- with 256 threads this kernel made a catalogue run's kernel stream run dry at 13 %
+// of the instants (2060 instead of 2520 spectra/s).
+__global__ __launch_bounds__(DLAGP_SETUP_THREADS) void copy_segments(CopyTable t, unsigned char *__restrict__ pack) {
+    const CopySegment s = t.seg[blockIdx.y];
+    const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    if (((s.device_ptr | s.bytes) & 15) == 0) {  // the pack offset is a multiple of 256
+        uint4 *dev = reinterpret_cast<uint4 *>(s.device_ptr);
+        uint4 *pk = reinterpret_cast<uint4 *>(pack + s.offset);
+        for (size_t i = first; i < s.bytes / 16; i += stride)
+            if (t.to_pack) pk[i] = dev[i];
+            else dev[i] = pk[i];
+    } else {
+        unsigned int *dev = reinterpret_cast<unsigned int *>(s.device_ptr);
+        unsigned int *pk = reinterpret_cast<unsigned int *>(pack + s.offset);
+        for (size_t i = first; i < s.bytes / 4; i += stride)
+            if (t.to_pack) pk[i] = dev[i];
+            else dev[i] = pk[i];
+    }
+}
+
 __global__ void fill_f64(double *__restrict__ dst, long n, double value) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = value;
 }

@@ -444,7 +444,13 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     "level_spread" (1 = the kernels that end an occupation level -- Occam term and separation mask,
  *                     evidence, resampling -- run as two launches that spread a sightline over ~30 compute units; 0 = one
  *                     1024-thread workgroup per sightline; identical results, bit for bit; default 1), "level_search_groups"
- *                     (workgroups per sightline that share the searches of the spread form, 1..64, default 16)
+ *                     (workgroups per sightline that share the searches of the spread form, 1..64, default 16),
+ *                     "pack_transfers" (1 = the small host <-> device transfers of a host-pointer call, up to 8 MB in all,
+ *                     cross the bus as ONE copy each way and a kernel distributes / collects the pieces -- a dozen dependent
+ *                     4 us copies per one-spectrum model selection otherwise; 0 = one copy per array; default 1),
+ *                     "pack_setup_uploads" (the same for the arrays of a context's set-up: 0 = one copy per array, 1 = together,
+ *                     2 = together when the device's kernel stream is idle at that moment -- beside a running sweep the single
+ *                     copies get through sooner than a kernel finds a wave slot; default 2)
  *   dlagp_timing_read: sum of accumulate-kernel durations (ms) and launch count since the last
  *                     reset; synchronises the recorded events.
  */
