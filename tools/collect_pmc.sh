@@ -18,3 +18,5 @@ for group in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_s
   rm -rf "$out/pass$i"
 done
 wc -l "$out/counters.txt"
+# configs[1] (the default arguments): the summary bench.py attaches to a run of the same (config, n, S)
+if [ $# -eq 0 ]; then python3 "$root/tools/summarise_pmc.py" "$out/counters.txt" 3000 10000 > "$out/pmc_traffic.json"; fi

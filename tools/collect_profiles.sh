@@ -38,6 +38,14 @@ for n in 300 685 1250 3061; do
 done
 echo ']' >> $out/frac_vs_n.json
 python3 tools/measure_frac_vs_n.py --pixels 755 --spread 0.65 2>> $out/bench.err | tail -1 > $out/frac_ragged_mix.json
-python3 tools/measure_route_a.py 256 2>/dev/null | tail -1 > $out/route_a.json
+# the drop-in route (the reference driver's loop, imports swapped): wall time, then the same under rocprofv3 for its kernels
+python3 tools/measure_route_a.py 256 2>/dev/null | tail -1 > $out/route_a_wall.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_route_a -- python3 tools/measure_route_a.py 256 > $out/route_a_under_rocprof.json 2>> $out/bench.err
+cp $out/prof_route_a/*/*_kernel_stats.csv $out/kernel_stats_route_a.csv
+python3 tools/route_a_frac.py $out/kernel_stats_route_a.csv $out/route_a_wall.json > $out/route_a.json
+# ... and the catalogue driver's kernels
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cat -- python3 tools/measure_catalogue.py 1024 10000 32 dr12q > $out/catalogue_under_rocprof.json 2>> $out/bench.err
+cp $out/prof_cat/*/*_kernel_stats.csv $out/kernel_stats_catalogue.csv
+rm -rf $out/prof_route_a $out/prof_cat
 rm -rf $out/prof $out/prof_c3 $out/prof_c4 $out/prof_c5
 ls -la $out

@@ -1,0 +1,6 @@
+set -u
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+bash tools/collect_profiles.sh r06 > gpurun_out/collect_r06.log 2>&1
+tail -5 gpurun_out/collect_r06.log
+bash tools/collect_pmc.sh r06 > gpurun_out/collect_pmc_r06.log 2>&1
+tail -3 gpurun_out/collect_pmc_r06.log

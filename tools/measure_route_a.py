@@ -67,9 +67,18 @@ def main():
         loop(spectra, z_qsos, param, FixedPrior(), dla, sub, learned)
         pr.disable()
         pstats.Stats(pr).sort_stats("cumtime").print_stats(30)
-    print(json.dumps({"route": "A (reference driver loop, imports swapped)", "spectra": num, "S": S, "max_dlas": 4,
-                      "seconds": t, "spectra_per_s": num / t, "ms_per_spectrum": 1e3 * t / num,
-                      "argmax_counts": np.bincount(argmax, minlength=6).tolist(), "options": options}))
+    from gpy_dla_detection_amd.run_bayes_select import kept_pixel_counts
+
+    kept = kept_pixel_counts(param, spectra, z_qsos)
+    # algorithmic FLOP of the run (n k (k + 1) + 2 n k per evaluation; 1 null + S sub-DLA + 4 S DLA evaluations
+    # per spectrum) -- against the wall time here, and against the kernels' own time by tools/route_a_frac.py
+    flop = float(kept.sum()) * (20 * 21 + 40) * (1 + 5 * S)
+    out = {"route": "A (reference driver loop, imports swapped)", "spectra": num, "S": S, "max_dlas": 4,
+           "seconds": t, "spectra_per_s": num / t, "ms_per_spectrum": 1e3 * t / num,
+           "kept_pixels": {"min": int(kept.min()), "median": float(np.median(kept)), "mean": float(kept.mean()), "max": int(kept.max())},
+           "algorithmic_gflop_per_spectrum": flop / num / 1e9, "wall_frac_of_fp64_peak": flop / t / 78.6e12,
+           "argmax_counts": np.bincount(argmax, minlength=6).tolist(), "options": options}
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
