@@ -109,3 +109,53 @@ def gapped_sightline(index=4, n_unmasked=600, gaps=((203, 333),), comb=(400, 420
     sight.y, sight.v = sight.y[sel], sight.v[sel]
     sight.this_mu, sight.this_M, sight.this_omega2 = sight.this_mu[sel], sight.this_M[sel], sight.this_omega2[sel]
     return sight
+
+
+def driver_datasets(max_dlas):
+    """
+    What the reference driver keeps of one spectrum's model selection (run_bayes_select.py:189-230), as a table:
+    dataset name -> function of a context dict(gp, dla_gp, subdla_gp, bayes, wavelengths, z_qso, MAP).  The three per-model
+    vectors of `BayesModelSelect` are laid out [null, sub-DLA, DLA(1..max_dlas)].  Used by tools/gen_golden.py (on the
+    reference's classes) and by the route-A test (on this package's), so that both store the same things the same way.
+    """
+    per_model = {"no_dla": lambda v: v[0], "lls": lambda v: v[1], "dla": lambda v: v[-max_dlas:]}
+    stored = {
+        "min_z_dlas": lambda c: c["dla_gp"].params.min_z_dla(c["wavelengths"], c["z_qso"]),
+        "max_z_dlas": lambda c: c["dla_gp"].params.max_z_dla(c["wavelengths"], c["z_qso"]),
+        "sample_log_likelihoods_dla": lambda c: c["dla_gp"].sample_log_likelihoods,
+        "base_sample_inds": lambda c: c["dla_gp"].base_sample_inds.T,
+        "sample_log_likelihoods_lls": lambda c: c["subdla_gp"].sample_log_likelihoods[:, 0],
+        "MAP_z_dlas": lambda c: c["MAP"][0],
+        "MAP_log_nhis": lambda c: c["MAP"][1],
+        "model_posteriors": lambda c: c["bayes"].model_posteriors,
+        "p_dlas": lambda c: c["bayes"].p_dla,
+        "p_no_dlas": lambda c: c["bayes"].p_no_dla,
+    }
+    for quantity in ("log_priors", "log_likelihoods", "log_posteriors"):
+        for suffix, pick in per_model.items():
+            stored["%s_%s" % (quantity, suffix)] = lambda c, q=quantity, pick=pick: pick(getattr(c["bayes"], q))
+    return stored
+
+
+def run_driver_loop(spectra, z_qsos, params, make_models, bayes, max_dlas):
+    """
+    The reference driver's loop over spectra (run_bayes_select.py:141-230) around ANY implementation of the three GP
+    classes: `make_models()` -> (gp, dla_gp, subdla_gp) in the driver's construction order; `set_data` on each, model
+    selection over [gp, subdla_gp, dla_gp], MAP; returns the per-quasar datasets stacked.
+    """
+    import numpy as np
+
+    stored = driver_datasets(max_dlas)
+    rows = {name: [] for name in stored}
+    for (wavelengths, flux, noise_variance, pixel_mask), z_qso in zip(spectra, z_qsos):
+        np.random.seed(0)  # :144
+        rest_wavelengths = params.emitted_wavelengths(wavelengths, z_qso)
+        gp, dla_gp, subdla_gp = make_models()
+        for model in (gp, dla_gp, subdla_gp):
+            model.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
+        bayes.model_selection([gp, subdla_gp, dla_gp], z_qso)  # the model list of :189
+        context = dict(gp=gp, dla_gp=dla_gp, subdla_gp=subdla_gp, bayes=bayes, wavelengths=wavelengths, z_qso=z_qso,
+                       MAP=dla_gp.maximum_a_posteriori())
+        for name, value_of in stored.items():
+            rows[name].append(np.array(value_of(context)))
+    return {name: np.stack(values) for name, values in rows.items()}

@@ -1795,58 +1795,15 @@ def test_reference_driver_loop_with_swapped_imports_matches_golden():
     learned = tuple(learned)[:7]
     prior = FixedPrior()
     broadening = True
-    bayes = BayesModelSelect([0, 1, max_dlas], 2)
-    num_quasars = len(spectra)
-    out = dict(
-        min_z_dlas=np.full((num_quasars,), np.nan), max_z_dlas=np.full((num_quasars,), np.nan),
-        log_priors_no_dla=np.full((num_quasars,), np.nan), log_priors_dla=np.full((num_quasars, max_dlas), np.nan),
-        log_priors_lls=np.full((num_quasars,), np.nan),
-        log_likelihoods_no_dla=np.full((num_quasars,), np.nan), log_likelihoods_dla=np.full((num_quasars, max_dlas), np.nan),
-        log_likelihoods_lls=np.full((num_quasars,), np.nan),
-        log_posteriors_no_dla=np.full((num_quasars,), np.nan), log_posteriors_dla=np.full((num_quasars, max_dlas), np.nan),
-        log_posteriors_lls=np.full((num_quasars,), np.nan),
-        sample_log_likelihoods_dla=np.full((num_quasars, S, max_dlas), np.nan),
-        base_sample_inds=np.zeros((num_quasars, S, max_dlas - 1), dtype=np.int32),
-        sample_log_likelihoods_lls=np.full((num_quasars, S), np.nan),
-        MAP_z_dlas=np.full((num_quasars, max_dlas, max_dlas), np.nan),
-        MAP_log_nhis=np.full((num_quasars, max_dlas, max_dlas), np.nan),
-        model_posteriors=np.full((num_quasars, 1 + 1 + max_dlas), np.nan),
-        p_dlas=np.full((num_quasars,), np.nan), p_no_dlas=np.full((num_quasars,), np.nan),
-    )
-    for quasar_ind, (spectrum, z_qso) in enumerate(zip(spectra, z_qso_list)):
-        np.random.seed(0)
-        wavelengths, flux, noise_variance, pixel_mask = spectrum  # read_spec(filename)
-        rest_wavelengths = param.emitted_wavelengths(wavelengths, z_qso)
+    from tests.golden_inputs import run_driver_loop
 
-        gp = NullGP(param, prior, *learned)
-        gp.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
-        dla_gp = DLAGP(param, prior, dla_samples, *learned, min_z_separation=3000.0, broadening=broadening)
-        dla_gp.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
-        subdla_gp = SubDLAGP(param, prior, subdla_samples, *learned, min_z_separation=3000.0, broadening=broadening)
-        subdla_gp.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
-
-        bayes.model_selection([gp, subdla_gp, dla_gp], z_qso)
-
-        out["min_z_dlas"][quasar_ind] = dla_gp.params.min_z_dla(wavelengths, z_qso)
-        out["max_z_dlas"][quasar_ind] = dla_gp.params.max_z_dla(wavelengths, z_qso)
-        out["log_priors_no_dla"][quasar_ind] = bayes.log_priors[0]
-        out["log_priors_dla"][quasar_ind, :] = bayes.log_priors[-max_dlas:]
-        out["log_priors_lls"][quasar_ind] = bayes.log_priors[1]
-        out["log_likelihoods_no_dla"][quasar_ind] = bayes.log_likelihoods[0]
-        out["log_likelihoods_dla"][quasar_ind, :] = bayes.log_likelihoods[-max_dlas:]
-        out["log_likelihoods_lls"][quasar_ind] = bayes.log_likelihoods[1]
-        out["log_posteriors_no_dla"][quasar_ind] = bayes.log_posteriors[0]
-        out["log_posteriors_dla"][quasar_ind, :] = bayes.log_posteriors[-max_dlas:]
-        out["log_posteriors_lls"][quasar_ind] = bayes.log_posteriors[1]
-        out["sample_log_likelihoods_dla"][quasar_ind, :, :] = dla_gp.sample_log_likelihoods[:, :]
-        out["base_sample_inds"][quasar_ind, :, :] = dla_gp.base_sample_inds[:, :].T
-        out["sample_log_likelihoods_lls"][quasar_ind, :] = subdla_gp.sample_log_likelihoods[:, 0]
-        MAP_z_dla, MAP_log_nhi = dla_gp.maximum_a_posteriori()
-        out["MAP_z_dlas"][quasar_ind, :, :] = MAP_z_dla[:, :]
-        out["MAP_log_nhis"][quasar_ind, :, :] = MAP_log_nhi[:, :]
-        out["model_posteriors"][quasar_ind, :] = bayes.model_posteriors[:]
-        out["p_dlas"][quasar_ind] = bayes.p_dla
-        out["p_no_dlas"][quasar_ind] = bayes.p_no_dla
+    out = run_driver_loop(
+        spectra, z_qso_list, param,
+        lambda: (NullGP(param, prior, *learned),
+                 DLAGP(param, prior, dla_samples, *learned, min_z_separation=3000.0, broadening=broadening),
+                 SubDLAGP(param, prior, subdla_samples, *learned, min_z_separation=3000.0, broadening=broadening)),
+        BayesModelSelect([0, 1, max_dlas], 2), max_dlas)
+    assert out["base_sample_inds"].dtype == np.int32 and out["sample_log_likelihoods_dla"].shape == (len(spectra), S, max_dlas)
     out["z_qsos"] = np.array(z_qso_list)
     out["num_dla_samples"], out["k"] = param.num_dla_samples, param.k
     assert_catalogue_matches_golden(out, g, rtol=RTOL_LL)

@@ -346,47 +346,15 @@ def g8_catalogue():
     dla_samples = ArraySamples(params, off, 20.0 + 3.0 * u)
     sub_samples = ArraySamples(params, off, 19.5 + 0.5 * u)
     bayes = RefBayes([0, 1, max_dlas], 2)
-    N = len(spectra)
-    out = dict(
-        min_z_dlas=np.full(N, np.nan), max_z_dlas=np.full(N, np.nan),
-        log_priors_no_dla=np.full(N, np.nan), log_priors_dla=np.full((N, max_dlas), np.nan),
-        log_likelihoods_no_dla=np.full(N, np.nan), log_likelihoods_dla=np.full((N, max_dlas), np.nan),
-        log_posteriors_no_dla=np.full(N, np.nan), log_posteriors_dla=np.full((N, max_dlas), np.nan),
-        sample_log_likelihoods_dla=np.full((N, S, max_dlas), np.nan),
-        base_sample_inds=np.zeros((N, S, max_dlas - 1), dtype=np.int32),
-        log_likelihoods_lls=np.full(N, np.nan), log_posteriors_lls=np.full(N, np.nan),
-        log_priors_lls=np.full(N, np.nan), sample_log_likelihoods_lls=np.full((N, S), np.nan),
-        MAP_z_dlas=np.full((N, max_dlas, max_dlas), np.nan), MAP_log_nhis=np.full((N, max_dlas, max_dlas), np.nan),
-        model_posteriors=np.full((N, 2 + max_dlas), np.nan), p_dlas=np.full(N, np.nan), p_no_dlas=np.full(N, np.nan),
-    )
-    for q, ((wavelengths, flux, noise_variance, pixel_mask), z_qso) in enumerate(zip(spectra, z_qsos)):
-        np.random.seed(0)
-        rest_wavelengths = params.emitted_wavelengths(wavelengths, z_qso)
-        gp = RefNullGP(params, prior, *learned)
-        gp.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
-        dla_gp = RefDLAGP(params, prior, dla_samples, *learned, min_z_separation=3000.0, broadening=True)
-        dla_gp.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
-        sub_gp = RefSubDLAGP(params, prior, sub_samples, *learned, min_z_separation=3000.0, broadening=True)
-        sub_gp.set_data(rest_wavelengths, flux, noise_variance, pixel_mask, z_qso, build_model=True)
-        bayes.model_selection([gp, sub_gp, dla_gp], z_qso)
-        out["min_z_dlas"][q] = params.min_z_dla(wavelengths, z_qso)
-        out["max_z_dlas"][q] = params.max_z_dla(wavelengths, z_qso)
-        out["log_priors_no_dla"][q] = bayes.log_priors[0]
-        out["log_priors_dla"][q] = bayes.log_priors[-max_dlas:]
-        out["log_priors_lls"][q] = bayes.log_priors[1]
-        out["log_likelihoods_no_dla"][q] = bayes.log_likelihoods[0]
-        out["log_likelihoods_dla"][q] = bayes.log_likelihoods[-max_dlas:]
-        out["log_likelihoods_lls"][q] = bayes.log_likelihoods[1]
-        out["log_posteriors_no_dla"][q] = bayes.log_posteriors[0]
-        out["log_posteriors_dla"][q] = bayes.log_posteriors[-max_dlas:]
-        out["log_posteriors_lls"][q] = bayes.log_posteriors[1]
-        out["sample_log_likelihoods_dla"][q] = dla_gp.sample_log_likelihoods
-        out["base_sample_inds"][q] = dla_gp.base_sample_inds.T
-        out["sample_log_likelihoods_lls"][q] = sub_gp.sample_log_likelihoods[:, 0]
-        out["MAP_z_dlas"][q], out["MAP_log_nhis"][q] = dla_gp.maximum_a_posteriori()
-        out["model_posteriors"][q] = bayes.model_posteriors
-        out["p_dlas"][q] = bayes.p_dla
-        out["p_no_dlas"][q] = bayes.p_no_dla
+    from tests.golden_inputs import run_driver_loop
+
+    # the driver's loop (run_bayes_select.py:141-230) around the REFERENCE's classes: its per-quasar datasets, stacked
+    out = dict(run_driver_loop(
+        spectra, z_qsos, params,
+        lambda: (RefNullGP(params, prior, *learned),
+                 RefDLAGP(params, prior, dla_samples, *learned, min_z_separation=3000.0, broadening=True),
+                 RefSubDLAGP(params, prior, sub_samples, *learned, min_z_separation=3000.0, broadening=True)),
+        bayes, max_dlas))
     out["z_qsos"] = np.array(z_qsos)
     out["S"], out["max_dlas"] = S, max_dlas
     out["input_crc"] = checksum(*[a for spec in spectra for a in spec[:3]])
