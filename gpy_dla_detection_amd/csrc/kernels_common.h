@@ -1050,24 +1050,68 @@ struct ResampleShared {
 // its sightline: the level's maximum, the lanes' scales and scans, the evidence (group 0 writes it), the cumulative
 // weights of ALL samples into `cum` (LDS; or, IN_PLACE, over the weights in memory -- one group only), then this
 // group's share of the searches.
-template <bool IN_PLACE>
+// LANES_PER_THREAD = 1024 / threads, a compile-time bound of the turns a thread takes over the virtual lanes: everything this
+// phase reads -- the lanes' maxima and sums, the wave counts, the weights of the thread's chunks, its first uniforms -- has an
+// address that is known when the kernel starts, so all of it is REQUESTED first and used later: four dependent trips to L2
+// (1.5 us each on a workgroup that has nothing else to do) become one.
+template <bool IN_PLACE, int LANES_PER_THREAD>
 __device__ __forceinline__ void resample(const LevelArgs &a, long b, int tid, int threads, int group, int groups, double *cum_lds,
                                          ResampleShared &sh) {
     const long S = a.S;
     const int level = a.level;
     const double *xm = x_m(a, b), *xs = x_s(a, b);
     const int lane = tid & 63;
+    const bool resamples = level + 1 < a.max_dlas;
+    const double *W = a.weights + b * S;
+    const long chunk = (S + DLAGP_LEVEL_LANES - 1) / DLAGP_LEVEL_LANES;
+    constexpr int KEEP = 12;  // S <= 12 288: a chunk's reads are issued together, in front of everything else
+    constexpr int BATCH = 5;  // searches per thread in flight: each is ~14 dependent reads of the cumulative array
+    const bool prefetched = resamples && chunk <= KEEP;
+    const long stride = (long)groups * threads;
+    const long first = (long)group * threads + tid;
+    const double *u = a.uniforms + (b * (a.max_dlas - 1) + level) * S;
+
+    // ---- every read whose address does not depend on a result of this kernel
+    double m[LANES_PER_THREAD], sums[LANES_PER_THREAD], w[LANES_PER_THREAD][KEEP], u_first[BATCH];
+#pragma unroll
+    for (int j = 0; j < LANES_PER_THREAD; ++j) {
+        const int vl = tid + j * threads;
+        m[j] = xm[vl];
+        sums[j] = xs[vl];
+    }
+    const double my_count = tid < 16 ? x_cnt(a, b)[tid] : 0.0;
+    if (prefetched) {
+#pragma unroll
+        for (int j = 0; j < LANES_PER_THREAD; ++j) {
+            const long lo = (long)(tid + j * threads) * chunk, hi = lo + chunk < S ? lo + chunk : S;
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) w[j][k] = lo + k < hi ? W[lo + k] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const long i = first + (long)k * stride;
+            u_first[k] = u[i < S ? i : S - 1];
+        }
+    }
+
     double top = -__builtin_inf();
-    for (int vl = tid; vl < DLAGP_LEVEL_LANES; vl += threads) top = fmax(top, xm[vl]);
+#pragma unroll
+    for (int j = 0; j < LANES_PER_THREAD; ++j) top = fmax(top, m[j]);
     top = wave_max(top);
     if (lane == 0) sh.red[tid >> 6] = top;
+    if (tid < 16) sh.tot[tid] = my_count;  // parked here until the scans below replace it (read in between by thread 0 only)
     __syncthreads();
     top = sh.red[0];
-    for (int w = 1; w < threads / 64; ++w) top = fmax(top, sh.red[w]);
-    for (int vl = tid; vl < DLAGP_LEVEL_LANES; vl += threads) {  // the real wave holds one whole virtual wave per turn
-        const double m = xm[vl];
-        const double f = m > -__builtin_inf() ? exp(m - top) : 0.0;
-        double incl = f * xs[vl];
+    for (int wv = 1; wv < threads / 64; ++wv) top = fmax(top, sh.red[wv]);
+    double count = 0.0;
+    if (tid == 0)
+        for (int wv = 0; wv < 16; ++wv) count += sh.tot[wv];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < LANES_PER_THREAD; ++j) {  // the real wave holds one whole virtual wave per turn
+        const int vl = tid + j * threads;
+        const double f = m[j] > -__builtin_inf() ? exp(m[j] - top) : 0.0;
+        double incl = f * sums[j];
         for (int off = 1; off < 64; off <<= 1) {
             const double o = __shfl_up(incl, off);
             if (lane >= off) incl += o;
@@ -1078,42 +1122,37 @@ __device__ __forceinline__ void resample(const LevelArgs &a, long b, int tid, in
     }
     __syncthreads();
     if (tid == 0) {
-        const double *cnt = x_cnt(a, b);
-        double run = 0.0, count = 0.0;
-        for (int w = 0; w < 16; ++w) {
-            sh.offs[w] = run;
-            run += sh.tot[w];
-            count += cnt[w];
+        double run = 0.0;
+        for (int wv = 0; wv < 16; ++wv) {
+            sh.offs[wv] = run;
+            run += sh.tot[wv];
         }
         sh.offs[16] = run;
         sh.offs[17] = count;
     }
     __syncthreads();
-    const double last = sh.offs[16], count = sh.offs[17];
+    const double last = sh.offs[16];
+    count = sh.offs[17];
     const double evidence = count > 0.0 ? top + log(last / count) - level * a.log_s : __builtin_nan("");
     if (group == 0 && tid == 0) {
         a.evidences[b * a.max_dlas + level] = evidence;
         if (!(evidence == evidence)) a.alive[b] = 0;
     }
-    if (level + 1 == a.max_dlas || !(evidence == evidence)) return;
+    if (!resamples || !(evidence == evidence)) return;
 
-    double *W = a.weights + b * S;
-    double *cum = IN_PLACE ? W : cum_lds;
-    const long chunk = (S + DLAGP_LEVEL_LANES - 1) / DLAGP_LEVEL_LANES;
-    constexpr int KEEP = 12;  // S <= 12 288: a chunk's reads are issued together
-    for (int vl = tid; vl < DLAGP_LEVEL_LANES; vl += threads) {
+    double *cum = IN_PLACE ? a.weights + b * S : cum_lds;
+#pragma unroll
+    for (int j = 0; j < LANES_PER_THREAD; ++j) {
+        const int vl = tid + j * threads;
         const long lo = (long)vl * chunk, hi = lo + chunk < S ? lo + chunk : S;
         if (lo >= S) break;
         const double f = sh.scale[vl];
         double run = sh.offs[vl >> 6] + ((vl & 63) ? sh.incl[vl - 1] : 0.0);
-        if (chunk <= KEEP) {
-            double w[KEEP];
-#pragma unroll
-            for (int k = 0; k < KEEP; ++k) w[k] = lo + k < hi ? W[lo + k] : 0.0;
+        if (prefetched) {
 #pragma unroll
             for (int k = 0; k < KEEP; ++k)
                 if (lo + k < hi) {
-                    run += f * w[k];
+                    run += f * w[j][k];
                     cum[lo + k] = run;
                 }
         } else {
@@ -1126,21 +1165,20 @@ __device__ __forceinline__ void resample(const LevelArgs &a, long b, int tid, in
     __syncthreads();
 
     int *out = a.base + (b * (a.max_dlas - 1) + level) * S;
-    const double *u = a.uniforms + (b * (a.max_dlas - 1) + level) * S;
     const double margin = DLAGP_TIE_MARGIN * last;
-    constexpr int BATCH = 5;  // searches per thread in flight: each is ~14 dependent reads of the cumulative array
-    const long stride = (long)groups * threads;
     int near = 0;
-    for (long i0 = (long)group * threads + tid; i0 < S; i0 += (long)BATCH * stride) {
+    bool first_turn = true;
+    for (long i0 = first; i0 < S; i0 += (long)BATCH * stride) {
         double x[BATCH];
         long left[BATCH], right[BATCH];
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const long i = i0 + (long)k * stride;
-            x[k] = u[i < S ? i : S - 1] * last;
+            x[k] = (first_turn && prefetched ? u_first[k] : u[i < S ? i : S - 1]) * last;
             left[k] = 0;
             right[k] = i < S ? S : 0;  // first index with cum[index] > x  (searchsorted side="right")
         }
+        first_turn = false;
         bool busy = true;
         while (busy) {
             busy = false;
@@ -1189,7 +1227,7 @@ __global__ __launch_bounds__(DLAGP_LEVEL_THREADS) void level_finish_fused(LevelA
     if (!a.alive[b]) return;  // an earlier level's evidence was NaN: the reference stopped there
     lvl::lane_weights<4>(a, b, tid);
     __syncthreads();
-    lvl::resample<!CUM_IN_LDS>(a, b, tid, DLAGP_LEVEL_THREADS, 0, 1, cum_lds, sh);
+    lvl::resample<!CUM_IN_LDS, 1>(a, b, tid, DLAGP_LEVEL_THREADS, 0, 1, cum_lds, sh);
 }
 
 // ---- the spread form: grid (workgroups per sightline, sightlines)
@@ -1205,7 +1243,8 @@ __global__ __launch_bounds__(DLAGP_LEVEL_SEARCH_THREADS) void level_resample(Lev
     __shared__ lvl::ResampleShared sh;
     const long b = blockIdx.y;
     if (!a.alive[b]) return;
-    lvl::resample<false>(a, b, threadIdx.x, DLAGP_LEVEL_SEARCH_THREADS, blockIdx.x, gridDim.x, cum_lds, sh);
+    lvl::resample<false, DLAGP_LEVEL_LANES / DLAGP_LEVEL_SEARCH_THREADS>(a, b, threadIdx.x, DLAGP_LEVEL_SEARCH_THREADS, blockIdx.x,
+                                                                         gridDim.x, cum_lds, sh);
 }
 
 // Start of an occupation sweep in one launch (reference dla_gp.py:112-119: NaN-initialised likelihoods and evidences,
