@@ -184,6 +184,36 @@ def kept_pixel_counts(params: Parameters, spectra, z_qso_list) -> np.ndarray:
     return counts
 
 
+def _single_piece_ramp(batch_size: int, S: int) -> tuple:
+    """
+    Sizes of the short batches a pipelined run starts on -- a quarter and a half of `batch_size`, or a half, or none: the
+    shortest whose launches the planner keeps single-piece for DR12Q's shortest and longest sightlines (31 and 157 chunks
+    of 8 pixel slots), in a one-model launch (nb ceil(S / 16) blocks) and in a pair launch (nb ceil(S / 8)).
+    """
+    import ctypes
+
+    from . import _lib
+
+    lib = _lib.load()
+
+    def single_piece(nb: int) -> bool:
+        for groups in (nb * -(-S // 16), nb * -(-S // 8)):
+            for chunks in (31.0, 157.0):
+                full, frac = ctypes.c_int(), ctypes.c_double()
+                if lib.dlagp_plan_cut(groups, chunks, 0, ctypes.byref(full), ctypes.byref(frac)) != 0:
+                    return False
+                if full.value != 1 or frac.value < 1.0 - 1e-9:
+                    return False
+        return True
+
+    quarter, half = batch_size // 4, batch_size // 2
+    if quarter >= 1 and single_piece(quarter) and single_piece(half):
+        return (quarter, half)
+    if half >= 1 and single_piece(half):
+        return (half,)
+    return ()
+
+
 def process_qso(
     spectra: Sequence[Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]],
     z_qso_list: Sequence[float],
@@ -389,18 +419,18 @@ def process_qso(
     # `prefetch=False` -- and seed=None, whose draws come from the global RNG in catalogue order -- runs everything in
     # this thread, in order.
     bounds = [(start, min(start + batch_size, len(mine))) for start in range(0, len(mine), batch_size)]
-    # A spectrum's numbers do not depend on the batch it rides in AS LONG AS the batch's launches are single-piece (more
-    # blocks of 16 samples than the planner's 2048 wave slots: one wave then takes a block from the first pixel to the
-    # log-likelihood).  A batch of a few spectra, or of few samples, is cut into pieces and its sums round differently
-    # (~1e-13; exactly-settled base indices can then differ where the likelihoods do): so the short first batches are used
-    # only where a quarter batch is still single-piece -- nb ceil(S / 8) virtual blocks in a pair launch -- and a short LAST
-    # batch agrees with its spectra's results in any other batch to rounding, not to the bit.
-    single_piece = (batch_size // 4) * -(-S // 8) > 2048
-    if prefetch and seed is not None and len(mine) > 3 * batch_size >= 12 and single_piece:
-        # the device waits while the first batch is prepared: the pipeline starts on a quarter and a half batch
-        ramp = (batch_size // 4, batch_size // 4 + batch_size // 2)
-        bounds = [(0, ramp[0]), ramp] + [(start, min(start + batch_size, len(mine)))
-                                         for start in range(ramp[1], len(mine), batch_size)]
+    # A spectrum's numbers do not depend on the batch it rides in AS LONG AS the batch's launches are single-piece: one wave
+    # then takes a block of 16 samples from the first pixel to the log-likelihood.  The planner cuts blocks into pieces when
+    # that fills the wave slots better -- a batch of a few spectra, or of few samples -- and the sums then round differently
+    # (~1e-13; base indices, exact for their likelihoods, can differ where those do).  So the pipeline's short FIRST batches
+    # (the device waits while the first batch is prepared) are only as short as the planner itself keeps single-piece, asked
+    # through the library (`dlagp_plan_cut`, pure host arithmetic); a short LAST batch agrees with its spectra's results in
+    # any other batch to rounding, not to the bit.
+    ramp = _single_piece_ramp(batch_size, S) if prefetch and seed is not None and len(mine) > 3 * batch_size >= 12 else ()
+    if ramp:
+        starts = [int(x) for x in np.cumsum((0,) + ramp)]
+        bounds = [(starts[i], starts[i + 1]) for i in range(len(ramp))] + [
+            (start, min(start + batch_size, len(mine))) for start in range(starts[-1], len(mine), batch_size)]
 
     def sweep_and_finish(start, stop, sightlines, batch, z_dla, z_lls):
         """whatever happens in the sweeps or the bookkeeping, the batch's contexts and workspace go back"""

@@ -650,15 +650,18 @@ def test_batch_bookkeeping_is_the_per_spectrum_loop():
 
 def test_pipeline_starts_on_short_batches():
     """
-    the pipelined driver begins with a quarter and a half batch (the device waits for the first batch's preparation) --
-    where a quarter batch's launches are still single-piece (nb ceil(S / 8) > 2048 wave slots: a spectrum's numbers then do
-    not depend on the batch it rides in); every spectrum's row lands where the in-order run puts it
+    the pipelined driver begins with a shorter batch (the device waits for the first batch's preparation) -- only as short
+    as the launch planner itself keeps single-piece (asked through dlagp_plan_cut: a spectrum's numbers then do not depend on
+    the batch it rides in); every spectrum's row lands where the in-order run puts it
     """
-    from gpy_dla_detection_amd.run_bayes_select import process_qso
+    from gpy_dla_detection_amd.run_bayes_select import _single_piece_ramp, process_qso
 
-    S = 8208  # a quarter of a batch of 8: 2 x 1026 virtual blocks
+    assert _single_piece_ramp(32, 10000) == (16,)      # 8 spectra x 625 blocks would be cut in two pieces: 16 it is
+    assert _single_piece_ramp(64, 10000) == (16, 32)
+    assert _single_piece_ramp(8, 64) == ()             # few samples: every short batch is multi-piece
+    S = 10000
     learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(S)
-    spectra, z_qsos = list(spectra) * 10, [z + 0.001 * i for i, z in enumerate(list(z_qsos) * 10)]
+    spectra, z_qsos = list(spectra) * 40, [z + 0.001 * i for i, z in enumerate(list(z_qsos) * 40)]
 
     class Engine(RecordingEngine):
         def model_evidences(self, batch, z_lls, nhi_sub, z_dla, nhi_dla, max_dlas, min_z_separation, seed):
@@ -666,16 +669,16 @@ def test_pipeline_starts_on_short_batches():
             return (z_dla[:, 0].copy(),) + out[1:]  # a value that names the spectrum
 
     piped, in_order = Engine(), Engine()
-    a = process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=2, batch_size=8,
+    a = process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=2, batch_size=32,
                     engine=piped)
-    b = process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=2, batch_size=8,
+    b = process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=2, batch_size=32,
                     engine=in_order, prefetch=False)
-    assert sorted(t[1].shape[0] for t in piped.tables) == [2, 4, 8, 8, 8]
-    assert [t[1].shape[0] for t in in_order.tables] == [8, 8, 8, 6]
+    assert sorted(t[1].shape[0] for t in piped.tables) == [8, 16, 32, 32, 32]
+    assert [t[1].shape[0] for t in in_order.tables] == [32, 32, 32, 24]
     for name in ("log_likelihoods_no_dla", "min_z_dlas", "max_z_dlas", "sample_log_likelihoods_dla", "base_sample_inds"):
         np.testing.assert_array_equal(a[name], b[name], err_msg=name)
-    assert len(set(a["log_likelihoods_no_dla"])) == 30
-    # few samples: a quarter batch would be cut into pieces and round differently -- no short first batches
+    assert len(set(a["log_likelihoods_no_dla"])) == 120
+    # few samples: no short first batches
     learned, few, few_z, params, dla_samples, sub_samples = catalogue_inputs(64)
     few, few_z = list(few) * 10, [z + 0.001 * i for i, z in enumerate(list(few_z) * 10)]
     short = Engine()

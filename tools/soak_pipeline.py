@@ -46,7 +46,7 @@ def main():
         report["rounds"].append({"seconds": round(t, 3), "arrays_differing_from_round_0": differing,
                                  "hbm_growth_gb": round((free0 - torch.cuda.mem_get_info()[0]) / 2 ** 30, 3),
                                  "big_allocs": get_option("big_allocs"), "big_frees": get_option("big_frees")})
-    # In order on the calling thread the batches are 0-32, 32-64, ...; the pipeline's are 0-8, 8-24, 24-56, ...: every
+    # In order on the calling thread the batches are 0-32, 32-64, ...; the pipeline's are 0-16, 16-48, 48-80, ...: every
     # spectrum rides in a different batch.  On batches a block of 16 samples is one wave's work from the first pixel to the
     # log-likelihood (single-piece plans), so its result does not depend on what else is in the launch: equal to the last bit.
     ordered = process_qso(spectra[:256], z_qsos[:256], params, FixedPrior(), dla, sub, learned, batch_size=32, prefetch=False)
