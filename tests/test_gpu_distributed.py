@@ -186,6 +186,18 @@ if world > 1:
     ev1, ll1, base1 = parallel.sweep_sharded_samples_device(batch, g["dla_sample_z"][None, :], nhi, max_dlas,
                                                             float(g["dla_min_z_separation"]), uniforms)
     np.savez(os.path.join(out, "local_rank%d.npz" % rank), ev=ev1, ll=ll1, base=base1)
+# the catalogue driver sharded over the ranks: the per-quasar values of the whole catalogue on every rank after ONE all-gather
+# (RCCL when the group is nccl), the per-sample arrays of a rank's own quasars written as its shard
+from gpy_dla_detection_amd import run_bayes_select as rbs
+from tests.test_host_logic import FixedPrior, catalogue_inputs
+learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(128)
+spectra, z_qsos = list(spectra) * 3, [z + 0.001 * i for i, z in enumerate(list(z_qsos) * 3)]
+res = rbs.process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=3, batch_size=4,
+                      device=0, rank=rank, world_size=world)
+if world > 1:
+    assert res["sample_log_likelihoods_dla"].shape[0] == len(res["local_rows"]) < len(spectra)
+    assert res["log_posteriors_dla"].shape == (len(spectra), 3)
+rbs.write_results(res, os.path.join(out, "catalogue.h5"))
 with open(os.path.join(out, "runtime_rank%d.txt" % rank), "w") as f:
     f.write("\n".join(_lib.hip_runtime_copies()))
 dist.barrier()
@@ -228,3 +240,19 @@ def test_sharded_sweeps_through_a_process_group(tmp_path, backend, nproc):
             np.testing.assert_allclose(local["ev"][0], g["dla_evidences"], rtol=1e-9)
         copies = (tmp_path / ("runtime_rank%d.txt" % rank)).read_text().split()
         assert len(copies) == 1, copies  # torch (RCCL) and the library share one HIP runtime
+    # the sharded catalogue run: main file + shards merge into the single-process result (batched differently: rounding)
+    from gpy_dla_detection_amd import run_bayes_select as rbs
+    from tests.test_host_logic import FixedPrior, catalogue_inputs
+
+    learned, spectra, z_qsos, params, dla_samples, sub_samples = catalogue_inputs(128)
+    spectra, z_qsos = list(spectra) * 3, [z + 0.001 * i for i, z in enumerate(list(z_qsos) * 3)]
+    alone = rbs.process_qso(spectra, z_qsos, params, FixedPrior(), dla_samples, sub_samples, learned, max_dlas=3, batch_size=4)
+    main = str(tmp_path / "catalogue.npz")
+    merged = (rbs.merge_results(main, [str(tmp_path / ("catalogue.rank%d.npz" % r)) for r in range(nproc)]) if nproc > 1
+              else rbs._read_one(main))
+    assert sorted(merged) == sorted(alone)
+    np.testing.assert_array_equal(merged["base_sample_inds"], alone["base_sample_inds"])
+    assert merged["base_sample_inds"].dtype == np.int32
+    for name, value in alone.items():
+        if np.asarray(value).dtype.kind == "f":
+            np.testing.assert_allclose(merged[name], value, rtol=1e-10, equal_nan=True, err_msg=name)
