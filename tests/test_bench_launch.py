@@ -167,7 +167,7 @@ def test_measured_traffic_belongs_to_the_workload_it_was_measured_on(bench, tmp_
 
 
 def test_design_tables_render_from_the_committed_profiles():
-    """DESIGN.md section 7 is generated: tools/design_table.py turns profiles/r05_* into its two tables, and every figure of the
+    """DESIGN.md section 7 is generated: tools/design_table.py turns profiles/r06_* into its two tables, and every figure of the
     main table that DESIGN.md prints comes out of that run (numbers traceable to the profiles)"""
     import re
     import subprocess
@@ -175,7 +175,7 @@ def test_design_tables_render_from_the_committed_profiles():
 
     from tests.conftest import REPO
 
-    res = subprocess.run([sys.executable, os.path.join(REPO, "tools", "design_table.py"), os.path.join(REPO, "profiles"), "r05"],
+    res = subprocess.run([sys.executable, os.path.join(REPO, "tools", "design_table.py"), os.path.join(REPO, "profiles"), "r06"],
                          capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr[-2000:]
     rows = [line for line in res.stdout.splitlines() if line.startswith("| ")]

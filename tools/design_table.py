@@ -11,7 +11,10 @@ root, tag = sys.argv[1], sys.argv[2]
 def load(name):
     path = os.path.join(root, "%s_%s" % (tag, name)) if root.endswith("profiles") else os.path.join(root, name)
     text = open(path).read().strip()
-    return json.loads(text.splitlines()[-1]) if not text.startswith("[") else json.loads(text)
+    try:
+        return json.loads(text)  # one JSON document, possibly indented
+    except ValueError:
+        return json.loads(text.splitlines()[-1])  # a tool's output with its one JSON line last
 
 
 def kernel_avg(csv_name, needle):
@@ -24,9 +27,10 @@ def kernel_avg(csv_name, needle):
 
 b = load("bench.json")
 r = b["roofline"]
-print("| quantity | round 5 | file |")
+print("| quantity | round %s | file |" % tag.lstrip("r0"))
 print("|---|---|---|")
-print("| step, configs[1] | %.4f ms → **%.1f M evals/s** | `%s_bench.json` |" % (b["ms_per_step"], b["value"] / 1e6, tag))
+print("| step, configs[1] | %.4f ms → **%.1f M evals/s**%s | `%s_bench.json` |"
+      % (b["ms_per_step"], b["value"] / 1e6, (" (`step_frac` %.1f %% of FP64 peak)" % (100 * r["step_frac"])) if "step_frac" in r else "", tag))
 avg, calls = kernel_avg("kernel_stats.csv", "accumulate_mfma<3, true, false, 0, 1, false, false")
 print("| accumulate_mfma, configs[1] | %.4f ms by HIP events → %.1f TFLOP/s = **%.1f %%** of 78.6 (`frac_cold` %.1f %%); %.4f ms avg over %d launches under rocprofv3 | `%s_bench.json`, `%s_kernel_stats.csv` |"
       % (r["kernel_ms"], r["achieved"], 100 * r["frac"], 100 * r["frac_cold"], (avg or 0) / 1e3, calls, tag, tag))
@@ -63,8 +67,16 @@ try:
 except (OSError, KeyError):
     pass
 x = load("route_a.json")
-print("| route A (reference driver loop, imports swapped), 256 spectra | **%.2f ms per spectrum** (%.0f spectra/s) | `%s_route_a.json` |"
-      % (x["ms_per_spectrum"], x["spectra_per_s"], tag))
+if "kernel_ms_per_spectrum" in x:  # round 6 on: with the kernels' own time from the rocprofv3 run of the same command
+    fam = x["kernel_us_per_spectrum_by_family"]
+    print("| route A (reference driver loop, imports swapped), 256 spectra, n median %.0f | **%.2f ms per spectrum** (%.0f spectra/s); kernels %.3f ms per spectrum = **%.1f %%** of FP64 peak over their own time (accumulate %.0f µs at %.1f %%, level finish %.0f, finalisation %.0f, transfers %.0f, set-up %.0f, null %.0f); %.0f launches per spectrum | `%s_route_a.json`, `%s_kernel_stats_route_a.csv` |"
+          % (x["kept_pixels"]["median"], x["ms_per_spectrum"], x["spectra_per_s"], x["kernel_ms_per_spectrum"], 100 * x["kernel_frac_of_fp64_peak"],
+             fam.get("accumulate_mfma", 0), 100 * x["accumulate_frac_of_fp64_peak"], fam.get("level finish", 0), fam.get("finalisation", 0),
+             fam.get("transfers (copy_segments + blit copies)", 0), fam.get("set-up", 0), fam.get("null model (generic kernel)", 0),
+             x["launches_per_spectrum"], tag, tag))
+else:
+    print("| route A (reference driver loop, imports swapped), 256 spectra | **%.2f ms per spectrum** (%.0f spectra/s) | `%s_route_a.json` |"
+          % (x["ms_per_spectrum"], x["spectra_per_s"], tag))
 cb = b["cpu_baseline"]
 print("| CPU baseline (oracle, %d pinned processes × 1 BLAS thread) | **%.1f k evals/s** (chunks %s; ramp %s); 1 process %.1f k; default threads %.1f k on %s threads | `%s_bench.json` |"
       % (cb["cores"], cb["value"] / 1e3, " / ".join("%.1f" % (v / 1e3) for v in cb["chunk_rates"]),
