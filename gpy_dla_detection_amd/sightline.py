@@ -439,7 +439,7 @@ class DeviceBatch:
         if max_dlas < 2:
             return evidences, sample_ll, base
         ties = self.resample_ties(max_dlas)
-        self.last_ties = ties
+        self.last_ties, self.last_changed = ties, 0
         if ties.any():
             self.last_changed = settle_near_ties(
                 ties, evidences, sample_ll, base, uniforms, sample_z, sample_nhi, min_z_separation,
