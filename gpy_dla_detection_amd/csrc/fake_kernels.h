@@ -8,7 +8,8 @@ namespace dlagp {
 inline LineConstants DLAGP_LINES;
 inline unsigned long long DLAGP_STAMPS[8];
 template <bool ROW16, bool NATIVE>
-void finalize_rank20(const double *, int, long, long, const SightlineDev *, double *, int *, const unsigned char *) {}
+void finalize_rank20(const double *, int, long, long, const SightlineDev *, double *, int *, const unsigned char *, double * = nullptr,
+                     long = 0) {}  // the real kernel's parameter list (kernels_common.h): the host side takes its address
 template <bool CUM_IN_LDS>
 void level_finish_fused(LevelArgs) {}
 inline void level_weights(LevelArgs) {}
