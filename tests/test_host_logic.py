@@ -1077,6 +1077,31 @@ def test_native_data_half_is_prepare_data_bit_for_bit():
     assert rc == _lib.DLAGP_EINVAL and "modelled window" in _lib.last_error()
 
 
+def test_native_data_half_matches_reference_golden_set_data():
+    """the same entry against golden set G7 -- the reference's own NullGP.set_data (null_gp.py:117-177) on a raw spectrum --
+    directly: every array identical (the padding from NumPy's log10 / power, as the binding supplies it)"""
+    from gpy_dla_detection_amd import _lib
+    from gpy_dla_detection_amd.sightline import numpy_padding, prepare_params
+
+    g = load_golden("set_data.npz")
+    z_qso, rest, flux, nv, mask, *_ = raw_spectrum_and_model()
+    params = Parameters()
+    observed = params.observed_wavelengths(rest, z_qso)  # the native entry starts from read_spec's observed wavelengths
+    if not np.array_equal(params.emitted_wavelengths(observed, z_qso), rest):
+        pytest.skip("this fixture's rest wavelengths are not the image of an observed grid under / (1 + z)")
+    lib, struct = _lib.load(), prepare_params(params)
+    rc, first = native_prepare_spectrum(lib, struct, observed, flux, nv, mask, z_qso)
+    assert rc == 0
+    rc, got = native_prepare_spectrum(lib, struct, observed, flux, nv, mask, z_qso,
+                                      pad=numpy_padding(3, params.pixel_spacing, first["edges"][None, :])[0])
+    assert rc == 0
+    for name in ("x", "y", "v", "padded_wavelengths", "unmasked_wavelengths", "this_wavelengths"):
+        assert same_bits(got[name], g[name]), name
+    assert same_bits(got["normalization_median"], g["normalization_median"])
+    assert same_bits(got["bounds"][:2], [g["min_z_dla"], g["max_z_dla"]])
+    assert np.array_equal(got["keep"], ~mask[g["ind_unmasked"]])
+
+
 def test_native_sample_tables_are_the_holders_own():
     """z_min + (z_max - z_min) * offsets in C (prepare_host.h sample_redshifts) == samples.DLASamples.sample_z_dlas"""
     import ctypes
