@@ -335,7 +335,7 @@ def settle_near_ties(ties, evidences, sample_ll, base, uniforms, sample_z, sampl
     Makes a device sweep's `base_sample_inds` np.random.choice's by construction.  The library's cdf and NumPy's differ by
     rounding (~1e-16), so the two can disagree on an index only where a uniform lies that close to a cdf step; the library
     counts, per sightline and level, the searches that ended within 1e-11 of a step (`ties`, dlagp_batch_resample_ties).
-    For those levels -- about two in a thousand at S = 10 000 -- the indices are recomputed here with NumPy's own arithmetic
+    For those levels -- at most two in a thousand at S = 10 000 (2 S margin per search when every sample carries weight) -- the indices are recomputed here with NumPy's own arithmetic
     (`exact_choice`) from the level's likelihoods as the device returned them.  They have never differed outside tests
     that plant uniforms on the steps; if they do, the sightline's remaining levels are redone from that level on with the
     host half of every level in NumPy (`level_eval(b, z (S, kd), nhi (S, kd)) -> (S,)` evaluates on the device).

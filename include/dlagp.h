@@ -291,7 +291,7 @@ int dlagp_batch_null(dlagp_batch *batch, double *out);
  * DLAGP_TIE_MARGIN = 1e-11 of the step on either side of its answer is counted per (sightline, level);
  * dlagp_batch_resample_ties returns the counts of the batch's most recent sweep, and a caller that wants the reference's
  * indices to the last bit recomputes the levels with a non-zero count with NumPy's own arithmetic (the Python classes do:
- * gpy_dla_detection_amd/sightline.py `settle_near_ties`; about two levels in a thousand at S = 10 000, and the recomputed
+ * gpy_dla_detection_amd/sightline.py `settle_near_ties`; at most two levels in a thousand at S = 10 000 -- fewer the more the weights concentrate -- and the recomputed
  * indices have never differed outside planted tests).
  */
 int dlagp_batch_sweep(dlagp_batch *batch, int64_t S, int max_dlas, const double *sample_z,
