@@ -155,6 +155,13 @@ struct LevelArgs {
     int *ties;
 };
 
+// Two level finishes in one pair of launches: the rows of the grid beyond `nb_first` sightlines belong to `second` (the
+// one-absorber model that rode in level 1's pair launch: evidence only, its own buffers).
+struct LevelArgsTwo {
+    LevelArgs first, second;
+    int nb_first;
+};
+
 #if defined(__HIPCC__)
 __device__ __forceinline__ long sample_point(const SampleSource &src, long b, long s, int j, long S, int kd) {
     if (src.pair_S) {  // pair launch: the point behind virtual sample s (rows beyond the last point repeat it; never stored)

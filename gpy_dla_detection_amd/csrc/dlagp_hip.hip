@@ -355,6 +355,7 @@ struct Workspace {
     DeviceBuffer cache;  // profile cache of the multi-level sweep, [nb][S][max n_slots]
     DeviceBuffer sub_z, sub_nhi, sub_evidences, sub_ll;  // the one-absorber model of dlagp_batch_model_evidences
     DeviceBuffer sub_level_ll, sub_alive;  // pair launches: the one-absorber model's raw level and its per-sightline flags
+    DeviceBuffer sub_cdf, sub_level_x;     // ... and its own weights and exchange: its level finish rides beside the sweep's level 1
     PinnedBuffer stage;           // host staging of the host-pointer entry points
     DeviceBuffer pack;            // ... and its device-side twin: small transfers cross the bus as one copy (Transfers)
     void release() {
@@ -382,6 +383,8 @@ struct Workspace {
         sub_ll.release();
         sub_level_ll.release();
         sub_alive.release();
+        sub_cdf.release();
+        sub_level_x.release();
     }
 };
 
@@ -1217,7 +1220,9 @@ static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, c
 static Option g_opt_level_spread = 1;
 static Option g_opt_level_search_groups = 16;  // workgroups per sightline that share the searches of the spread form
 static Option g_last_level_spread = 0;
-static int launch_level_finish(int nb, hipStream_t stream, LevelArgs a) {
+// `also`: a second level finish of the same shape (S, sightlines) to run in the same launches -- the paired one-absorber
+// model's beside the sweep's level 1 (two launches less per model selection); the one-workgroup forms run it separately.
+static int launch_level_finish(int nb, hipStream_t stream, LevelArgs a, const LevelArgs *also = nullptr) {
     const long S = a.S;
     const size_t lds_bytes = (size_t)S * sizeof(double);
     const int lds_limit = 144000;  // beside the kernels' 16.7 KB of static LDS: S <= 18 000
@@ -1228,7 +1233,21 @@ static int launch_level_finish(int nb, hipStream_t stream, LevelArgs a) {
     // beyond the default limit (64 KB in all) the attribute is needed -- per device, so it is set at every such launch
     // rather than remembered (a process may drive several devices)
     const bool big_lds = resamples && lds_bytes > 46 * 1024;
-    if (spread) {
+    if (!spread && also) {
+        int rc = launch_level_finish(nb, stream, *also);
+        if (rc) return rc;
+        also = nullptr;
+    }
+    if (spread && also) {
+        const LevelArgsTwo both{a, *also, nb};
+        hipLaunchKernelGGL(level_weights_two, dim3(DLAGP_LEVEL_LANES / 64, 2u * (unsigned)nb), dim3(64), 0, stream, both);
+        if (big_lds)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(level_resample_two),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit));
+        const int groups = resamples ? (int)std::max<int64_t>(1, std::min<int64_t>(g_opt_level_search_groups, 64)) : 1;
+        hipLaunchKernelGGL(level_resample_two, dim3((unsigned)groups, 2u * (unsigned)nb), dim3(DLAGP_LEVEL_SEARCH_THREADS),
+                           resamples ? (uint32_t)lds_bytes : 0u, stream, both);
+    } else if (spread) {
         hipLaunchKernelGGL(level_weights, dim3(DLAGP_LEVEL_LANES / 64, (unsigned)nb), dim3(64), 0, stream, a);
         if (big_lds)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(level_resample),
@@ -1281,6 +1300,8 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     if ((rc = grow(g, ws.ties, (size_t)nb * std::max(max_dlas - 1, 1) * sizeof(int)))) return rc;
     if (pair && (rc = grow(g, ws.sub_level_ll, rows * sizeof(double)))) return rc;
     if (pair && (rc = grow(g, ws.sub_alive, (size_t)(nb + 1) * sizeof(int)))) return rc;
+    if (pair && (rc = grow(g, ws.sub_cdf, rows * sizeof(double)))) return rc;
+    if (pair && (rc = grow(g, ws.sub_level_x, (size_t)nb * DLAGP_LEVEL_EXCH * sizeof(double)))) return rc;
     const long n_ll = (long)rows * max_dlas, n_base = (long)rows * (max_dlas - 1);
     g.last_stream = stream;  // the fills below already use the group's scratch
     g.launched = true;
@@ -1371,18 +1392,21 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
             if (rc) return rc;
             first = false;
         }
-        if (pair && level == 0 && launch) {
-            const SampleSource sub0{d_sample_z, pair->d_nhi, nullptr, 1, (long)pair->nhi_stride, 0, nullptr, nullptr, 0, 0, 0, 0, 0};
-            LevelArgs sub_level{ws.sub_level_ll.as<const double>(), (long)S, 0, 1, sub0, min_z_separation, log_s, nullptr,
-                                pair->d_sample_ll, pair->d_evidences, nullptr, ws.cdf.as<double>(), ws.level_x.as<double>(),
-                                ws.sub_alive.as<int>(), ws.status.as<const int>(), ws.alive.as<int>() + nb, nullptr};
-            if ((rc = launch_level_finish(nb, stream, sub_level))) return rc;
-        }
-        if (phase == SWEEP_START) return DLAGP_OK;  // level 1's own evidence and resampling wait for the uniforms
+        if (phase == SWEEP_START) return DLAGP_OK;  // level 1's evidence and resampling wait for the uniforms -- and the paired
+                                                    // model's level finish waits with them: it rides in the same launches
         LevelArgs this_level{ws.level_ll.as<const double>(), (long)S, level, max_dlas, src0, min_z_separation, log_s, d_uniforms,
                              d_sample_ll, d_evidences, d_base, ws.cdf.as<double>(), ws.level_x.as<double>(), ws.alive.as<int>(),
                              ws.status.as<const int>(), ws.alive.as<int>() + nb, ws.ties.as<int>()};
-        if ((rc = launch_level_finish(nb, stream, this_level))) return rc;
+        if (pair && level == 0) {
+            // the one-absorber model of the pair launch: one level, no resampling, its own weights / exchange / alive flags
+            // (the launch's non-PD flag is the sweep's: this_level accumulates it)
+            const SampleSource sub0{d_sample_z, pair->d_nhi, nullptr, 1, (long)pair->nhi_stride, 0, nullptr, nullptr, 0, 0, 0, 0, 0};
+            const LevelArgs sub_level{ws.sub_level_ll.as<const double>(), (long)S, 0, 1, sub0, min_z_separation, log_s, nullptr,
+                                      pair->d_sample_ll, pair->d_evidences, nullptr, ws.sub_cdf.as<double>(),
+                                      ws.sub_level_x.as<double>(), ws.sub_alive.as<int>(), ws.status.as<const int>(),
+                                      ws.alive.as<int>() + nb, nullptr};
+            if ((rc = launch_level_finish(nb, stream, this_level, &sub_level))) return rc;
+        } else if ((rc = launch_level_finish(nb, stream, this_level))) return rc;
     }
     return DLAGP_OK;
 }

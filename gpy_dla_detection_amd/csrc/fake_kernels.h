@@ -18,12 +18,18 @@ inline void level_resample(LevelArgs) {}
 inline void mark_arg(const CopyTable &t, fake::Stream *s, uint64_t ticket) {
     for (int i = 0; i < t.count; ++i) fake::mark(reinterpret_cast<const void *>(t.seg[i].device_ptr), s, ticket);
 }
+inline void level_weights_two(LevelArgsTwo) {}
+inline void level_resample_two(LevelArgsTwo) {}
 // what a level-finish launch touches (fake::launch marks pointer arguments; this struct travels by value)
 inline void mark_arg(const LevelArgs &a, fake::Stream *s, uint64_t t) {
     for (const void *p : {(const void *)a.ll, (const void *)a.uniforms, (const void *)a.sample_ll, (const void *)a.evidences,
                           (const void *)a.base, (const void *)a.weights, (const void *)a.exch, (const void *)a.alive,
                           (const void *)a.status, (const void *)a.ties})
         fake::mark(p, s, t);
+}
+inline void mark_arg(const LevelArgsTwo &p, fake::Stream *s, uint64_t t) {
+    mark_arg(p.first, s, t);
+    mark_arg(p.second, s, t);
 }
 inline void accumulate_generic() {}
 inline void absorption_generic() {}

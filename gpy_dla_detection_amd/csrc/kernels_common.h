@@ -1247,6 +1247,27 @@ __global__ __launch_bounds__(DLAGP_LEVEL_SEARCH_THREADS) void level_resample(Lev
                                                                          gridDim.x, cum_lds, sh);
 }
 
+// ---- two level finishes side by side (LevelArgsTwo): the same two kernels, the grid's rows dealt to two argument sets
+__global__ __launch_bounds__(64) void level_weights_two(LevelArgsTwo p) {
+    const bool second = (int)blockIdx.y >= p.nb_first;
+    const LevelArgs &a = second ? p.second : p.first;
+    const long b = (long)blockIdx.y - (second ? p.nb_first : 0);
+    if (!second) lvl::begin(a, b, blockIdx.x == 0, threadIdx.x);
+    if (!a.alive[b]) return;
+    lvl::lane_weights<12>(a, b, (int)blockIdx.x * 64 + (int)threadIdx.x);
+}
+
+__global__ __launch_bounds__(DLAGP_LEVEL_SEARCH_THREADS) void level_resample_two(LevelArgsTwo p) {
+    extern __shared__ double cum_lds[];
+    __shared__ lvl::ResampleShared sh;
+    const bool second = (int)blockIdx.y >= p.nb_first;
+    const LevelArgs &a = second ? p.second : p.first;
+    const long b = (long)blockIdx.y - (second ? p.nb_first : 0);
+    if (!a.alive[b]) return;
+    lvl::resample<false, DLAGP_LEVEL_LANES / DLAGP_LEVEL_SEARCH_THREADS>(a, b, threadIdx.x, DLAGP_LEVEL_SEARCH_THREADS, blockIdx.x,
+                                                                         gridDim.x, cum_lds, sh);
+}
+
 // Start of an occupation sweep in one launch (reference dla_gp.py:112-119: NaN-initialised likelihoods and evidences,
 // zeroed base indices; plus this library's flags): five fill launches before, 20 us of a one-spectrum call.
 __global__ void sweep_init(double *__restrict__ sample_ll, long n_ll, double *__restrict__ evidences, long n_ev,
