@@ -346,6 +346,7 @@ struct Workspace {
     DeviceBuffer part;    // partial rows [nsplit][rows][row_width]
     DeviceBuffer part2;   // ranks above 20 on the MFMA path: the column groups' sums regrouped into one row per block
     DeviceBuffer status;  // int flag raised by finalize on a non-PD pivot
+    DeviceBuffer null_part, null_status;  // the same two for the null model's side launch (LaunchGroup::side_stream)
     DeviceBuffer z, nhi, out;  // staging for the host-pointer entry points
     // device-resident occupation sweep: raw level log-likelihoods, cdf scratch, per-sightline alive flag,
     // and staging of its host-pointer variant
@@ -374,6 +375,8 @@ struct Workspace {
         part.release();
         part2.release();
         status.release();
+        null_part.release();
+        null_status.release();
         z.release();
         nhi.release();
         out.release();
@@ -428,6 +431,10 @@ struct LaunchGroup {
     int max_entries = 0, max_npad = 0;
     hipStream_t last_stream = nullptr;  // stream of the most recent launch (drained before buffers are recycled)
     bool launched = false;
+    // the null model of a model-evidence call runs BESIDE the sweeps, on the calling thread's transfer stream, with partial
+    // sums and a status flag of its own (ws.null_part, ws.null_status): it depends on nothing the sweeps produce
+    hipStream_t side_stream = nullptr;
+    bool side_launched = false;
     bool mfma_ok = false;
     int col_groups = 1;         // MFMA path: column groups per block (1 for rank <= 20, see kernels_mfma.h)
     bool grid_uniform = false;  // every member's wavelength grid is log-uniform (core patch eligible)
@@ -448,6 +455,8 @@ struct LaunchGroup {
     void drain() {
         if (launched) (void)hipStreamSynchronize(last_stream);
         launched = false;
+        if (side_launched) (void)hipStreamSynchronize(side_stream);
+        side_launched = false;
         for (auto &p : parts) p->drain();
     }
     void release() {
@@ -536,6 +545,7 @@ struct dlagp_batch {
         double min_z_separation = 0.0;
         size_t stage_used = 0;          // staging bytes of the first phase: the second phase's lie behind them
         hipStream_t stream = nullptr;   // the calling thread's kernel stream: _finish must come from the same thread
+        bool null_on_side = false;      // the null model was launched by _start beside the sweeps (launch_null_side)
         bool pair = false;              // the sub-DLA sweep rode in level 1's launch (pair launch): _finish resumes that sweep
         int64_t sub_nhi_stride = 0;
         int cached = 0;                 // ... and whether it keeps level-1 profiles (decided in _start)
@@ -1182,6 +1192,51 @@ struct Transfers {
         return DLAGP_OK;
     }
 };
+
+// The null model of every member (NullGP.log_model_evidence, reference null_gp.py:294-305) on `side`, beside whatever the
+// group has on its kernel stream: what launch_one does for kd == 0 -- the generic kernel on one "sample" per sightline, four
+// pixel ranges each, and its finalisation -- with partial sums and a non-PD flag of its own.  The same numbers, bit for bit.
+static Option g_opt_null_side = 1;  // 0: the null model always as the call's last launch on the kernel stream
+static int launch_null_side(LaunchGroup &g, double *d_out, hipStream_t side) {
+    Workspace &ws = g.ws;
+    const int nb = (int)g.ctxs.size();
+    const int nparts = 4;
+    const size_t nblocks = (size_t)nb;  // one block of 16 samples (one of them real) per sightline
+    int rc;
+    if (g.side_launched) {  // an earlier side launch still in flight (a call that failed or was cancelled before its downloads)
+        HIP_TRY(hipStreamSynchronize(g.side_stream));
+        g.side_launched = false;
+    }
+    if ((rc = ws.null_part.reserve((size_t)nparts * nblocks * g.row_width * 16 * sizeof(double)))) return rc;
+    if ((rc = ws.null_status.reserve(sizeof(int)))) return rc;
+    const SightlineDev *table = g.d_table.as<SightlineDev>();
+    const int lds_entries = std::max(g.max_entries, g.max_npad);
+    const int lds_pixels = g.max_npad;
+    const size_t lds_bytes = (size_t)(lds_entries + lds_pixels + DLAGP_MAX_LINES + 1 + 8) * sizeof(double);
+    if (lds_bytes > 160 * 1024)
+        return fail(DLAGP_EINVAL, "sightline too long for the generic kernel: %zu B of LDS needed", lds_bytes);
+    if (lds_bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(accumulate_generic),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    g.side_stream = side;
+    g.side_launched = true;
+    const SampleSource none{nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0};
+    int *status = ws.null_status.as<int>();
+    hipLaunchKernelGGL(accumulate_generic, dim3(1u, (unsigned)nb, (unsigned)nparts), dim3(DLAGP_GENERIC_THREADS), (uint32_t)lds_bytes,
+                       side, table, 1L, 0, none, ws.null_part.as<double>(), status, lds_entries, lds_pixels, 0);
+    HIP_TRY(hipGetLastError());
+    if (g.k == DLAGP_FIN_K) {
+        const bool row16 = (int64_t)nblocks <= g_opt_finalize_row16_blocks;
+        auto fin = row16 ? finalize_rank20<true, false> : finalize_rank20<false, false>;
+        hipLaunchKernelGGL(fin, dim3((unsigned)nblocks), dim3(DLAGP_FIN_THREADS), DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double), side,
+                           ws.null_part.as<double>(), nparts, (long)nb, 1L, table, d_out, status, (const unsigned char *)nullptr,
+                           (double *)nullptr, 0L);
+    } else {
+        launch_finalize_general(side, ws.null_part.as<const double>(), nparts, (long)nb, 1L, table, d_out, status, nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    return DLAGP_OK;
+}
 
 // host-pointer wrapper: stage, launch, copy back, report non-PD as DLAGP_ELINALG
 static int sweep_from_host(LaunchGroup &g, int64_t S, int kd, const double *z, const double *nhi, double *out) {
@@ -2535,6 +2590,14 @@ int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dla
     const size_t second_phase = (n_base + 2 * nb + rows + nb * max_dlas + rows * max_dlas) * sizeof(double) +
                                 n_base * sizeof(int32_t) + 2 * sizeof(int) + nb * max_dlas * sizeof(int32_t) + 16 * 256;
     if ((rc = tr.reserve(second_phase)) || (rc = tr.run_uploads())) return rc;
+    // the null model of every member, beside the sweeps: on this thread's transfer stream (behind the uploads just queued, in
+    // front of _finish's downloads), with buffers of its own -- 30 us of a one-spectrum call that nothing has to wait for
+    // Only for a few sightlines (a caller that works one spectrum at a time): beside OTHER batches' sweeps, as in the
+    // catalogue pipeline, the generic kernel's four-wave workgroups would wait for four free wave slots on one compute unit
+    // (host_shared.h, DLAGP_SETUP_THREADS) and hold this batch's downloads back; there the null model stays the call's
+    // last launch on the kernel stream (45 us of a 12 ms batch).
+    batch->pending.null_on_side = g_opt_null_side != 0 && nb <= 4;
+    if (batch->pending.null_on_side && (rc = launch_null_side(g, ws.out.as<double>(), tr.transfer))) return rc;
     batch->pending.pair = pair;
     batch->pending.sub_nhi_stride = sub_nhi_stride;
     if (pair) {
@@ -2589,7 +2652,7 @@ int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniform
     tr.download(base_inds, ws.base.ptr, n_base * sizeof(int32_t));
     int status[2] = {0, 0};
     tr.download(&status[0], ws.alive.as<int>() + nb, sizeof(int));
-    tr.download(&status[1], ws.status.ptr, sizeof(int));
+    tr.download(&status[1], batch->pending.null_on_side ? ws.null_status.ptr : ws.status.ptr, sizeof(int));
     ties_come_back(batch, tr, max_dlas);
     const size_t capacity = ws.stage.bytes;
     if ((rc = tr.reserve())) return rc;
@@ -2607,12 +2670,15 @@ int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniform
                           ws.sample_ll.as<double>(), ws.base.as<int>(), stream, /*keep_sticky_flag=*/true);
     }
     if (rc) return rc;
-    // the null model last: its launch leaves its own flag in ws.status, which the sweeps' launches would reset
-    rc = launch_sweep(g, 1, 0, SampleSource{nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0},
-                      ws.out.as<double>(), stream);
-    if (rc) return rc;
+    if (!batch->pending.null_on_side) {
+        // the null model last: its launch leaves its own flag in ws.status, which the sweeps' launches would reset
+        rc = launch_sweep(g, 1, 0, SampleSource{nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0},
+                          ws.out.as<double>(), stream);
+        if (rc) return rc;
+    }  // (else: launched by _start on the transfer stream, which the downloads below follow on)
     if ((rc = tr.run_downloads())) return rc;
     g.launched = false;  // as in sweep_from_host
+    g.side_launched = false;  // run_downloads waited for the transfer stream
     for (auto &p : g.parts) p->launched = false;
     if (status[0] || status[1]) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
     return DLAGP_OK;
@@ -2827,6 +2893,7 @@ int dlagp_set_option(const char *name, int64_t value) try {
     else if (!strcmp(name, "pair_models")) g_opt_pair_models = value != 0;
     else if (!strcmp(name, "pack_setup_uploads")) g_opt_pack_setup_uploads = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "pack_transfers")) g_opt_pack_transfers = value != 0;
+    else if (!strcmp(name, "null_side")) g_opt_null_side = value != 0;
     else if (!strcmp(name, "level_spread")) g_opt_level_spread = value != 0;
     else if (!strcmp(name, "level_search_groups")) g_opt_level_search_groups = value < 1 ? 1 : (value > 64 ? 64 : value);
     else return fail(DLAGP_EINVAL, "unknown option '%s'", name);
@@ -2878,6 +2945,7 @@ int dlagp_get_option(const char *name, int64_t *value) try {
     else if (!strcmp(name, "last_sweep_paired")) *value = g_last_sweep_paired;
     else if (!strcmp(name, "pack_setup_uploads")) *value = g_opt_pack_setup_uploads;
     else if (!strcmp(name, "pack_transfers")) *value = g_opt_pack_transfers;
+    else if (!strcmp(name, "null_side")) *value = g_opt_null_side;
     else if (!strcmp(name, "level_spread")) *value = g_opt_level_spread;
     else if (!strcmp(name, "level_search_groups")) *value = g_opt_level_search_groups;
     else if (!strcmp(name, "last_level_spread")) *value = g_last_level_spread;

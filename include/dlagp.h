@@ -448,6 +448,10 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     "pack_transfers" (1 = the small host <-> device transfers of a host-pointer call, up to 8 MB in all,
  *                     cross the bus as ONE copy each way and a kernel distributes / collects the pieces -- a dozen dependent
  *                     4 us copies per one-spectrum model selection otherwise; 0 = one copy per array; default 1),
+ *                     "null_side" (1 = in dlagp_batch_model_evidences* on a batch of up to four sightlines the null model's
+ *                     two kernels run beside the sweeps, on the calling thread's transfer stream with buffers of their own,
+ *                     instead of as the call's last launch: -4.5 % wall per one-spectrum model selection; identical results;
+ *                     default 1),
  *                     "pack_setup_uploads" (the same for the arrays of a context's set-up: 0 = one copy per array, 1 = together,
  *                     2 = together when the device's kernel stream is idle at that moment -- beside a running sweep the single
  *                     copies get through sooner than a kernel finds a wave slot; default 2)
