@@ -22,6 +22,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <memory>
@@ -426,6 +427,10 @@ struct LaunchGroup {
     int device = 0;
     std::vector<dlagp_ctx *> ctxs;
     DeviceBuffer d_table;  // SightlineDev[nb]
+    // a batch of ONE member reads the member's own table (its context's group holds the same descriptor at position 0): no
+    // second upload, no wait for it.  Not owned; a batch whose member has been destroyed no longer launches (batch_alive).
+    const SightlineDev *table_alias = nullptr;
+    const SightlineDev *table() const { return table_alias ? table_alias : static_cast<const SightlineDev *>(d_table.ptr); }
     int k = 0, row_width = 0, num_lines = 0;
     bool broadening = true;
     int max_entries = 0, max_npad = 0;
@@ -466,6 +471,7 @@ struct LaunchGroup {
         for (auto &p : parts) p->release();
         parts.clear();
         d_table.release();
+        table_alias = nullptr;
         ws.release();
         for (auto &kv : plans) kv.second->release();
         plans.clear();
@@ -545,7 +551,8 @@ struct dlagp_batch {
         double min_z_separation = 0.0;
         size_t stage_used = 0;          // staging bytes of the first phase: the second phase's lie behind them
         hipStream_t stream = nullptr;   // the calling thread's kernel stream: _finish must come from the same thread
-        bool null_on_side = false;      // the null model was launched by _start beside the sweeps (launch_null_side)
+        bool null_on_side = false;      // the null model runs beside the sweeps (launch_null_side) ...
+        bool null_launched = false;     // ... and has been enqueued (by _start, or by _finish beside the deepest level's finish)
         bool pair = false;              // the sub-DLA sweep rode in level 1's launch (pair launch): _finish resumes that sweep
         int64_t sub_nhi_stride = 0;
         int cached = 0;                 // ... and whether it keeps level-1 profiles (decided in _start)
@@ -571,7 +578,9 @@ static plan::Options planner_options(int column_groups = 1) {
     return opt;
 }
 
-static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
+// `defer_upload`: a NEW plan's bytes are handed to the caller instead of being copied here -- it sends them to (*out)->blob.ptr
+// with the call's other uploads, in front of the launch (dlagp_batch_model_evidences_start); left empty when the plan existed.
+static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out, std::vector<char> *defer_upload = nullptr) {
     const LaunchGroup::PlanKey key(S, g_opt_pixel_splits, g_opt_plan_item_cost, g_opt_plan_rest_first, g_opt_plan_slots,
                                    g_opt_plan_xcd_affine, g_opt_plan_taper, g_opt_plan_affine_min_chunks);
     auto it = g.plans.find(key);
@@ -600,17 +609,18 @@ static int build_plan(LaunchGroup &g, int64_t S, LaunchPlan **out) {
     }
     std::unique_ptr<LaunchPlan> plan(new LaunchPlan());
     // planning runs on the launching thread, ahead of the launch on the caller's stream: ONE blocking copy (three cost
-    // a one-spectrum call 50 us more)
+    // a one-spectrum call 50 us more) -- or none, when the caller has uploads of its own under way (defer_upload)
     const size_t passes_bytes = host.passes.size() * sizeof(PassDesc), items_bytes = host.items.size() * sizeof(WorkItem);
     plan->items_at = (passes_bytes + 255) & ~(size_t)255;
     plan->counts_at = (plan->items_at + items_bytes + 255) & ~(size_t)255;
-    std::vector<char> staged(plan->counts_at + std::max<size_t>(1, host.counts.size()), 0);
+    std::vector<char> staged((plan->counts_at + std::max<size_t>(1, host.counts.size()) + 15) & ~(size_t)15, 0);
     std::memcpy(staged.data(), host.passes.data(), passes_bytes);
     std::memcpy(staged.data() + plan->items_at, host.items.data(), items_bytes);
     std::memcpy(staged.data() + plan->counts_at, host.counts.data(), host.counts.size());
     int rc = plan->blob.reserve(staged.size());
     if (rc) return rc;
-    HIP_TRY(hipMemcpy(plan->blob.ptr, staged.data(), staged.size(), hipMemcpyHostToDevice));
+    if (defer_upload) defer_upload->swap(staged);
+    else HIP_TRY(hipMemcpy(plan->blob.ptr, staged.data(), staged.size(), hipMemcpyHostToDevice));
     plan->nitems = (int)host.items.size();
     plan->max_parts = host.max_parts;
     *out = plan.get();
@@ -752,7 +762,7 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
     Workspace &ws = g.ws;
     const int nb = (int)g.ctxs.size();
     const long rows = (long)nb * S;
-    const SightlineDev *table = g.d_table.as<SightlineDev>();
+    const SightlineDev *table = g.table();
     int rc;
     if ((rc = enter_stream(g, stream))) return rc;
 
@@ -1010,6 +1020,7 @@ static hipStream_t shared_stream_if_any(int device) {
 // a catalogue does not grow the number of events with the number of chunks.
 struct CallEvents {
     hipEvent_t uploaded = nullptr, computed = nullptr;
+    hipEvent_t gate = nullptr;  // a point inside the call's kernel sequence that a side launch waits for (made on first use)
 };
 struct EventPool {
     std::mutex mutex;
@@ -1197,6 +1208,7 @@ struct Transfers {
 // group has on its kernel stream: what launch_one does for kd == 0 -- the generic kernel on one "sample" per sightline, four
 // pixel ranges each, and its finalisation -- with partial sums and a non-PD flag of its own.  The same numbers, bit for bit.
 static Option g_opt_null_side = 1;  // 0: the null model always as the call's last launch on the kernel stream
+static Option g_opt_null_side_level = -2;  // the side launch waits for this level's evaluations (0-based; -1: the deepest level's, -2: the one before)
 static int launch_null_side(LaunchGroup &g, double *d_out, hipStream_t side) {
     Workspace &ws = g.ws;
     const int nb = (int)g.ctxs.size();
@@ -1209,7 +1221,7 @@ static int launch_null_side(LaunchGroup &g, double *d_out, hipStream_t side) {
     }
     if ((rc = ws.null_part.reserve((size_t)nparts * nblocks * g.row_width * 16 * sizeof(double)))) return rc;
     if ((rc = ws.null_status.reserve(sizeof(int)))) return rc;
-    const SightlineDev *table = g.d_table.as<SightlineDev>();
+    const SightlineDev *table = g.table();
     const int lds_entries = std::max(g.max_entries, g.max_npad);
     const int lds_pixels = g.max_npad;
     const size_t lds_bytes = (size_t)(lds_entries + lds_pixels + DLAGP_MAX_LINES + 1 + 8) * sizeof(double);
@@ -1341,7 +1353,8 @@ enum { SWEEP_ALL = 0, SWEEP_START = 1, SWEEP_FINISH = 2 };
 static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d_sample_z, const double *d_sample_nhi,
                         int64_t nhi_stride, double min_z_separation, const double *d_uniforms, double *d_evidences,
                         double *d_sample_ll, int *d_base, hipStream_t stream, bool keep_sticky_flag = false,
-                        const PairSpec *pair = nullptr, int phase = SWEEP_ALL, int *cache_decision = nullptr) {
+                        const PairSpec *pair = nullptr, int phase = SWEEP_ALL, int *cache_decision = nullptr,
+                        const std::function<int()> *after_level_launch = nullptr) {
     CallOptionsScope options_of_this_call;
     Workspace &ws = g.ws;
     const int nb = (int)g.ctxs.size();
@@ -1362,13 +1375,12 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     g.launched = true;
     if (phase != SWEEP_FINISH) {
         // a second sweep of the same call adds to the first one's non-PD flag (keep_sticky_flag)
-        hipLaunchKernelGGL(sweep_init, dim3((unsigned)std::max<long>(1, std::min<long>((std::max(n_ll, n_base) + 255) / 256, 2048))),
-                           dim3(256), 0, stream, d_sample_ll, n_ll, d_evidences, (long)nb * max_dlas, ws.alive.as<int>(),
-                           (long)nb, keep_sticky_flag ? 0 : 1, n_base > 0 ? d_base : nullptr, n_base);
-        if (pair)  // the paired model's own state: one level, its own alive flags (the sticky flag is the sweep's)
-            hipLaunchKernelGGL(sweep_init, dim3((unsigned)std::max<long>(1, std::min<long>(((long)rows + 255) / 256, 2048))), dim3(256),
-                               0, stream, pair->d_sample_ll, (long)rows, pair->d_evidences, (long)nb, ws.sub_alive.as<int>(),
-                               (long)nb, 1, (int *)nullptr, 0L);
+        // (with it the paired model's own state: one level, its own alive flags -- the sticky flag is the sweep's)
+        const long fill = std::max(std::max(n_ll, n_base), pair ? (long)rows : 0L);
+        hipLaunchKernelGGL(sweep_init, dim3((unsigned)std::max<long>(1, std::min<long>((fill + 255) / 256, 2048))), dim3(256), 0, stream,
+                           d_sample_ll, n_ll, d_evidences, (long)nb * max_dlas, ws.alive.as<int>(), (long)nb, keep_sticky_flag ? 0 : 1,
+                           n_base > 0 ? d_base : nullptr, n_base, pair ? pair->d_sample_ll : nullptr, pair ? (long)rows : 0L,
+                           pair ? pair->d_evidences : nullptr, pair ? (long)nb : 0L, pair ? ws.sub_alive.as<int>() : nullptr);
         HIP_TRY(hipGetLastError());
     }
     const SampleSource src0{d_sample_z, d_sample_nhi, d_base, 1, (long)nhi_stride, max_dlas - 1, nullptr, nullptr, 0, 0, 0, 0, 0};
@@ -1426,6 +1438,11 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
     if (cache_decision && phase != SWEEP_FINISH) *cache_decision = all_cached ? 1 : 0;
     g_last_sweep_paired = pair ? 1 : 0;
     const double log_s = std::log((double)S);
+    // which level's launch the caller's hook follows: option null_side_level (0-based; negative: counted from the deepest,
+    // -1 = the deepest), among the levels this phase launches
+    const int first_launched = phase == SWEEP_FINISH ? 1 : 0;
+    const int wanted = g_opt_null_side_level < 0 ? max_dlas + (int)g_opt_null_side_level : (int)g_opt_null_side_level;
+    const int hook_level = std::min(std::max(wanted, first_launched), max_dlas - 1);
     for (int level = 0; level < max_dlas; ++level) {
         bool first = true;
         const bool launch = !(phase == SWEEP_FINISH && level == 0);  // FINISH: level 1 was launched by START
@@ -1447,6 +1464,9 @@ static int sweep_levels(LaunchGroup &g, int64_t S, int max_dlas, const double *d
             if (rc) return rc;
             first = false;
         }
+        // a level's evaluations are enqueued: what follows on this stream are small kernels (its finalisation and level
+        // finish) -- the caller's moment for work that may run beside them
+        if (launch && level == hook_level && after_level_launch && (rc = (*after_level_launch)())) return rc;
         if (phase == SWEEP_START) return DLAGP_OK;  // level 1's evidence and resampling wait for the uniforms -- and the paired
                                                     // model's level finish waits with them: it rides in the same launches
         LevelArgs this_level{ws.level_ll.as<const double>(), (long)S, level, max_dlas, src0, min_z_separation, log_s, d_uniforms,
@@ -1643,7 +1663,9 @@ static int upload_staged(void *dst, const void *src, size_t bytes, int device) {
 
 // fill the group-level summary from its members and upload the descriptor table; `positions`: where each member
 // sits in the caller's arrays (a part of a heterogeneous batch), default 0, 1, 2, ...
-static int finish_group(LaunchGroup &g, const std::vector<int> *positions = nullptr, bool defer_sync = false) {
+// `table_staged`: the caller has staged the (one-member) table already, with the member's arrays (create_context).
+static int finish_group(LaunchGroup &g, const std::vector<int> *positions = nullptr, bool defer_sync = false,
+                        bool table_staged = false) {
     std::vector<SightlineDev> table;
     g.k = g.ctxs[0]->sl.k;
     g.row_width = g.ctxs[0]->sl.row_width;
@@ -1666,10 +1688,16 @@ static int finish_group(LaunchGroup &g, const std::vector<int> *positions = null
                     (ctx->sl.ntaps > 1) == g.broadening;
     }
     if (lls_mixed) g.mfma_ok = false;
-    int rc = g.d_table.reserve(table.size() * sizeof(SightlineDev));
-    if (rc) return rc;
-    // the table must be in place before the group's first launch, which runs on the caller's stream
-    if ((rc = upload_staged(g.d_table.ptr, table.data(), table.size() * sizeof(SightlineDev), g.device))) return rc;
+    if (g.ctxs.size() == 1 && !positions && &g != &g.ctxs[0]->self && g.ctxs[0]->self.d_table.ptr) {
+        g.table_alias = g.ctxs[0]->self.d_table.as<SightlineDev>();  // in place since the member's own set-up (wait_setup)
+        return DLAGP_OK;
+    }
+    int rc = DLAGP_OK;
+    if (!table_staged) {
+        if ((rc = g.d_table.reserve(table.size() * sizeof(SightlineDev)))) return rc;
+        // the table must be in place before the group's first launch, which runs on the caller's stream
+        if ((rc = upload_staged(g.d_table.ptr, table.data(), table.size() * sizeof(SightlineDev), g.device))) return rc;
+    }
     return defer_sync ? flush_uploads(g.device) : setup_sync(g.device);
 }
 
@@ -1774,9 +1802,18 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
         const double log0 = uniform ? std::log10(wavelengths[0]) : 0.0;
         const double dlog = uniform ? (std::log10(wavelengths[ne - 1]) - log0) / (ne - 1) : 0.0;
         uniform = uniform && dlog > 0.0;
-        for (int e = 1; uniform && e < ne; ++e)
-            uniform = wavelengths[e] > wavelengths[e - 1] &&
-                      std::fabs((std::log10(wavelengths[e]) - log0) / dlog - e) <= 0.4;
+        // entry e within 0.4 entries of log0 + e dlog, without a logarithm per entry (1200 of them were a third of this
+        // function's host time): the bounds w0 10^((e -+ 0.4) dlog) advance by one multiplication per entry; their rounding
+        // drift over a grid (~1e-13 relative) is nine orders below the tolerance (0.4 dlog ln 10 ~ 1e-4 relative)
+        if (uniform) {
+            const double ratio = std::pow(10.0, dlog);
+            double lo = wavelengths[0] * std::pow(10.0, -0.4 * dlog), hi = wavelengths[0] * std::pow(10.0, 0.4 * dlog);
+            for (int e = 1; uniform && e < ne; ++e) {
+                lo *= ratio;
+                hi *= ratio;
+                uniform = wavelengths[e] > wavelengths[e - 1] && wavelengths[e] >= lo && wavelengths[e] <= hi;
+            }
+        }
         sl.grid_uniform = uniform ? 1 : 0;
         sl.grid_log0 = log0;
         sl.grid_inv_dlog = uniform ? 1.0 / dlog : 0.0;
@@ -1820,6 +1857,24 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
         if (!rc) rc = upload_staged(ctx->slot_pixel.ptr, slot_pixel.data(), sb, device);
         if (!rc) rc = upload_staged(ctx->slot_pos.ptr, ctx->h_slot_pos.data(), sb, device);
     }
+    sl.y = ctx->y.as<double>();
+    sl.mu = ctx->mu.as<double>();
+    sl.omega2 = ctx->omega2.as<double>();
+    sl.v = ctx->v.as<double>();
+    sl.pos = ctx->pos.as<int>();
+    sl.lam = ctx->lam.as<double>();
+    sl.P = ctx->P.as<double>();
+    sl.Pm = ctx->Pm.as<double>();
+    sl.aux = ctx->aux.as<double>();
+    // the descriptor is complete: the table of the context's own group {this} travels with the arrays (one copy, one
+    // copy_segments launch for all of them -- staged at the end of the sequence it was a second pair, 10 us of every
+    // one-spectrum call)
+    if (!rc) rc = ctx->self.d_table.reserve(sizeof(SightlineDev));
+    if (!rc) {
+        SightlineDev own = sl;
+        own.batch_index = 0;
+        rc = upload_staged(ctx->self.d_table.ptr, &own, sizeof(SightlineDev), device);
+    }
     if (!rc) rc = upload_staged(ctx->pos.ptr, hpos.data(), (size_t)sl.n_pad * sizeof(int), device);
     if (!rc) rc = upload_staged(ctx->lam.ptr, wavelengths, (size_t)sl.num_entries * sizeof(double), device);
     if (!rc) rc = fill(ctx);
@@ -1833,15 +1888,6 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     // d would turn an even number of negative pixels into a finite number, so such a sightline takes the generic kernel,
     // which takes the logarithm pixel by pixel as the reference does.
     if (ctx->negative_noise && !g_opt_negative_noise_mfma) ctx->mfma_ok = false;
-    sl.y = ctx->y.as<double>();
-    sl.mu = ctx->mu.as<double>();
-    sl.omega2 = ctx->omega2.as<double>();
-    sl.v = ctx->v.as<double>();
-    sl.pos = ctx->pos.as<int>();
-    sl.lam = ctx->lam.as<double>();
-    sl.P = ctx->P.as<double>();
-    sl.Pm = ctx->Pm.as<double>();
-    sl.aux = ctx->aux.as<double>();
 
     if ((rc = flush_uploads(device))) {  // whatever `fill` and the tables above have staged: the kernels below read it
         (void)setup_sync(device);
@@ -1868,7 +1914,7 @@ static int create_context(dlagp_ctx **out, int n, int n_u, int k, const double *
     ctx->self.ctxs.push_back(ctx);
     // ends with the one synchronisation of the whole set-up sequence -- unless the caller defers it to the batch it is
     // building (DLAGP_FLAG_DEFER_SYNC); the kernels' temporaries then stay with the context until it is destroyed
-    rc = finish_group(ctx->self, nullptr, defer_sync);
+    rc = finish_group(ctx->self, nullptr, defer_sync, /*table_staged=*/true);
     ctx->setup_pending = defer_sync;
     if (defer_sync && !rc) {
         if (hipEventCreateWithFlags(&ctx->setup_event, hipEventDisableTiming) != hipSuccess ||
@@ -2090,6 +2136,7 @@ void dlagp_destroy(dlagp_ctx *ctx) try {
         for (dlagp_batch *batch : ctx->batches) batch->group.drain();
         for (dlagp_batch *batch : ctx->batches) {  // and it must not touch the context again
             std::replace(batch->group.ctxs.begin(), batch->group.ctxs.end(), ctx, (dlagp_ctx *)nullptr);
+            if (batch->group.table_alias == ctx->self.table()) batch->group.table_alias = nullptr;
             for (auto &part : batch->group.parts)
                 std::replace(part->ctxs.begin(), part->ctxs.end(), ctx, (dlagp_ctx *)nullptr);
         }
@@ -2585,19 +2632,46 @@ int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dla
     tr.upload(ws.sub_nhi.ptr, sub_sample_nhi, n_sub_nhi * sizeof(double));
     tr.upload(ws.z.ptr, sample_z, rows * sizeof(double));
     tr.upload(ws.nhi.ptr, sample_nhi, n_nhi * sizeof(double));
+    // the work items of the pair launch, planned now: they go up with the samples instead of as a blocking copy of their own
+    // between the call's launches (15 us of a one-spectrum call, all of it in front of the first sweep kernel)
+    std::vector<char> plan_bytes;
+    if (pair) {
+        LaunchPlan *plan = nullptr;
+        if ((rc = build_plan(g, pair_virtual_samples(S), &plan, &plan_bytes))) return rc;
+        if (!plan_bytes.empty()) tr.upload(plan->blob.ptr, plan_bytes.data(), plan_bytes.size());
+    }
     // the staging buffer is sized for BOTH phases now: growing it in _finish would free memory the copies of this
     // phase may still be reading
     const size_t second_phase = (n_base + 2 * nb + rows + nb * max_dlas + rows * max_dlas) * sizeof(double) +
                                 n_base * sizeof(int32_t) + 2 * sizeof(int) + nb * max_dlas * sizeof(int32_t) + 16 * 256;
-    if ((rc = tr.reserve(second_phase)) || (rc = tr.run_uploads())) return rc;
-    // the null model of every member, beside the sweeps: on this thread's transfer stream (behind the uploads just queued, in
-    // front of _finish's downloads), with buffers of its own -- 30 us of a one-spectrum call that nothing has to wait for
+    if ((rc = tr.reserve(second_phase)) || (rc = tr.run_uploads())) {
+        if (!plan_bytes.empty()) {  // the new plan's items never reached the device: no later launch may find it
+            g.drain();  // (launches in flight still read the other plans)
+            for (auto &kv : g.plans) kv.second->release();
+            g.plans.clear();
+        }
+        return rc;
+    }
+    // The null model of every member BESIDE the sweeps: on this thread's transfer stream, with buffers of its own -- 30 us of a
+    // one-spectrum call that nothing has to wait for.  When?  Not in front of the sweep's first launch: on a one-spectrum call
+    // everything there is the host's time with the device idle (two launches and their events: ~20 us).  Not right behind that
+    // launch either: the generic kernel's workgroups take compute units from an accumulate launch whose work items are dealt
+    // to the wave slots in advance, and the launch waits for its slowest unit (+22 us on a 237 us pair launch; the null
+    // kernel itself took 267 us instead of 24).  _finish enqueues it behind an event that fires when the deepest level's
+    // evaluations are done: it runs beside that level's finalisation and level finish, small kernels that leave most of the
+    // chip idle.  (A one-level call has no such moment: there it goes first, as it did before.)
     // Only for a few sightlines (a caller that works one spectrum at a time): beside OTHER batches' sweeps, as in the
     // catalogue pipeline, the generic kernel's four-wave workgroups would wait for four free wave slots on one compute unit
     // (host_shared.h, DLAGP_SETUP_THREADS) and hold this batch's downloads back; there the null model stays the call's
     // last launch on the kernel stream (45 us of a 12 ms batch).
     batch->pending.null_on_side = g_opt_null_side != 0 && nb <= 4;
-    if (batch->pending.null_on_side && (rc = launch_null_side(g, ws.out.as<double>(), tr.transfer))) return rc;
+    batch->pending.null_launched = false;
+    // its flag exists from here on: _finish registers the flag's download before the launch that would allocate it
+    if (batch->pending.null_on_side && (rc = ws.null_status.reserve(sizeof(int)))) return rc;
+    if (batch->pending.null_on_side && max_dlas == 1) {
+        if ((rc = launch_null_side(g, ws.out.as<double>(), tr.transfer))) return rc;
+        batch->pending.null_launched = true;
+    }
     batch->pending.pair = pair;
     batch->pending.sub_nhi_stride = sub_nhi_stride;
     if (pair) {
@@ -2610,6 +2684,7 @@ int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dla
         rc = sweep_levels(g, S, 1, ws.sub_z.as<double>(), ws.sub_nhi.as<double>(), sub_nhi_stride, min_z_separation, nullptr,
                           ws.sub_evidences.as<double>(), ws.sub_ll.as<double>(), nullptr, stream);
     }
+    if (rc) return rc;
     if (rc) return rc;
     batch->pending.active = true;
     batch->pending.S = S;
@@ -2658,24 +2733,43 @@ int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniform
     if ((rc = tr.reserve())) return rc;
     if (ws.stage.bytes != capacity) return fail(DLAGP_EDEVICE, "internal: the staging buffer grew between the two phases");
     if ((rc = tr.run_uploads())) return rc;
+    // the null model beside the deepest level's finalisation and level finish (see _start)
+    const std::function<int()> null_beside_last_level = [&]() -> int {
+        if (tr.transfer != stream) {
+            CallEvents *ev = nullptr;
+            int rc_ev = call_events(g.device, &ev);
+            if (rc_ev) return rc_ev;
+            if (!ev->gate) HIP_TRY(hipEventCreateWithFlags(&ev->gate, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ev->gate, stream));
+            HIP_TRY(hipStreamWaitEvent(tr.transfer, ev->gate, 0));
+        }
+        batch->pending.null_launched = true;
+        return launch_null_side(g, ws.out.as<double>(), tr.transfer);
+    };
+    const std::function<int()> *hook =
+        batch->pending.null_on_side && !batch->pending.null_launched ? &null_beside_last_level : nullptr;
     if (batch->pending.pair) {
         const PairSpec sub{ws.sub_nhi.as<double>(), batch->pending.sub_nhi_stride, ws.sub_evidences.as<double>(), ws.sub_ll.as<double>()};
         rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), batch->pending.nhi_stride,
                           batch->pending.min_z_separation, ws.uniforms.as<double>(), ws.evidences.as<double>(),
                           ws.sample_ll.as<double>(), ws.base.as<int>(), stream, /*keep_sticky_flag=*/true, &sub, SWEEP_FINISH,
-                          &batch->pending.cached);
+                          &batch->pending.cached, hook);
     } else {
         rc = sweep_levels(g, S, max_dlas, ws.z.as<double>(), ws.nhi.as<double>(), batch->pending.nhi_stride,
                           batch->pending.min_z_separation, ws.uniforms.as<double>(), ws.evidences.as<double>(),
-                          ws.sample_ll.as<double>(), ws.base.as<int>(), stream, /*keep_sticky_flag=*/true);
+                          ws.sample_ll.as<double>(), ws.base.as<int>(), stream, /*keep_sticky_flag=*/true, nullptr, SWEEP_ALL,
+                          nullptr, hook);
     }
     if (rc) return rc;
+    if (batch->pending.null_on_side && !batch->pending.null_launched) {  // no level was launched by this phase
+        if ((rc = null_beside_last_level())) return rc;
+    }
     if (!batch->pending.null_on_side) {
         // the null model last: its launch leaves its own flag in ws.status, which the sweeps' launches would reset
         rc = launch_sweep(g, 1, 0, SampleSource{nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0},
                           ws.out.as<double>(), stream);
         if (rc) return rc;
-    }  // (else: launched by _start on the transfer stream, which the downloads below follow on)
+    }  // (else: enqueued above on the transfer stream, which the downloads below follow on)
     if ((rc = tr.run_downloads())) return rc;
     g.launched = false;  // as in sweep_from_host
     g.side_launched = false;  // run_downloads waited for the transfer stream
@@ -2893,6 +2987,7 @@ int dlagp_set_option(const char *name, int64_t value) try {
     else if (!strcmp(name, "pair_models")) g_opt_pair_models = value != 0;
     else if (!strcmp(name, "pack_setup_uploads")) g_opt_pack_setup_uploads = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "pack_transfers")) g_opt_pack_transfers = value != 0;
+    else if (!strcmp(name, "null_side_level")) g_opt_null_side_level = value;
     else if (!strcmp(name, "null_side")) g_opt_null_side = value != 0;
     else if (!strcmp(name, "level_spread")) g_opt_level_spread = value != 0;
     else if (!strcmp(name, "level_search_groups")) g_opt_level_search_groups = value < 1 ? 1 : (value > 64 ? 64 : value);
@@ -2945,6 +3040,7 @@ int dlagp_get_option(const char *name, int64_t *value) try {
     else if (!strcmp(name, "last_sweep_paired")) *value = g_last_sweep_paired;
     else if (!strcmp(name, "pack_setup_uploads")) *value = g_opt_pack_setup_uploads;
     else if (!strcmp(name, "pack_transfers")) *value = g_opt_pack_transfers;
+    else if (!strcmp(name, "null_side_level")) *value = g_opt_null_side_level;
     else if (!strcmp(name, "null_side")) *value = g_opt_null_side;
     else if (!strcmp(name, "level_spread")) *value = g_opt_level_spread;
     else if (!strcmp(name, "level_search_groups")) *value = g_opt_level_search_groups;

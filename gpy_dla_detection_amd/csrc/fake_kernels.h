@@ -14,23 +14,34 @@ template <bool CUM_IN_LDS>
 void level_finish_fused(LevelArgs) {}
 inline void level_weights(LevelArgs) {}
 inline void level_resample(LevelArgs) {}
-// what a segment copy touches: the device array of every piece
-inline void mark_arg(const CopyTable &t, fake::Stream *s, uint64_t ticket) {
-    for (int i = 0; i < t.count; ++i) fake::mark(reinterpret_cast<const void *>(t.seg[i].device_ptr), s, ticket);
-}
 inline void level_weights_two(LevelArgsTwo) {}
 inline void level_resample_two(LevelArgsTwo) {}
-// what a level-finish launch touches (fake::launch marks pointer arguments; this struct travels by value)
-inline void mark_arg(const LevelArgs &a, fake::Stream *s, uint64_t t) {
-    for (const void *p : {(const void *)a.ll, (const void *)a.uniforms, (const void *)a.sample_ll, (const void *)a.evidences,
-                          (const void *)a.base, (const void *)a.weights, (const void *)a.exch, (const void *)a.alive,
-                          (const void *)a.status, (const void *)a.ties})
-        fake::mark(p, s, t);
-}
-inline void mark_arg(const LevelArgsTwo &p, fake::Stream *s, uint64_t t) {
-    mark_arg(p.first, s, t);
-    mark_arg(p.second, s, t);
-}
 inline void accumulate_generic() {}
 inline void absorption_generic() {}
 }  // namespace dlagp
+
+// What a launch touches through a struct that travels BY VALUE (fake::launch marks pointer arguments itself).  In namespace
+// fake: the structs are global, so argument-dependent lookup finds these overloads through the fake::Stream argument only
+// (round 6: they sat in namespace dlagp and were never called).
+namespace fake {
+// what a segment copy touches: the device array of every piece
+inline void mark_arg(const CopyTable &t, Stream *s, uint64_t ticket) {
+    for (int i = 0; i < t.count; ++i) {
+        // a piece registered before its array was allocated (round 6: the null model's flag, downloaded by a call whose
+        // side launch -- the allocation -- had moved behind the registration: a GPU fault on the real device)
+        if (!t.seg[i].device_ptr && t.seg[i].bytes) report("copy_segments piece with a NULL device address", nullptr);
+        mark(reinterpret_cast<const void *>(t.seg[i].device_ptr), s, ticket);
+    }
+}
+// what a level-finish launch touches (launch marks pointer arguments; this struct travels by value)
+inline void mark_arg(const LevelArgs &a, Stream *s, uint64_t t) {
+    for (const void *p : {(const void *)a.ll, (const void *)a.uniforms, (const void *)a.sample_ll, (const void *)a.evidences,
+                          (const void *)a.base, (const void *)a.weights, (const void *)a.exch, (const void *)a.alive,
+                          (const void *)a.status, (const void *)a.ties})
+        mark(p, s, t);
+}
+inline void mark_arg(const LevelArgsTwo &p, Stream *s, uint64_t t) {
+    mark_arg(p.first, s, t);
+    mark_arg(p.second, s, t);
+}
+}  // namespace fake

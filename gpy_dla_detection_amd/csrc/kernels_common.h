@@ -1270,16 +1270,26 @@ __global__ __launch_bounds__(DLAGP_LEVEL_SEARCH_THREADS) void level_resample_two
 
 // Start of an occupation sweep in one launch (reference dla_gp.py:112-119: NaN-initialised likelihoods and evidences,
 // zeroed base indices; plus this library's flags): five fill launches before, 20 us of a one-spectrum call.
+// `sample_ll2`, `evidences2`, `alive2`: the state of a second, one-level model started with the sweep (the paired one-absorber
+// model of a model selection: its own likelihoods, evidences and alive flags; no sticky flag, no base indices) -- or NULL.
 __global__ void sweep_init(double *__restrict__ sample_ll, long n_ll, double *__restrict__ evidences, long n_ev,
-                           int *__restrict__ alive, long nb, int clear_sticky, int *__restrict__ base, long n_base) {
+                           int *__restrict__ alive, long nb, int clear_sticky, int *__restrict__ base, long n_base,
+                           double *__restrict__ sample_ll2, long n_ll2, double *__restrict__ evidences2, long n_ev2,
+                           int *__restrict__ alive2) {
     const double nan = __builtin_nan("");
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_ll; i += stride) sample_ll[i] = nan;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_base; i += stride) base[i] = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_ll2; i += stride) sample_ll2[i] = nan;
     if (blockIdx.x == 0) {
         for (long i = threadIdx.x; i < n_ev; i += blockDim.x) evidences[i] = nan;
         for (long i = threadIdx.x; i < nb; i += blockDim.x) alive[i] = 1;
         if (threadIdx.x == 0 && clear_sticky) alive[nb] = 0;
+        for (long i = threadIdx.x; i < n_ev2; i += blockDim.x) evidences2[i] = nan;
+        if (alive2) {
+            for (long i = threadIdx.x; i < nb; i += blockDim.x) alive2[i] = 1;
+            if (threadIdx.x == 0) alive2[nb] = 0;
+        }
     }
 }
 

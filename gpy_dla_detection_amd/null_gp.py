@@ -215,14 +215,14 @@ class _LearnedRegistry:
             if (grid.ndim != 1 or M.ndim != 2 or mu.ndim != 1 or log_omega.ndim != 1 or M.shape[0] != grid.shape[0]
                     or any(a.dtype.kind not in "fiu" for a in (grid, mu, M, log_omega))):
                 return None
-            if grid.shape[0] < 2 or not np.all(np.diff(grid) > 0):
-                return None  # unsorted grid: scipy's interp1d sorts, np.interp does not -- the general path serves
             with self.lock:
                 for i in range(len(self.entries) - 1, -1, -1):
-                    if self.entries[i].matches(grid, mu, M, log_omega):
+                    if self.entries[i].matches(grid, mu, M, log_omega):  # (a known model's grid is sorted: checked below)
                         entry = self.entries.pop(i)
                         self.entries.append(entry)
                         return entry
+                if grid.shape[0] < 2 or not np.all(np.diff(grid) > 0):
+                    return None  # unsorted grid: scipy's interp1d sorts, np.interp does not -- the general path serves
                 entry = _LearnedModel(np.array(grid, dtype=np.float64), np.array(mu, dtype=np.float64),
                                       np.array(M.T, dtype=np.float64, order="C"), np.array(log_omega, dtype=np.float64))
                 self.entries.append(entry)

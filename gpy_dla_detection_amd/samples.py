@@ -80,8 +80,12 @@ class DLASamples:
         return self._nhi_samples
 
     def _map_offsets(self, wavelengths: np.ndarray, z_qso: float) -> np.ndarray:
-        z_min = self.params.min_z_dla(wavelengths, z_qso)
-        z_max = self.params.max_z_dla(wavelengths, z_qso)
+        params = self.params
+        if type(params).min_z_dla is Parameters.min_z_dla and type(params).max_z_dla is Parameters.max_z_dla:
+            z_min, z_max = params.z_dla_range(wavelengths, z_qso)  # the two bounds with the in-range test made once
+        else:  # a subclass with bounds of its own
+            z_min = params.min_z_dla(wavelengths, z_qso)
+            z_max = params.max_z_dla(wavelengths, z_qso)
         return z_min + (z_max - z_min) * self._offset_samples
 
     def sample_z_dlas(self, wavelengths: np.ndarray, z_qso: float) -> np.ndarray:

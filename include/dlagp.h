@@ -451,7 +451,9 @@ int dlagp_level_finish_device(int nb, int64_t S, int level, int max_dlas, const 
  *                     "null_side" (1 = in dlagp_batch_model_evidences* on a batch of up to four sightlines the null model's
  *                     two kernels run beside the sweeps, on the calling thread's transfer stream with buffers of their own,
  *                     instead of as the call's last launch: -4.5 % wall per one-spectrum model selection; identical results;
- *                     default 1),
+ *                     default 1), "null_side_level" (... behind an event that fires when this occupation level's evaluations
+ *                     are done, so that they run beside that level's small finishing kernels and take no compute unit from an
+ *                     accumulate launch: 0-based level, negative = counted from the deepest, -1 = the deepest; default -2),
  *                     "pack_setup_uploads" (the same for the arrays of a context's set-up: 0 = one copy per array, 1 = together,
  *                     2 = together when the device's kernel stream is idle at that moment -- beside a running sweep the single
  *                     copies get through sooner than a kernel finds a wave slot; default 2)
