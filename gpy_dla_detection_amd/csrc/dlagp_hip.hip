@@ -440,6 +440,11 @@ struct LaunchGroup {
     // sums and a status flag of its own (ws.null_part, ws.null_status): it depends on nothing the sweeps produce
     hipStream_t side_stream = nullptr;
     bool side_launched = false;
+    // a launch plan's work items that went up with a call's uploads (dlagp_batch_model_evidences_start): the copy runs on the
+    // calling thread's transfer stream; the call's kernels wait for it, but a call that FAILS before its first launch leaves
+    // it in flight with nothing of the group behind it -- and plans are released with the group (found by the sanitizer replay)
+    hipStream_t upload_stream = nullptr;
+    bool upload_pending = false;
     bool mfma_ok = false;
     int col_groups = 1;         // MFMA path: column groups per block (1 for rank <= 20, see kernels_mfma.h)
     bool grid_uniform = false;  // every member's wavelength grid is log-uniform (core patch eligible)
@@ -462,6 +467,8 @@ struct LaunchGroup {
         launched = false;
         if (side_launched) (void)hipStreamSynchronize(side_stream);
         side_launched = false;
+        if (upload_pending) (void)hipStreamSynchronize(upload_stream);
+        upload_pending = false;
         for (auto &p : parts) p->drain();
     }
     void release() {
@@ -2647,10 +2654,15 @@ int dlagp_batch_model_evidences_start(dlagp_batch *batch, int64_t S, int max_dla
     if ((rc = tr.reserve(second_phase)) || (rc = tr.run_uploads())) {
         if (!plan_bytes.empty()) {  // the new plan's items never reached the device: no later launch may find it
             g.drain();  // (launches in flight still read the other plans)
+            (void)hipStreamSynchronize(tr.transfer);  // ... and whatever part of the uploads did leave may be writing this one
             for (auto &kv : g.plans) kv.second->release();
             g.plans.clear();
         }
         return rc;
+    }
+    if (!plan_bytes.empty()) {
+        g.upload_stream = tr.transfer;
+        g.upload_pending = true;
     }
     // The null model of every member BESIDE the sweeps: on this thread's transfer stream, with buffers of its own -- 30 us of a
     // one-spectrum call that nothing has to wait for.  When?  Not in front of the sweep's first launch: on a one-spectrum call
@@ -2773,6 +2785,7 @@ int dlagp_batch_model_evidences_finish(dlagp_batch *batch, const double *uniform
     if ((rc = tr.run_downloads())) return rc;
     g.launched = false;  // as in sweep_from_host
     g.side_launched = false;  // run_downloads waited for the transfer stream
+    g.upload_pending = false;
     for (auto &p : g.parts) p->launched = false;
     if (status[0] || status[1]) return fail(DLAGP_ELINALG, "Matrix is not positive definite (I + M' D^-1 M)");
     return DLAGP_OK;
