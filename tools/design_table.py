@@ -69,11 +69,21 @@ except (OSError, KeyError):
 x = load("route_a.json")
 if "kernel_ms_per_spectrum" in x:  # round 6 on: with the kernels' own time from the rocprofv3 run of the same command
     fam = x["kernel_us_per_spectrum_by_family"]
-    print("| route A (reference driver loop, imports swapped), 256 spectra, n median %.0f | **%.2f ms per spectrum** (%.0f spectra/s); kernels %.3f ms per spectrum = **%.1f %%** of FP64 peak over their own time (accumulate %.0f µs at %.1f %%, level finish %.0f, finalisation %.0f, transfers %.0f, set-up %.0f, null %.0f); %.0f launches per spectrum | `%s_route_a.json`, `%s_kernel_stats_route_a.csv` |"
-          % (x["kept_pixels"]["median"], x["ms_per_spectrum"], x["spectra_per_s"], x["kernel_ms_per_spectrum"], 100 * x["kernel_frac_of_fp64_peak"],
-             fam.get("accumulate_mfma", 0), 100 * x["accumulate_frac_of_fp64_peak"], fam.get("level finish", 0), fam.get("finalisation", 0),
-             fam.get("transfers (copy_segments + blit copies)", 0), fam.get("set-up", 0), fam.get("null model (generic kernel)", 0),
-             x["launches_per_spectrum"], tag, tag))
+    null = next((v for k, v in fam.items() if k.startswith("null model")), 0)
+    if "device_busy_ms_per_spectrum" in x:  # ... and the kernels' timeline (two streams: summed durations count overlaps twice)
+        t = x["timeline_us_per_spectrum"]
+        busy = ("device busy %.3f ms per spectrum = **%.1f %%** of FP64 peak over that time (kernels summed %.3f ms: the null model's two run beside the sweep's); "
+                % (x["device_busy_ms_per_spectrum"], 100 * x["busy_frac_of_fp64_peak"], x["kernel_ms_per_spectrum"]))
+        where = ("; of the wall time %.0f µs host between two spectra, %.0f µs from a spectrum's first kernel to its first accumulate launch"
+                 % (t["host_between_spectra"], t["first_kernel_to_first_accumulate"]))
+    else:
+        busy = "kernels %.3f ms per spectrum = **%.1f %%** of FP64 peak over their own time " % (x["kernel_ms_per_spectrum"], 100 * x["kernel_frac_of_fp64_peak"])
+        where = ""
+    print("| route A (reference driver loop, imports swapped), 256 spectra, n median %.0f | **%.2f ms per spectrum** (%.0f spectra/s; three runs %s); %s(accumulate %.0f µs at %.1f %%, level finish %.0f, finalisation %.0f, transfers %.0f, set-up %.0f, null %.0f); %.0f launches per spectrum%s | `%s_route_a.json`, `%s_kernel_stats_route_a.csv`, `%s_route_a_timeline.json` |"
+          % (x["kept_pixels"]["median"], x["ms_per_spectrum"], x["spectra_per_s"], " / ".join("%.3f" % v for v in x.get("ms_per_spectrum_runs", [])),
+             busy, fam.get("accumulate_mfma", 0), 100 * x["accumulate_frac_of_fp64_peak"], fam.get("level finish", 0), fam.get("finalisation", 0),
+             fam.get("transfers (copy_segments + blit copies)", 0), fam.get("set-up", 0), null,
+             x["launches_per_spectrum"], where, tag, tag, tag))
 else:
     print("| route A (reference driver loop, imports swapped), 256 spectra | **%.2f ms per spectrum** (%.0f spectra/s) | `%s_route_a.json` |"
           % (x["ms_per_spectrum"], x["spectra_per_s"], tag))

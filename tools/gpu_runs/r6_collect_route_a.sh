@@ -12,11 +12,10 @@ print(med["ms_per_spectrum_runs"])
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_route_a -- python3 tools/measure_route_a.py 256 > $out/route_a_under_rocprof.json 2>/dev/null
 cp $out/prof_route_a/*/*_kernel_stats.csv $out/kernel_stats_route_a.csv; rm -rf $out/prof_route_a
-python3 tools/route_a_frac.py $out/kernel_stats_route_a.csv $out/route_a_wall.json > $out/route_a.json
-head -c 1500 $out/route_a.json
 # where the wall time goes: the kernels' timeline (chain span, idle inside, host gap between spectra) and the host's functions
 rocprofv3 --kernel-trace --output-format csv -d $out/prof_tl -- python3 tools/measure_route_a.py 256 > /dev/null 2>&1
-python3 tools/route_a_timeline.py $(ls $out/prof_tl/*/*_kernel_trace.csv | head -1) 60 > $out/route_a_timeline.json
+python3 tools/route_a_timeline.py $(ls $out/prof_tl/*/*_kernel_trace.csv | head -1) > $out/route_a_timeline.json
 rm -rf $out/prof_tl
+python3 tools/route_a_frac.py $out/kernel_stats_route_a.csv $out/route_a_wall.json $out/route_a_timeline.json > $out/route_a.json
 python3 tools/route_a_host_segments.py 256 > $out/route_a_host_segments.json 2>/dev/null
 head -c 900 $out/route_a_timeline.json

@@ -3,7 +3,10 @@
 The drop-in route's device efficiency from a rocprofv3 kernel-stats CSV of `tools/measure_route_a.py N` and that run's own
 JSON line: kernel time per spectrum, its split by kernel family, and the algorithmic FLOP of the spectra over
 the kernels' time and over the accumulate kernels' time, against the dense FP64 peak.
-usage: tools/route_a_frac.py <kernel_stats.csv> <route_a.json> > profiles/r06_route_a.json
+The null model's two kernels run on a second stream BESIDE the sweep's (dlagp_hip.hip, launch_null_side): the sum of the kernels'
+durations then counts some instants twice; with the timeline of tools/route_a_timeline.py as third argument the device-busy
+time (the union of the kernels' intervals) is reported as well, and the fraction of peak over it.
+usage: tools/route_a_frac.py <kernel_stats.csv> <route_a.json> [route_a_timeline.json] > profiles/r06_route_a.json
 """
 import csv
 import json
@@ -14,7 +17,10 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 line = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
 # the tool runs the loop once over two spectra (warm-up) and once over all of them: every spectrum costs the same kernels
 spectra = line["spectra"] + 2
-families = {"accumulate_mfma": "accumulate_mfma", "accumulate_generic": "null model (generic kernel)", "finalize": "finalisation",
+# (finalize_rank20<.., false>: partial sums in the generic kernel's layout -- on this route only the null model's)
+families = {"accumulate_mfma": "accumulate_mfma", "accumulate_generic": "null model (generic kernel + its finalisation, side stream)",
+            "true, false>": "null model (generic kernel + its finalisation, side stream)",
+            "false, false>": "null model (generic kernel + its finalisation, side stream)", "finalize": "finalisation",
             "level_": "level finish", "copy": "transfers (copy_segments + blit copies)", "sweep_init": "sweep_init",
             "interp_model": "set-up", "build_": "set-up", "fill_records": "set-up"}
 split, total = {}, 0.0
@@ -34,4 +40,14 @@ out.update({
     "launches_per_spectrum": round(sum(int(r["Calls"]) for r in rows) / spectra, 1),
     "source": "rocprofv3 --kernel-trace --stats -- python3 tools/measure_route_a.py %d (wall figures: the same tool without the profiler)" % line["spectra"],
 })
+if len(sys.argv) > 3:
+    timeline = json.load(open(sys.argv[3]))["median_us"]
+    busy = timeline["device_busy_in_chain"]
+    out.update({
+        "device_busy_ms_per_spectrum": busy / 1e3,
+        "busy_frac_of_fp64_peak": gflop * 1e9 / (busy / 1e6) / PEAK,
+        "timeline_us_per_spectrum": {"host_between_spectra": timeline["host_gap_between_chains"],
+                                     "first_kernel_to_first_accumulate": timeline["first_kernel_to_first_accumulate"],
+                                     "chain_span": timeline["chain_span"], "device_idle_in_chain": timeline["device_idle_in_chain"]},
+    })
 print(json.dumps(out, indent=1))
