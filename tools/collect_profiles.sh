@@ -38,11 +38,22 @@ for n in 300 685 1250 3061; do
 done
 echo ']' >> $out/frac_vs_n.json
 python3 tools/measure_frac_vs_n.py --pixels 755 --spread 0.65 2>> $out/bench.err | tail -1 > $out/frac_ragged_mix.json
-# the drop-in route (the reference driver's loop, imports swapped): wall time, then the same under rocprofv3 for its kernels
-python3 tools/measure_route_a.py 256 2>/dev/null | tail -1 > $out/route_a_wall.json
+# the drop-in route (the reference driver's loop, imports swapped): wall time (median of three), the same under rocprofv3 for
+# its kernels, the kernels' timeline (chain span, device-busy time, host gap between spectra) and the host's functions
+for i in 1 2 3; do python3 tools/measure_route_a.py 256 2>/dev/null | tail -1 > $out/route_a_wall_$i.json; done
+python3 - "$out" <<'PY'
+import json, sys
+out = sys.argv[1]
+runs = sorted((json.loads(open("%s/route_a_wall_%d.json" % (out, i)).read()) for i in (1, 2, 3)), key=lambda d: d["ms_per_spectrum"])
+median = runs[1]
+median["ms_per_spectrum_runs"] = [r["ms_per_spectrum"] for r in runs]
+json.dump(median, open(out + "/route_a_wall.json", "w"))
+PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_route_a -- python3 tools/measure_route_a.py 256 > $out/route_a_under_rocprof.json 2>> $out/bench.err
 cp $out/prof_route_a/*/*_kernel_stats.csv $out/kernel_stats_route_a.csv
-python3 tools/route_a_frac.py $out/kernel_stats_route_a.csv $out/route_a_wall.json > $out/route_a.json
+python3 tools/route_a_timeline.py $(ls $out/prof_route_a/*/*_kernel_trace.csv | head -1) > $out/route_a_timeline.json
+python3 tools/route_a_frac.py $out/kernel_stats_route_a.csv $out/route_a_wall.json $out/route_a_timeline.json > $out/route_a.json
+python3 tools/route_a_host_segments.py 256 > $out/route_a_host_segments.json 2>> $out/bench.err
 # ... and the catalogue driver's kernels
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_cat -- python3 tools/measure_catalogue.py 1024 10000 32 dr12q > $out/catalogue_under_rocprof.json 2>> $out/bench.err
 cp $out/prof_cat/*/*_kernel_stats.csv $out/kernel_stats_catalogue.csv
