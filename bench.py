@@ -666,19 +666,20 @@ class Workload:
         if config == 2:
             z, nhi = self.z, self.nhi_dla
             if not self.strong:
-                self.devs[0].eval_device(S, 1, z.data_ptr(), nhi.data_ptr(), self.out.data_ptr(), stream)
-                target = self.out
-            else:  # this rank's slice, then all S log-likelihoods on every rank (S / N doubles per rank over RCCL)
-                lo, hi = self.lo, self.hi
-                self.devs[0].eval_device(hi - lo, 1, z.data_ptr() + 8 * lo, nhi.data_ptr() + 8 * lo,
-                                         self.local.data_ptr(), stream)
-                if env.dist_on:
-                    env.all_gather(self.everything, self.local)
-                else:
-                    self.everything.copy_(self.local)
-                target = self.everything
+                # the level's log-likelihoods ("- log S") and its log-mean-exp model evidence (reference dla_gp.py:132-190) in one
+                # call: the evidence comes out of the finalisation kernel's tail, no launch of its own
+                self.devs[0].eval_evidence_device(S, 1, z.data_ptr(), nhi.data_ptr(), self.out.data_ptr(), 0,
+                                                  self.evidences.data_ptr() + 8 * slot, stream=stream)
+                return
+            # this rank's slice, then all S log-likelihoods on every rank (S / N doubles per rank over RCCL)
+            lo, hi = self.lo, self.hi
+            self.devs[0].eval_device(hi - lo, 1, z.data_ptr() + 8 * lo, nhi.data_ptr() + 8 * lo, self.local.data_ptr(), stream)
+            if env.dist_on:
+                env.all_gather(self.everything, self.local)
+            else:
+                self.everything.copy_(self.local)
             # "- log S" and the log-mean-exp model evidence of the level (reference dla_gp.py:155-190)
-            sl.level_evidence_device(target.data_ptr(), 1, S, 0, self.evidences.data_ptr() + 8 * slot,
+            sl.level_evidence_device(self.everything.data_ptr(), 1, S, 0, self.evidences.data_ptr() + 8 * slot,
                                      device=env.local_rank, stream=stream)
             return
         ev = self.evidences.data_ptr() + 8 * slot * self.per_step

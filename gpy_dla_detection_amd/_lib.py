@@ -70,6 +70,9 @@ SIGNATURES = {
     "dlagp_level_finish_device": (c_int, [c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_double, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dlagp_level_evidence_device": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "dlagp_eval_evidence_device": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "dlagp_batch_eval_evidence_device": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                 c_void_p]),
     "dlagp_set_option": (c_int, [c_char_p, c_int64]),
     "dlagp_plan_cut": (c_int, [c_int64, c_double, c_int64, POINTER(c_int), _dp]),
     "dlagp_plan_debug": (c_int, [c_int, POINTER(c_int), POINTER(POINTER(ctypes.c_ubyte)), c_int, c_int64,

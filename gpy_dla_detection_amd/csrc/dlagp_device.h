@@ -124,6 +124,20 @@ struct CopyTable {
     CopySegment seg[DLAGP_COPY_SEGMENTS];
 };
 
+// The level evidence folded into the finalisation (finalize_rank20's optional tail; reference dla_gp.py:155-190): every
+// workgroup writes its samples' log p - log S (NaN where too_close), leaves (max, sum of exp(. - max), count) of its 16 samples
+// in `part[block]`, and the LAST workgroup of a sightline to arrive (ticket) combines the blocks' triples in block order:
+//   evidence = M + log(sum_b s_b exp(m_b - M) / n) - level log S,   M = max_b m_b   (NaN for an all-NaN level).
+// evidence == nullptr: no tail.  tickets[nb] are zero when a launch starts and zero again when it ends.
+struct EvidenceTail {
+    double *evidence;                 // [nb] by batch_index
+    const unsigned char *too_close;   // [nb][S] by batch_index, or nullptr
+    double *part;                     // [nblocks][3] scratch
+    int *tickets;                     // [nb] by the launch's sightline order
+    double log_s;
+    int level;
+};
+
 // What the kernels that end an occupation level need (reference dla_gp.py:155-218; kernels_common.h "level finish").
 // One struct, passed by value, for the one-workgroup kernel and for the three kernels of the spread form.
 //   weights  [nb][S]  exp(value - max) of the level, 0 for a NaN sample

@@ -353,6 +353,7 @@ struct Workspace {
     // and staging of its host-pointer variant
     DeviceBuffer level_ll, cdf, alive, uniforms, evidences, sample_ll, base;
     DeviceBuffer level_x;  // what the phases of the level finish hand each other, [nb][DLAGP_LEVEL_EXCH] (kernels_common.h)
+    DeviceBuffer ev_part, ev_tickets;  // the evidence tail of finalize_rank20: the blocks' triples, the sightlines' ticket counters
     DeviceBuffer ties;     // [nb][max_dlas - 1] searches of the resampling that ended within DLAGP_TIE_MARGIN of a cdf step
     DeviceBuffer cache;  // profile cache of the multi-level sweep, [nb][S][max n_slots]
     DeviceBuffer sub_z, sub_nhi, sub_evidences, sub_ll;  // the one-absorber model of dlagp_batch_model_evidences
@@ -367,6 +368,8 @@ struct Workspace {
         level_ll.release();
         cdf.release();
         level_x.release();
+        ev_part.release();
+        ev_tickets.release();
         ties.release();
         alive.release();
         uniforms.release();
@@ -403,6 +406,7 @@ static Option g_opt_shared_rows = 1;  // cached levels: a wave whose samples sta
 // test hook: contexts with a negative noise variance stay on the MFMA kernel (default: they take the generic kernel, whose
 // per-pixel log(d) is NaN for any negative d as in the reference) -- the tests of that kernel's non-PD flag need them
 static Option g_opt_negative_noise_mfma = 0;
+static Option g_opt_fold_evidence = 1;  // dlagp_*eval_evidence_device: the evidence in finalize_rank20's tail (0: a launch of its own)
 static Option g_opt_finalize_wave = 1;  // ranks above 20: one wave per sample factors the matrix in LDS (0: one thread per sample)
 
 // Decomposition of one MFMA launch (a launch group at one sample count) into work items, see build_plan
@@ -737,6 +741,7 @@ static bool fused_eligible(const LaunchGroup &g, const LaunchPlan *plan, int pat
 // broadening, cores repaired once per wave, rank 20, a homogeneous batch); finished by the waves themselves on single-piece
 // plans and by finalize_rank20 otherwise.  Option "pair_models" = 0 keeps the two launches (the cross-check).
 static Option g_last_sweep_paired = 0;
+static Option g_last_evidence_folded = 0;  // the most recent dlagp_*eval_evidence_device: 1 = evidence from finalize_rank20's tail
 static int64_t pair_virtual_samples(int64_t S) { return 16 * ((S + 7) / 8); }
 static bool pair_eligible(LaunchGroup &g, int64_t S) {
     if (!call_options().pair_models || !g.parts.empty() || (call_options().debug & 2)) return false;
@@ -762,8 +767,17 @@ static void launch_finalize_general(hipStream_t stream, const double *part, int 
 // One homogeneous launch group: accumulate + finalize.  `status`: the non-PD flag the finalisation raises (the
 // group's own unless the caller shares one between the parts of a heterogeneous batch); `keep_status`: this launch
 // must not clear it (an earlier part of the same level may have raised it).
+// `tail`: the level evidence the caller wants with the log-likelihoods (dlagp_eval_evidence_device).  A plan that ends in
+// finalize_rank20 computes it there (EvidenceTail, dlagp_device.h) and sets tail->done; any other plan leaves it to the caller.
+struct TailRequest {
+    int level = 0;
+    const unsigned char *too_close = nullptr;
+    double *evidence = nullptr;
+    bool done = false;
+};
 static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src, double *d_out, hipStream_t stream,
-                      int *status_shared = nullptr, bool keep_status = false, double *d_out2 = nullptr) {
+                      int *status_shared = nullptr, bool keep_status = false, double *d_out2 = nullptr,
+                      TailRequest *tail = nullptr) {
     CallOptionsScope options_of_this_call;
     if (S <= 0) return DLAGP_OK;
     Workspace &ws = g.ws;
@@ -903,9 +917,22 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
         // which layout the partial sums are in: the MFMA kernel's tiles as they come, or the generic kernel's columns
         auto fin = row16 ? (use_mfma ? finalize_rank20<true, true> : finalize_rank20<true, false>)
                          : (use_mfma ? finalize_rank20<false, true> : finalize_rank20<false, false>);
+        EvidenceTail ev{};
+        if (tail && tail->evidence && !src.pair_S && g_opt_fold_evidence) {
+            // the blocks' triples and the sightlines' ticket counters (zero between launches: zeroed when the buffer is
+            // made, put back by the kernel's last workgroup)
+            if ((rc = grow(g, ws.ev_part, (size_t)nblocks * 3 * sizeof(double)))) return rc;
+            if (ws.ev_tickets.bytes < (size_t)nb * sizeof(int)) {
+                if ((rc = grow(g, ws.ev_tickets, (size_t)nb * sizeof(int)))) return rc;
+                HIP_TRY(hipMemsetAsync(ws.ev_tickets.ptr, 0, ws.ev_tickets.bytes, stream));
+            }
+            ev = EvidenceTail{tail->evidence, tail->too_close, ws.ev_part.as<double>(), ws.ev_tickets.as<int>(),
+                              std::log((double)S), tail->level};
+            tail->done = true;
+        }
         hipLaunchKernelGGL(fin, dim3((unsigned)nblocks), dim3(DLAGP_FIN_THREADS), lds_bytes, stream,
                            ws.part.as<double>(), nparts, rows, (long)S, table, d_out, status,
-                           plan ? plan->counts() : nullptr, src.pair_S ? d_out2 : nullptr, (long)src.pair_S);
+                           plan ? plan->counts() : nullptr, src.pair_S ? d_out2 : nullptr, (long)src.pair_S, ev);
     } else {
         launch_finalize_general(stream, ws.part.as<const double>(), nparts, rows, (long)S, table, d_out, status,
                                 plan ? plan->counts() : nullptr);
@@ -917,12 +944,13 @@ static int launch_one(LaunchGroup &g, int64_t S, int kd, const SampleSource &src
 // The launch group itself, or -- for a batch that mixes kernel flavours -- its homogeneous parts one after the other
 // on the same stream, all raising the one non-PD flag of `g`.
 static int launch_sweep(LaunchGroup &g, int64_t S, int kd, const SampleSource &src, double *d_out,
-                        hipStream_t stream) {
+                        hipStream_t stream, TailRequest *tail = nullptr) {
     CallOptionsScope options_of_this_call;
     g_last_launch_groups = g.parts.empty() ? 1 : (int64_t)g.parts.size();
     int rc = enter_stream(g, stream);
     if (rc) return rc;
-    if (g.parts.empty() || kd == 0 || S <= 0) return launch_one(g, S, kd, src, d_out, stream);  // kd == 0: null model, generic kernel anyway
+    if (g.parts.empty() || kd == 0 || S <= 0)  // kd == 0: null model, generic kernel anyway
+        return launch_one(g, S, kd, src, d_out, stream, nullptr, false, nullptr, tail);
     if ((rc = grow(g, g.ws.status, sizeof(int)))) return rc;
     g.last_stream = stream;
     g.launched = true;
@@ -1249,7 +1277,7 @@ static int launch_null_side(LaunchGroup &g, double *d_out, hipStream_t side) {
         auto fin = row16 ? finalize_rank20<true, false> : finalize_rank20<false, false>;
         hipLaunchKernelGGL(fin, dim3((unsigned)nblocks), dim3(DLAGP_FIN_THREADS), DLAGP_FINALIZE_LDS_DOUBLES * sizeof(double), side,
                            ws.null_part.as<double>(), nparts, (long)nb, 1L, table, d_out, status, (const unsigned char *)nullptr,
-                           (double *)nullptr, 0L);
+                           (double *)nullptr, 0L, EvidenceTail{});
     } else {
         launch_finalize_general(side, ws.null_part.as<const double>(), nparts, (long)nb, 1L, table, d_out, status, nullptr);
     }
@@ -2454,6 +2482,50 @@ int dlagp_batch_eval_device(dlagp_batch *batch, int64_t S, int kd, const double 
                         static_cast<hipStream_t>(stream));
 } DLAGP_CATCH_INT("dlagp_batch_eval_device")
 
+// Log-likelihoods AND the level's evidence in one call (the by-sample pair dlagp_*eval_device + dlagp_level_evidence_device;
+// reference dla_gp.py:132-190 for one occupation level): d_out receives log p - log S (NaN where too_close), d_evidence the
+// log-mean-exp evidence.  Where the launch ends in finalize_rank20 the evidence is that kernel's tail (the last workgroup to
+// arrive combines the blocks' sums: no second launch); plans that finalise in the accumulate waves, ranks above 20, mixed
+// batches and the generic kernel get the level_evidence launch behind theirs.
+static int eval_with_evidence(LaunchGroup &g, int64_t S, int kd, const double *d_z, const double *d_nhi, double *d_out, int level,
+                              const uint8_t *d_too_close, double *d_evidence, hipStream_t stream) {
+    if (!d_evidence) return fail(DLAGP_EINVAL, "d_evidence is NULL");
+    if (level < 0) return fail(DLAGP_EINVAL, "level = %d, need level >= 0", level);
+    TailRequest tail;
+    tail.level = level;
+    tail.too_close = d_too_close;
+    tail.evidence = d_evidence;
+    int rc = launch_sweep(g, S, kd, SampleSource{d_z, d_nhi, nullptr, 0, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0}, d_out, stream, &tail);
+    if (rc) return rc;
+    g_last_evidence_folded = tail.done ? 1 : 0;
+    if (!tail.done) {
+        hipLaunchKernelGGL(level_evidence, dim3((unsigned)g.ctxs.size()), dim3(DLAGP_EVIDENCE_THREADS), 0, stream, d_out, (long)S, level,
+                           d_too_close, d_evidence, std::log((double)S));
+        HIP_TRY(hipGetLastError());
+    }
+    return DLAGP_OK;
+}
+
+int dlagp_eval_evidence_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, const double *d_nhi, double *d_out,
+                               int level, const uint8_t *d_too_close, double *d_evidence, void *stream) try {
+    int rc = check_eval_args(ctx, S, kd, d_z, d_nhi, d_out);
+    if (rc) return rc;
+    if (S <= 0) return fail(DLAGP_EINVAL, "S = %lld, need S > 0", (long long)S);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = wait_setup(ctx))) return rc;
+    return eval_with_evidence(ctx->self, S, kd, d_z, d_nhi, d_out, level, d_too_close, d_evidence, static_cast<hipStream_t>(stream));
+} DLAGP_CATCH_INT("dlagp_eval_evidence_device")
+
+int dlagp_batch_eval_evidence_device(dlagp_batch *batch, int64_t S, int kd, const double *d_z, const double *d_nhi, double *d_out,
+                                     int level, const uint8_t *d_too_close, double *d_evidence, void *stream) try {
+    int rc = check_eval_args(batch, S, kd, d_z, d_nhi, d_out);
+    if (rc || (rc = batch_alive(batch))) return rc;
+    if (S <= 0) return fail(DLAGP_EINVAL, "S = %lld, need S > 0", (long long)S);
+    cancel_pending(batch);
+    HIP_TRY(hipSetDevice(batch->group.device));
+    return eval_with_evidence(batch->group, S, kd, d_z, d_nhi, d_out, level, d_too_close, d_evidence, static_cast<hipStream_t>(stream));
+} DLAGP_CATCH_INT("dlagp_batch_eval_evidence_device")
+
 int dlagp_batch_eval(dlagp_batch *batch, int64_t S, int kd, const double *z, const double *nhi, double *out) try {
     int rc = check_eval_args(batch, S, kd, z, nhi, out);
     if (rc || (rc = batch_alive(batch))) return rc;
@@ -3001,6 +3073,7 @@ int dlagp_set_option(const char *name, int64_t value) try {
     else if (!strcmp(name, "pack_setup_uploads")) g_opt_pack_setup_uploads = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(name, "pack_transfers")) g_opt_pack_transfers = value != 0;
     else if (!strcmp(name, "null_side_level")) g_opt_null_side_level = value;
+    else if (!strcmp(name, "fold_evidence")) g_opt_fold_evidence = value != 0;
     else if (!strcmp(name, "null_side")) g_opt_null_side = value != 0;
     else if (!strcmp(name, "level_spread")) g_opt_level_spread = value != 0;
     else if (!strcmp(name, "level_search_groups")) g_opt_level_search_groups = value < 1 ? 1 : (value > 64 ? 64 : value);
@@ -3051,6 +3124,8 @@ int dlagp_get_option(const char *name, int64_t *value) try {
     else if (!strcmp(name, "last_launch_fused")) *value = g_last_launch_fused;
     else if (!strcmp(name, "pair_models")) *value = g_opt_pair_models;
     else if (!strcmp(name, "last_sweep_paired")) *value = g_last_sweep_paired;
+    else if (!strcmp(name, "last_evidence_folded")) *value = g_last_evidence_folded;
+    else if (!strcmp(name, "fold_evidence")) *value = g_opt_fold_evidence;
     else if (!strcmp(name, "pack_setup_uploads")) *value = g_opt_pack_setup_uploads;
     else if (!strcmp(name, "pack_transfers")) *value = g_opt_pack_transfers;
     else if (!strcmp(name, "null_side_level")) *value = g_opt_null_side_level;

@@ -9,7 +9,7 @@ inline LineConstants DLAGP_LINES;
 inline unsigned long long DLAGP_STAMPS[8];
 template <bool ROW16, bool NATIVE>
 void finalize_rank20(const double *, int, long, long, const SightlineDev *, double *, int *, const unsigned char *, double * = nullptr,
-                     long = 0) {}  // the real kernel's parameter list (kernels_common.h): the host side takes its address
+                     long = 0, EvidenceTail = EvidenceTail{}) {}  // the real kernel's parameter list (kernels_common.h): the host side takes its address
 template <bool CUM_IN_LDS>
 void level_finish_fused(LevelArgs) {}
 inline void level_weights(LevelArgs) {}
@@ -39,6 +39,9 @@ inline void mark_arg(const LevelArgs &a, Stream *s, uint64_t t) {
                           (const void *)a.base, (const void *)a.weights, (const void *)a.exch, (const void *)a.alive,
                           (const void *)a.status, (const void *)a.ties})
         mark(p, s, t);
+}
+inline void mark_arg(const EvidenceTail &e, Stream *s, uint64_t t) {
+    for (const void *p : {(const void *)e.evidence, (const void *)e.too_close, (const void *)e.part, (const void *)e.tickets}) mark(p, s, t);
 }
 inline void mark_arg(const LevelArgsTwo &p, Stream *s, uint64_t t) {
     mark_arg(p.first, s, t);

@@ -608,13 +608,123 @@ __global__ __launch_bounds__(256) void regroup_native(const double *__restrict__
     }
 }
 
+// The tail of finalize_rank20 with an EvidenceTail (dlagp_device.h): called by ALL threads of the workgroup, uniformly.
+//   writer / smp / value: this thread holds sample `smp`'s log-density (NaN if its matrix was not positive definite)
+//   row: the sample's position in the caller's arrays; b / g / ngroups: sightline, block of the sightline, blocks per sightline
+// The blocks' triples are combined in an order that does not depend on which workgroup arrives last: thread t of the last
+// workgroup takes blocks t, t + 256, ... in that order, the threads' sums meet in a fixed tree -- the same bits run after run.
+__device__ __forceinline__ double tail_load(const double *p) {  // from the device's coherent level, never a stale cache line
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void evidence_tail(const EvidenceTail &ev, bool writer, int smp, double value, long row, double *out,
+                                              long b, long g, long ngroups, int batch_index, int valid) {
+    __shared__ double tail_v[DLAGP_FIN_SAMPLES];
+    __shared__ double tail_red[3 * (DLAGP_FIN_THREADS / 64)];
+    __shared__ int tail_last;
+    const int tid = threadIdx.x;
+    const double nan = __builtin_nan("");
+    if (writer) {
+        double v = value - ev.log_s;  // the "additional Occam's razor" (dla_gp.py:157-159)
+        if (ev.too_close && ev.too_close[row]) v = nan;  // separation mask (:164-177)
+        out[row] = v;
+        tail_v[smp] = v;
+    }
+    __syncthreads();
+    if (tid < 64) {  // the block's triple: max, sum of exp(. - max) in sample order, count of finite samples
+        const double x = tid < valid ? tail_v[tid] : nan;  // (the block's samples beyond S have no writer)
+        double m = x == x ? x : -__builtin_inf();
+        for (int off = 8; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+        const double e = x == x ? exp(x - m) : 0.0;
+        double sum = 0.0, count = 0.0;
+        for (int i = 0; i < DLAGP_FIN_SAMPLES; ++i) {
+            sum += __shfl(e, i);
+            count += __shfl(x == x ? 1.0 : 0.0, i);
+        }
+        if (tid == 0) {
+            double *mine = ev.part + 3 * (b * ngroups + g);
+            __hip_atomic_store(mine + 0, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 1, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 2, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // The hand-off of MI355X_MICROARCH.md ("hand-offs measured with sc1 loads in place of the acquire", first row):
+            // write-through (sc1) stores, this wave's wait for them, then ONE relaxed agent-scope add; the workgroup whose add
+            // came last reads with sc1 loads behind a barrier.  No agent-scope fence: a release per workgroup writes back the
+            // XCD's L2 (1.7-6.5 us each, four workgroups per compute unit) -- with __threadfence() here this kernel took
+            // 40 us instead of 18 and the fold LOST 22 us per launch (profiles/r06_experiments.txt item 16).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tail_last = __hip_atomic_fetch_add(ev.tickets + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)ngroups - 1;
+        }
+    }
+    __syncthreads();
+    if (!tail_last) return;  // (the barrier above is the one the adding wave joins before anybody loads)
+    const double *parts = ev.part + 3 * b * ngroups;
+    const int wave = tid >> 6;
+    // this thread's blocks t, t + 256, ...: all of their triples requested before the first is used (up to KEEP blocks per
+    // thread stay in registers: 16 384 samples per sightline; longer levels read theirs again)
+    constexpr int KEEP = 4;
+    double pm[KEEP], ps[KEEP], pc[KEEP];
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        const long blk = tid + (long)k * DLAGP_FIN_THREADS;
+        const bool there = blk < ngroups;
+        pm[k] = there ? tail_load(parts + 3 * blk) : 0.0;
+        ps[k] = there ? tail_load(parts + 3 * blk + 1) : 0.0;
+        pc[k] = there ? tail_load(parts + 3 * blk + 2) : 0.0;
+    }
+    double m = -__builtin_inf();
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k)
+        if (pc[k] > 0.0) m = fmax(m, pm[k]);
+    for (long blk = tid + (long)KEEP * DLAGP_FIN_THREADS; blk < ngroups; blk += DLAGP_FIN_THREADS)
+        if (tail_load(parts + 3 * blk + 2) > 0.0) m = fmax(m, tail_load(parts + 3 * blk));
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0) tail_red[wave] = m;
+    __syncthreads();
+    m = tail_red[0];
+    for (int w = 1; w < DLAGP_FIN_THREADS / 64; ++w) m = fmax(m, tail_red[w]);
+    __syncthreads();
+    double sum = 0.0, count = 0.0;
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k)
+        if (pc[k] > 0.0) {
+            sum += ps[k] * exp(pm[k] - m);
+            count += pc[k];
+        }
+    for (long blk = tid + (long)KEEP * DLAGP_FIN_THREADS; blk < ngroups; blk += DLAGP_FIN_THREADS) {
+        const double c = tail_load(parts + 3 * blk + 2);
+        if (c > 0.0) {
+            sum += tail_load(parts + 3 * blk + 1) * exp(tail_load(parts + 3 * blk) - m);
+            count += c;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off);
+        count += __shfl_xor(count, off);
+    }
+    if ((tid & 63) == 0) {
+        tail_red[wave] = sum;
+        tail_red[DLAGP_FIN_THREADS / 64 + wave] = count;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double total = 0.0, n = 0.0;
+        for (int w = 0; w < DLAGP_FIN_THREADS / 64; ++w) {
+            total += tail_red[w];
+            n += tail_red[DLAGP_FIN_THREADS / 64 + w];
+        }
+        // an all-NaN level: nanmax and nanmean are NaN (dla_gp.py:180-190)
+        ev.evidence[batch_index] = n > 0.0 ? m + log(total / n) - ev.level * ev.log_s : nan;
+        ev.tickets[b] = 0;  // the next launch finds its ticket counter at zero
+    }
+}
+
 // NATIVE: the partial sums come from the MFMA kernel (layout above); else from the generic kernel (column-major).
 template <bool ROW16, bool NATIVE>
 __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const double *__restrict__ part, int nsplit, long rows, long S,
                                                       const SightlineDev *__restrict__ sightlines,
                                                       double *__restrict__ out, int *__restrict__ status,
                                                       const unsigned char *__restrict__ part_counts,
-                                                      double *__restrict__ out2 = nullptr, long pair_S = 0) {
+                                                      double *__restrict__ out2 = nullptr, long pair_S = 0,
+                                                      EvidenceTail ev = EvidenceTail{}) {
     extern __shared__ double fin_lds[];
     constexpr int K = DLAGP_FIN_K;
     constexpr int NC = DLAGP_FIN_COLS;
@@ -763,58 +873,70 @@ __global__ __launch_bounds__(DLAGP_FIN_THREADS) void finalize_rank20(const doubl
         const double *col = fin_lds + smp;
         bool bad = false;
         double result = factor_solve_row16<LS>(col, q, col[(NC + K + 2) * LS], bad);
-        if (q != 4 || smp >= valid) return;  // row 20 = t sits in lane 4; samples beyond S hold unwritten partials
+        const bool writer = q == 4 && smp < valid;  // row 20 = t sits in lane 4; samples beyond S hold unwritten partials
+        if (writer && bad) {
+            result = __builtin_nan("");
+            atomicOr(status, 1);
+        }
+        if (ev.evidence) {  // (never with a pair launch: the host passes no tail then)
+            evidence_tail(ev, writer, smp, result, row0 + smp, out, b, g, ngroups, sightlines[b].batch_index, valid);
+            return;
+        }
+        if (writer) store(smp, result);
+        return;
+    }
+    // ---- factor + solve, one lane per sample (launches of many blocks: fewest instructions per sample)
+    const bool active = tid < valid;  // lanes beyond the sightline's last sample hold unwritten partials
+    if (!active && !ev.evidence) return;  // (with a tail they take part in its barriers)
+    double result = 0.0;
+    if (active) {
+        double *mine = fin_lds + tid;
+
+        double t[K], inv_diag[K];
+        double tt = 0.0;
+        LogProduct pivots;
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            double r[K];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) r[j] = mine[vech_col(i, j) * LS];
+            r[i] += 1.0;  // identity on the diagonal (null_gp.py:341)
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+                double s = r[j];
+#pragma unroll
+                for (int m = 0; m < j; ++m) s = fma(-r[m], mine[vech_col(j, m) * LS], s);
+                r[j] = s * inv_diag[j];
+            }
+            double s = r[i];
+#pragma unroll
+            for (int m = 0; m < i; ++m) s = fma(-r[m], r[m], s);
+            if (s <= 0.0) bad = true;  // NaN pivots propagate silently, as LAPACK's do
+            pivots.multiply(s);        // log det B = sum log L_ii^2
+            const double inv = fast_rsqrt(s);  // the same pivot arithmetic as the 16-lane form
+            inv_diag[i] = inv;
+#pragma unroll
+            for (int j = 0; j < i; ++j) mine[vech_col(i, j) * LS] = r[j];
+            double ti = mine[(NC + i) * LS];
+#pragma unroll
+            for (int m = 0; m < i; ++m) ti = fma(-r[m], t[m], ti);
+            ti *= inv;
+            t[i] = ti;
+            tt = fma(ti, ti, tt);
+        }
+        const double sum_r2 = mine[(NC + K) * LS];
+        const double sum_logd = mine[(NC + K + 1) * LS];
+        const double n_log_2pi = mine[(NC + K + 2) * LS];
+        result = -0.5 * ((sum_r2 - tt) + (sum_logd + pivots.log_value()) + n_log_2pi);
         if (bad) {
             result = __builtin_nan("");
             atomicOr(status, 1);
         }
-        store(smp, result);
+    }
+    if (ev.evidence) {
+        evidence_tail(ev, active, tid, result, row0 + tid, out, b, g, ngroups, sightlines[b].batch_index, valid);
         return;
-    }
-    // ---- factor + solve, one lane per sample (launches of many blocks: fewest instructions per sample)
-    if (tid >= valid) return;  // lanes beyond the sightline's last sample hold unwritten partials
-    double *mine = fin_lds + tid;
-
-    double t[K], inv_diag[K];
-    double tt = 0.0;
-    LogProduct pivots;
-    bool bad = false;
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-        double r[K];
-#pragma unroll
-        for (int j = 0; j <= i; ++j) r[j] = mine[vech_col(i, j) * LS];
-        r[i] += 1.0;  // identity on the diagonal (null_gp.py:341)
-#pragma unroll
-        for (int j = 0; j < i; ++j) {
-            double s = r[j];
-#pragma unroll
-            for (int m = 0; m < j; ++m) s = fma(-r[m], mine[vech_col(j, m) * LS], s);
-            r[j] = s * inv_diag[j];
-        }
-        double s = r[i];
-#pragma unroll
-        for (int m = 0; m < i; ++m) s = fma(-r[m], r[m], s);
-        if (s <= 0.0) bad = true;  // NaN pivots propagate silently, as LAPACK's do
-        pivots.multiply(s);        // log det B = sum log L_ii^2
-        const double inv = fast_rsqrt(s);  // the same pivot arithmetic as the 16-lane form
-        inv_diag[i] = inv;
-#pragma unroll
-        for (int j = 0; j < i; ++j) mine[vech_col(i, j) * LS] = r[j];
-        double ti = mine[(NC + i) * LS];
-#pragma unroll
-        for (int m = 0; m < i; ++m) ti = fma(-r[m], t[m], ti);
-        ti *= inv;
-        t[i] = ti;
-        tt = fma(ti, ti, tt);
-    }
-    const double sum_r2 = mine[(NC + K) * LS];
-    const double sum_logd = mine[(NC + K + 1) * LS];
-    const double n_log_2pi = mine[(NC + K + 2) * LS];
-    double result = -0.5 * ((sum_r2 - tt) + (sum_logd + pivots.log_value()) + n_log_2pi);
-    if (bad) {
-        result = __builtin_nan("");
-        atomicOr(status, 1);
     }
     store(tid, result);
 }

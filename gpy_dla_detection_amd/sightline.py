@@ -194,6 +194,16 @@ class DeviceSightline:
         """enqueue on `stream` (raw hipStream_t value); pointers are device addresses"""
         _lib.check(_lib.load().dlagp_eval_device(self._handle, S, kd, d_z, d_nhi, d_out, stream))
 
+    def eval_evidence_device(self, S: int, kd: int, d_z: int, d_nhi: int, d_out: int, level: int, d_evidence: int,
+                             d_too_close: int = 0, stream: int = 0) -> None:
+        """
+        `eval_device` and `level_evidence_device` in one call (dlagp_eval_evidence_device): d_out receives log p - log S
+        (NaN where too_close), d_evidence the level's log-mean-exp evidence -- from the finalisation kernel's own tail where
+        the launch has one, no second launch (reference dla_gp.py:132-190 for one level)
+        """
+        _lib.check(_lib.load().dlagp_eval_evidence_device(self._handle, S, kd, d_z, d_nhi, d_out, level, d_too_close or None,
+                                                          d_evidence, stream))
+
 
 def prepare_params(params, normalize: bool = True) -> "_lib.PrepareParams":
     """`Parameters` (reference set_parameters.py:14-165) as the native data half reads it (dlagp_prepare_params)"""
@@ -424,6 +434,12 @@ class DeviceBatch:
 
     def eval_device(self, S: int, kd: int, d_z: int, d_nhi: int, d_out: int, stream: int = 0) -> None:
         _lib.check(_lib.load().dlagp_batch_eval_device(self._handle, S, kd, d_z, d_nhi, d_out, stream))
+
+    def eval_evidence_device(self, S: int, kd: int, d_z: int, d_nhi: int, d_out: int, level: int, d_evidence: int,
+                             d_too_close: int = 0, stream: int = 0) -> None:
+        """every member's level in one call: log-likelihoods minus log S and evidences (dlagp_batch_eval_evidence_device)"""
+        _lib.check(_lib.load().dlagp_batch_eval_evidence_device(self._handle, S, kd, d_z, d_nhi, d_out, level,
+                                                                d_too_close or None, d_evidence, stream))
 
     def resample_ties(self, max_dlas: int) -> np.ndarray:
         """(nb, max_dlas - 1) near-tie counts of the batch's most recent sweep (dlagp_batch_resample_ties)"""

@@ -373,6 +373,23 @@ int dlagp_level_evidence_device(double *d_ll, int nb, int64_t S, int level, cons
                                 double *d_evidence, int device, void *stream);
 
 /*
+ * dlagp_eval_device / dlagp_batch_eval_device and dlagp_level_evidence_device as ONE call, for one occupation level whose
+ * samples all sit on this device (reference dla_gp.py:132-190): d_out [nb][S] receives log p - log S (NaN where
+ * d_too_close[b][i] != 0; NULL = no mask), d_evidence[b] the level's evidence.  Where the launch ends in the separate
+ * finalisation kernel (one sightline or few: the partial sums of a block's pieces are added there) the evidence is computed in
+ * that kernel's tail -- every workgroup leaves (max, sum of exp(. - max), count) of its 16 samples, the last one to arrive
+ * combines them in block order -- and no further launch follows; otherwise (batches that finalise inside the accumulate
+ * waves, ranks above 20, mixed flavours) dlagp_level_evidence_device's kernel is enqueued behind.  d_out is the same either
+ * way, bit for bit; the evidence of the two forms agrees to rounding (two-stage against one-stage log-sum-exp), and each form
+ * returns the same bits run after run.  dlagp_get_option("last_evidence_folded") tells which one ran; option "fold_evidence"
+ * = 0 forces the second.
+ */
+int dlagp_eval_evidence_device(dlagp_ctx *ctx, int64_t S, int kd, const double *d_z, const double *d_nhi, double *d_out,
+                               int level, const uint8_t *d_too_close, double *d_evidence, void *stream);
+int dlagp_batch_eval_evidence_device(dlagp_batch *batch, int64_t S, int kd, const double *d_z, const double *d_nhi,
+                                     double *d_out, int level, const uint8_t *d_too_close, double *d_evidence, void *stream);
+
+/*
  * One sightline's samples split over several GPUs (by-sample partition).  The samples of an
  * occupation level are independent (reference dla_gp.py:132-159; MATLAB parfor,
  * multi_dlas/process_qsos_multiple_dlas_meanflux.m:333) but the resampling needs all of them (:209-218).  Per level:

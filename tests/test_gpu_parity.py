@@ -2841,3 +2841,116 @@ def test_device_entry_points_are_graph_capturable():
     torch.cuda.synchronize()
     assert torch.equal(out, want) and torch.equal(ev, want_ev)
     np.testing.assert_allclose(out.cpu().numpy() + np.log(S), dev.eval(z, nhi), rtol=1e-13)
+
+
+def test_level_evidence_from_the_finalisation_kernels_tail(restore_options):
+    """
+    dlagp_eval_evidence_device = dlagp_eval_device + dlagp_level_evidence_device (reference dla_gp.py:132-190 for one level) in
+    one call.  Where the launch ends in finalize_rank20 the evidence comes from that kernel's tail -- the last workgroup to
+    arrive combines the blocks' (max, sum, count) -- and no second launch follows: the log-likelihoods are the two calls'
+    bit for bit (minus log S, NaN where masked), the evidence agrees with theirs to rounding and with NumPy's log-mean-exp,
+    the same bits run after run; sample counts that do not fill the last block, a masked level, an all-NaN level, a
+    not-positive-definite sample; option fold_evidence = 0 is the two launches exactly.  A batch of three sightlines draws one
+    ticket counter per member.
+    """
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch has no GPU")
+    from gpy_dla_detection_amd import sightline as sl
+    from gpy_dla_detection_amd.sightline import DeviceBatch, get_option, set_option
+
+    device = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+
+    def both_ways(target, nb, S, kd, z, nhi, level, mask):
+        d_z, d_n = torch.from_numpy(z).to(device), torch.from_numpy(nhi).to(device)
+        d_mask = torch.from_numpy(mask).to(device) if mask is not None else None
+        mask_ptr = d_mask.data_ptr() if d_mask is not None else 0
+        want = torch.empty((nb, S), dtype=torch.float64, device=device)
+        want_ev = torch.zeros(nb, dtype=torch.float64, device=device)
+        target.eval_device(S, kd, d_z.data_ptr(), d_n.data_ptr(), want.data_ptr())
+        sl.level_evidence_device(want.data_ptr(), nb, S, level, want_ev.data_ptr(), d_too_close=mask_ptr)
+        got = torch.full((nb, S), 7.0, dtype=torch.float64, device=device)
+        got_ev = torch.full((nb,), 7.0, dtype=torch.float64, device=device)
+        target.eval_evidence_device(S, kd, d_z.data_ptr(), d_n.data_ptr(), got.data_ptr(), level, got_ev.data_ptr(), d_too_close=mask_ptr)
+        torch.cuda.synchronize()
+        return want.cpu().numpy(), want_ev.cpu().numpy(), got.cpu().numpy(), got_ev.cpu().numpy()
+
+    def numpy_evidence(ll, level, S):
+        out = np.full(ll.shape[0], np.nan)
+        for b, row in enumerate(ll):
+            if np.isfinite(row).any():
+                top = np.nanmax(row)
+                out[b] = top + np.log(np.nanmean(np.exp(row - top))) - level * np.log(S)
+        return out
+
+    sight = make_sightline(3, n_unmasked=1400, n_masked=23)
+    dev = device_sightline(sight)
+    for S, kd, level, masked in ((10000, 1, 0, False), (1003, 2, 1, True), (17, 1, 0, False), (4096, 3, 2, True)):
+        z, _, nhi = make_qmc_samples(sight, S * kd)
+        z, nhi = z.reshape(S, kd).copy(), nhi.reshape(S, kd).copy()
+        mask = (rng.random((1, S)) < 0.2).astype(np.uint8) if masked else None
+        want, want_ev, got, got_ev = both_ways(dev, 1, S, kd, z, nhi, level, mask)
+        assert get_option("last_evidence_folded") == 1, (S, kd)
+        np.testing.assert_array_equal(got, want)  # NaN == NaN here
+        if masked:
+            assert np.isnan(got[0][mask[0] != 0]).all() and np.isfinite(got[0][mask[0] == 0]).all()
+        np.testing.assert_allclose(got_ev, want_ev, rtol=1e-13)
+        np.testing.assert_allclose(got_ev, numpy_evidence(got, level, S), rtol=1e-13)
+        # the same bits run after run, whichever workgroup arrives last
+        d_z, d_n = torch.from_numpy(z).to(device), torch.from_numpy(nhi).to(device)
+        d_mask = torch.from_numpy(mask).to(device) if masked else None
+        out = torch.empty((1, S), dtype=torch.float64, device=device)
+        evs = torch.zeros(24, dtype=torch.float64, device=device)
+        for i in range(24):
+            dev.eval_evidence_device(S, kd, d_z.data_ptr(), d_n.data_ptr(), out.data_ptr(), level, evs.data_ptr() + 8 * i,
+                                     d_too_close=d_mask.data_ptr() if masked else 0)
+        torch.cuda.synchronize()
+        assert np.unique(evs.cpu().numpy().view(np.int64)).size == 1
+        np.testing.assert_array_equal(evs.cpu().numpy()[:1], got_ev)
+        # launches that alternate between two masks: every evidence is its own launch's, never a block's sums left over from
+        # the launch before (the blocks' triples cross compute units through write-through stores and a ticket, no fence)
+        other = (rng.random((1, S)) < 0.5).astype(np.uint8)
+        d_other = torch.from_numpy(other).to(device)
+        _, _, _, other_ev = both_ways(dev, 1, S, kd, z, nhi, level, other)
+        evs = torch.zeros(40, dtype=torch.float64, device=device)
+        for i in range(40):
+            use = d_other.data_ptr() if i % 2 else (d_mask.data_ptr() if masked else 0)
+            dev.eval_evidence_device(S, kd, d_z.data_ptr(), d_n.data_ptr(), out.data_ptr(), level, evs.data_ptr() + 8 * i, d_too_close=use)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(evs.cpu().numpy()[0::2], np.repeat(got_ev, 20))
+        np.testing.assert_array_equal(evs.cpu().numpy()[1::2], np.repeat(other_ev, 20))
+        assert other_ev[0] != got_ev[0]
+        # the two launches behind one call
+        set_option("fold_evidence", 0)
+        _, _, apart, apart_ev = both_ways(dev, 1, S, kd, z, nhi, level, mask)
+        assert get_option("last_evidence_folded") == 0
+        set_option("fold_evidence", 1)
+        np.testing.assert_array_equal(apart, want)
+        np.testing.assert_array_equal(apart_ev, want_ev)
+
+    # every sample masked: an all-NaN level has a NaN evidence (np.nanmax / np.nanmean of nothing)
+    S = 500
+    z, _, nhi = make_qmc_samples(sight, S)
+    want, want_ev, got, got_ev = both_ways(dev, 1, S, 1, z, nhi, 0, np.ones((1, S), dtype=np.uint8))
+    assert np.isnan(got).all() and np.isnan(got_ev).all() and np.isnan(want_ev).all()
+
+    # three sightlines of different lengths: one ticket counter each, evidences at the members' positions
+    sights = [make_sightline(40 + i, n_unmasked=n_u, n_masked=m) for i, (n_u, m) in enumerate([(700, 3), (1250, 40), (300, 0)])]
+    devs = [device_sightline(s) for s in sights]
+    batch = DeviceBatch(devs)
+    S = 1500
+    zs = np.stack([make_qmc_samples(s, S)[0] for s in sights])
+    nhi = np.stack([make_qmc_samples(s, S)[2] for s in sights])
+    mask = (rng.random((3, S)) < 0.1).astype(np.uint8)
+    want, want_ev, got, got_ev = both_ways(batch, 3, S, 1, zs, nhi, 0, mask)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_allclose(got_ev, want_ev, rtol=1e-13)
+    np.testing.assert_allclose(got_ev, numpy_evidence(got, 0, S), rtol=1e-13)
+    for b, d in enumerate(devs):  # ... and each member on its own (its launch is cut at other pixels: agreement to rounding)
+        one = both_ways(d, 1, S, 1, zs[b], nhi[b], 0, mask[b:b + 1])
+        np.testing.assert_allclose(one[2][0], got[b], rtol=1e-11)
+        np.testing.assert_allclose(one[3][0], got_ev[b], rtol=1e-11)
+    batch.close()
+    for d in devs + [dev]:
+        d.close()
