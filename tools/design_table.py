@@ -36,7 +36,10 @@ print("| accumulate_mfma, configs[1] | %.4f ms by HIP events → %.1f TFLOP/s = 
       % (r["kernel_ms"], r["achieved"], 100 * r["frac"], 100 * r["frac_cold"], (avg or 0) / 1e3, calls, tag, tag))
 fin, _ = kernel_avg("kernel_stats.csv", "finalize_rank20")
 ev, _ = kernel_avg("kernel_stats.csv", "level_evidence")
-print("| finalize_rank20 / level_evidence | %.1f / %.1f µs | `%s_kernel_stats.csv` |" % (fin or 0, ev or 0, tag))
+if ev:
+    print("| finalize_rank20 / level_evidence | %.1f / %.1f µs | `%s_kernel_stats.csv` |" % (fin or 0, ev, tag))
+else:  # round 6 on: the step's evidence comes out of the finalisation kernel's tail (dlagp_eval_evidence_device)
+    print("| finalize_rank20 with the level evidence in its tail (no level_evidence launch) | %.1f µs | `%s_kernel_stats.csv` |" % (fin or 0, tag))
 for c, what in ((3, "64 sightlines × {sub-DLA, DLA(1)}: one pair launch"), (4, "one rank's 128 of 1024: null + sub-DLA + DLA(1)"),
                 (5, "one rank's 32 of 256: DLA(1..4), cached levels")):
     x = load("bench_config%d.json" % c)
