@@ -21,6 +21,8 @@
  *   dlagp_batch_*                  the same sweep on HBM-resident samples, one or many
  *                                  sightlines per launch (the reference's per-spectrum loop,
  *                                  run_bayes_select.py:141-189, made a batch)
+ *   dlagp_*eval_evidence_device    ... with the occupation level's evidence from the same launch
+ *                                  sequence (dla_gp.py:155-190)
  *
  * Conventions
  *   - all floating point is IEEE-754 float64; `keep` is one byte per pixel (0/1)

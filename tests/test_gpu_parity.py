@@ -806,6 +806,7 @@ def restore_options():
     set_option("pair_models", 1)
     set_option("level_spread", 1)
     set_option("level_search_groups", 16)
+    set_option("fold_evidence", 1)
 
 
 @pytest.mark.parametrize("shape", [dict(index=4, n_unmasked=1250, n_masked=28, k=20),
@@ -2928,6 +2929,27 @@ def test_level_evidence_from_the_finalisation_kernels_tail(restore_options):
         set_option("fold_evidence", 1)
         np.testing.assert_array_equal(apart, want)
         np.testing.assert_array_equal(apart_ev, want_ev)
+
+    # the kernel's other forms carry the same tail: one lane per sample instead of sixteen (identical bits), and the generic
+    # kernel's partial sums (another kernel's rounding: agreement with its own two launches)
+    S = 1003
+    z, _, nhi = make_qmc_samples(sight, S)
+    mask = (rng.random((1, S)) < 0.2).astype(np.uint8)
+    _, _, sixteen, sixteen_ev = both_ways(dev, 1, S, 1, z, nhi, 0, mask)
+    default = get_option("finalize_row16_blocks")
+    set_option("finalize_row16_blocks", 0)
+    want, want_ev, one_lane, one_lane_ev = both_ways(dev, 1, S, 1, z, nhi, 0, mask)
+    set_option("finalize_row16_blocks", default)
+    assert get_option("last_evidence_folded") == 1
+    np.testing.assert_array_equal(one_lane, sixteen)
+    np.testing.assert_array_equal(one_lane_ev, sixteen_ev)
+    set_option("path", 1)
+    want, want_ev, generic, generic_ev = both_ways(dev, 1, 200, 1, z[:200], nhi[:200], 0, mask[:, :200].copy())
+    assert get_option("last_launch_path") == 1 and get_option("last_evidence_folded") == 1
+    set_option("path", 0)
+    np.testing.assert_array_equal(generic, want)
+    np.testing.assert_allclose(generic_ev, want_ev, rtol=1e-13)
+    np.testing.assert_allclose(generic + np.log(200), sixteen[:, :200] + np.log(S), rtol=1e-9)  # (each minus its own log S)
 
     # every sample masked: an all-NaN level has a NaN evidence (np.nanmax / np.nanmean of nothing)
     S = 500
