@@ -80,7 +80,8 @@ typedef struct dlagp_model dlagp_model; /* the learned GP model (rest-frame grid
 
 /* ABI version of this header; bumped on any signature or status-code change.  2: DLAGP_ENOMEM.  3: near-tie counts of the
  * resampling (dlagp_batch_resample_ties; larger d_cdf_scratch / d_flags of dlagp_level_finish_device), dlagp_prepare_spectrum,
- * dlagp_batch_prepare. */
+ * dlagp_batch_prepare.  (Entry points ADDED without a bump, existing ones unchanged: dlagp_eval_evidence_device,
+ * dlagp_batch_eval_evidence_device.) */
 int dlagp_abi_version(void);
 
 /* Number of visible HIP devices (0 if none / runtime unusable). */
