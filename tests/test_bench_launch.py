@@ -184,3 +184,37 @@ def test_design_tables_render_from_the_committed_profiles():
     missing = [row[:90] for row in rows if row not in design]
     assert not missing, missing
     assert re.search(r"\| step, configs\[1\] \| 0\.\d+ ms", res.stdout)
+
+
+def test_route_a_timeline_reads_a_kernel_trace(tmp_path):
+    """tools/route_a_timeline.py on a synthetic rocprofv3 kernel trace: one chain per interp_model kernel, the device-busy time
+    as the union of the kernels' intervals (a side-stream kernel that overlaps counts once), the stretch to the first
+    accumulate launch and the host's gap between two chains"""
+    import csv
+    import subprocess
+
+    rows, t = [], 0
+    for _ in range(12):
+        names = ["dlagp::copy_segments(CopyTable, unsigned char*)", "dlagp::interp_model(x)", "dlagp::build_shared_operand(y)",
+                 "void dlagp::accumulate_mfma<3, true>(z)", "void dlagp::finalize_rank20<true, true>(z)", "dlagp::level_weights(LevelArgs)"]
+        for k, name in enumerate(names):
+            if k == 3:
+                t += 100_000  # the host's time between the set-up kernels and the first sweep launch
+            rows.append(dict(Start_Timestamp=t, End_Timestamp=t + 20_000, Kernel_Name=name))
+            if k == 4:  # the null model beside the finalisation, on another stream: same interval
+                rows.append(dict(Start_Timestamp=t + 5_000, End_Timestamp=t + 15_000, Kernel_Name="dlagp::accumulate_generic(w)"))
+            t += 20_000
+        t += 300_000
+    trace = tmp_path / "trace.csv"
+    with open(trace, "w", newline="") as fh:
+        writer = csv.DictWriter(fh, fieldnames=list(rows[0]))
+        writer.writeheader()
+        writer.writerows(rows)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "route_a_timeline.py"), str(trace)], capture_output=True,
+                         text=True, check=True).stdout
+    got = json.loads(out)
+    assert got["chains"] == 12 and got["launches_per_chain"] == 7
+    median = got["median_us"]
+    assert median["chain_span"] == 220.0 and median["device_busy_in_chain"] == 120.0 and median["device_idle_in_chain"] == 100.0
+    assert median["first_kernel_to_first_accumulate"] == 160.0 and median["host_gap_between_chains"] == 300.0
+    assert got["idle_in_chain_by_neighbours_us_per_spectrum"] == {"dlagp::build_shared_operand -> dlagp::accumulate_mfma": 100.0}
